@@ -1,0 +1,220 @@
+/* libspacer_hip.so -- C ABI of the MI355X-native SG-RLVR / GRPO hot path.
+ *
+ * The reference (OuyangKun10/SpaceR) has NO native boundary: every tensor op of its per-step hot path runs
+ * inside third-party Python wheels (transformers / flash-attn / deepspeed) called from
+ *   SpaceR-SG-RLVR/src/r1-v/src/open_r1/trainer/SG_RLVR_trainer.py   (abbrev. TR below).
+ * This header is the boundary a maintainer binds instead (ctypes stub: INTEGRATION.md).  Each entry names
+ * the reference call site whose arithmetic it replaces.
+ *
+ * Conventions (all entries):
+ *   - return 0 (SPACER_OK) or a negative SPACER_E* code; spacer_last_error() gives a thread-local message
+ *   - plain device pointers + sizes; no allocation, no ownership transfer, caller owns every buffer
+ *   - asynchronous on `stream` (a hipStream_t passed as void*), no hidden synchronisation
+ *   - bf16 = raw IEEE bfloat16 bits (uint16), row-major, innermost dimension contiguous unless an ld is given
+ *   - no exceptions cross the boundary; re-entrant, no global mutable state
+ */
+#ifndef SPACER_HIP_H
+#define SPACER_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* spacer_stream_t; /* hipStream_t */
+
+enum {
+    SPACER_OK = 0,
+    SPACER_EINVAL = -1,  /* bad argument / unsupported shape */
+    SPACER_ELAUNCH = -2, /* HIP launch failure */
+    SPACER_ENOMEM = -3,  /* caller workspace too small */
+};
+
+enum spacer_act { SPACER_ACT_NONE = 0, SPACER_ACT_QUICK_GELU = 1, SPACER_ACT_GELU_ERF = 2, SPACER_ACT_SILU = 3 };
+
+const char* spacer_last_error(void);
+int spacer_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * GEMM.  C[M,N] = act(alpha * A[M,K] . B[N,K]^T + bias[N]) + residual[M,N]
+ * Replaces every nn.Linear / Conv3d-as-GEMM the reference reaches through TR:357 (model forward) and
+ * TR:463 (generate): ViT patch embed / qkv / proj / fc1 / fc2 / merger, LLM q,k,v,o,gate,up,down, lm_head.
+ * K must be a multiple of 64 (pad the contraction dim with zeros); M, N arbitrary.
+ * out_f32 selects the dtype of C and residual (0 = bf16, 1 = fp32).  residual == C gives C += ...
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct spacer_gemm_epilogue {
+    const void* bias;     /* bf16 [N] or NULL */
+    const void* residual; /* [M, ldr] in the output dtype, or NULL */
+    long ldr;
+    int out_f32;
+    int act;     /* enum spacer_act */
+    float alpha; /* 0 is read as 1 */
+} spacer_gemm_epilogue;
+
+int spacer_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
+                        const spacer_gemm_epilogue* epi, spacer_stream_t stream);
+
+/* Skinny GEMM for the decode loop (M <= 64 rows, weights streamed once from HBM, split-K):
+ * C32[M,N] += A[M,K] . B[N,K]^T  (fp32 atomics; C may be the fp32 residual stream itself).  K % 256 == 0.
+ * epi must be NULL or {out_f32 = 1, residual = C}.  Replaces the per-token projections inside HF
+ * generate's loop (TR:463). */
+int spacer_gemm_skinny_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
+                            const spacer_gemm_epilogue* epi, spacer_stream_t stream);
+
+/* out[C, Rpad] = in[R, C]^T, zero-filling columns R..Rpad-1 (bf16).  Feeds the NT GEMM in backward. */
+int spacer_transpose_bf16(const void* in, long ld_in, void* out, long ld_out, int R, int C, int Rpad,
+                          spacer_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Normalisation (HF Qwen2VLRMSNorm / nn.LayerNorm reached through TR:357).
+ * x may be bf16 or fp32 (x_f32); y is bf16.  rstd/mean are fp32 [rows] saved for backward (may be NULL).
+ * ---------------------------------------------------------------------------------------------- */
+int spacer_rmsnorm_fwd(const void* x, int x_f32, const void* w, void* y, float* rstd, int rows, int cols, float eps,
+                       spacer_stream_t stream);
+/* dx has the dtype of x (dx += ... when dx_accumulate); dw / db are fp32 [cols] and are ACCUMULATED into
+ * (atomics), i.e. they can be the gradient buffers themselves. */
+int spacer_rmsnorm_bwd(const void* x, int x_f32, const void* w, const void* dy, const float* rstd, void* dx,
+                       int dx_accumulate, float* dw, int rows, int cols, spacer_stream_t stream);
+int spacer_layernorm_fwd(const void* x, int x_f32, const void* w, const void* b, void* y, float* mean, float* rstd,
+                         int rows, int cols, float eps, spacer_stream_t stream);
+int spacer_layernorm_bwd(const void* x, int x_f32, const void* w, const void* dy, const float* mean,
+                         const float* rstd, void* dx, int dx_accumulate, float* dw, float* db, int rows, int cols,
+                         spacer_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Rotary embeddings.  cos/sin are fp32 tables [tokens, head_dim] (host builds them from the M-RoPE /
+ * ViT position ids).  x is bf16 [tokens, heads, head_dim] in place: x = x*cos + rot_half(x)*sin in fp32.
+ * inverse != 0 applies the transpose rotation (backward).
+ * ---------------------------------------------------------------------------------------------- */
+int spacer_rope_inplace(void* x, long token_stride, const float* cos_t, const float* sin_t, int tokens, int heads,
+                        int head_dim, int inverse, spacer_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Attention.  Token-packed layout: q [T, Hq, D], k/v [T, Hkv, D] (bf16, strides in elements), o [T, Hq, D].
+ * Work is described by "segments": segment s owns query rows [q_start, q_start+q_len) which attend
+ *   (1) a shared prefix of keys [pre_start, pre_start+pre_len) with no mask, then
+ *   (2) their own keys [q_start, q_start+q_len), causal when `causal` != 0 else full.
+ * ViT per-frame attention (HF vision cu_seqlens) = segments with pre_len 0, causal 0, D = 80.
+ * LLM prefill = one causal segment.  Shared-prefix scoring of K rollouts of one prompt = the prompt as a
+ * causal segment + K segments with pre = the prompt (equal to K independent causal rows, TR:527).
+ * lse (fp32 [Hq, T]) is written for backward.  D in {80, 128}.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct spacer_attn_segment {
+    int q_start, q_len, pre_start, pre_len;
+} spacer_attn_segment;
+
+int spacer_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, long q_stride, long kv_stride,
+                    long o_stride, const spacer_attn_segment* segs_dev, int num_segs, int max_q_len, int T, int Hq,
+                    int Hkv, int D, int causal, float scale, spacer_stream_t stream);
+/* Backward.  dq is bf16 in the layout of q (q_stride); dk/dv are fp32 [T, Hkv, D] contiguous accumulators
+ * ZEROED BY THE CALLER (keys of a shared prompt collect contributions from several segments through
+ * atomics); delta (fp32 [Hq, T]) is scratch.  Segments must partition the tokens by their own ranges. */
+int spacer_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                    float* delta, void* dq, float* dk, float* dv, long q_stride, long kv_stride, long o_stride,
+                    const spacer_attn_segment* segs_dev, int num_segs, int max_q_len, int T, int Hq, int Hkv, int D,
+                    int causal, float scale, spacer_stream_t stream);
+
+/* Decode attention: one new query token per sequence (B sequences), KV = shared prompt KV of the
+ * sequence's prompt (prefix_k/v [n_prompts, Pmax, Hkv, D], length prefix_len[prompt_of[b]]) followed by the
+ * sequence's own tail (tail_k/v [B, Cmax, Hkv, D], length tail_len_dev[0] + 1 -- read from device memory so
+ * the step can be replayed from a hipGraph).  D = 128. */
+int spacer_attn_decode(const void* q, const void* prefix_k, const void* prefix_v, const int* prefix_len,
+                       const int* prompt_of, const void* tail_k, const void* tail_v, const int* tail_len_dev, void* o,
+                       int B, int Pmax, int Cmax, int Hq, int Hkv, int D, float scale, spacer_stream_t stream);
+
+/* Decode-step helpers (all read the step / tail length from device memory so that one decode step can be
+ * captured in a hipGraph and replayed):
+ *   rope table: cos/sin fp32 [B, D] for text position pos_base[b] + *step_dev (M-RoPE rows coincide for text)
+ *   qkv finish: acc32 [B,(Hq+2Hkv)*D] (+bias, rotary on q,k) -> q_out bf16 [B,Hq*D]; k,v appended to the tail
+ *               cache [B,Cmax,Hkv,D] at position *tail_len_dev; acc32 is re-zeroed for the next layer
+ *   swiglu_f32: y bf16 [B,inter] = silu(gate)*up from acc32 [B, 2*inter] (re-zeroed) */
+int spacer_decode_rope_table(const int* pos_base, const int* step_dev, float theta, float* cos_t, float* sin_t, int B,
+                             int D, spacer_stream_t stream);
+int spacer_decode_qkv_finish(float* acc32, const void* bias, const float* cos_t, const float* sin_t, void* q_out,
+                             void* tail_k, void* tail_v, const int* tail_len_dev, int B, int Hq, int Hkv, int D, int Cmax,
+                             spacer_stream_t stream);
+int spacer_swiglu_f32_fwd(float* acc32, void* y, int B, int inter, spacer_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Element-wise pieces of the MLPs and residual stream.
+ * ---------------------------------------------------------------------------------------------- */
+/* y = silu(gate) * up ; gate/up are the two halves of gu [rows, 2*inter] (gate first) */
+int spacer_swiglu_fwd(const void* gu, void* y, int rows, int inter, spacer_stream_t stream);
+/* dgu from dy (bf16) and gu */
+int spacer_swiglu_bwd(const void* gu, const void* dy, void* dgu, int rows, int inter, spacer_stream_t stream);
+/* y = act(x) ; dx = dy * act'(x)   (act in {QUICK_GELU, GELU_ERF}) */
+int spacer_act_fwd(const void* x, void* y, long n, int act, spacer_stream_t stream);
+int spacer_act_bwd(const void* x, const void* dy, void* dx, long n, int act, spacer_stream_t stream);
+/* db[cols] (fp32, +=) = column sums of dy [rows, cols] bf16 */
+int spacer_bias_grad(const void* dy, long ld, float* db, int rows, int cols, spacer_stream_t stream);
+/* out_bf16 = f32 (cast), and f32 accumulate/copy helpers for attention grads */
+int spacer_cast_f32_to_bf16(const float* in, void* out, long n, spacer_stream_t stream);
+int spacer_cast_bf16_to_f32(const void* in, float* out, long n, spacer_stream_t stream);
+int spacer_cast_f32_to_bf16_strided(const float* in, long ld_in, void* out, long ld_out, int rows, int cols,
+                                    spacer_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Embedding gather (+ video scatter) and its backward.  HF embed_tokens + masked_scatter (TR:357 path).
+ * out fp32 [T, H] (the residual stream is fp32).  Tokens with ids[t] == video_token_id take row
+ * video[vis_index++] instead (video rows are consumed in order).
+ * ---------------------------------------------------------------------------------------------- */
+int spacer_embed_fwd(const int64_t* ids, const void* table, const void* video, const int* video_row_of_token,
+                     float* out, int T, int H, spacer_stream_t stream);
+/* d_table (fp32 [V,H]) += rows of d_out for text tokens; d_video (fp32) = rows for video tokens */
+int spacer_embed_bwd(const int64_t* ids, const int* video_row_of_token, const float* d_out, float* d_table,
+                     float* d_video, int T, int H, spacer_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Frames -> normalised patch rows (HF Qwen2VLVideoProcessor rescale + CLIP normalise + patchify,
+ * reached through TR:417-425).  frames uint8 [F, 3, Hpx, Wpx]; out bf16 [gt*gh*gw, Kpad] in
+ * merge-block-major token order, feature order (c, tp, py, px), zero-padded from 1176 to Kpad.
+ * ---------------------------------------------------------------------------------------------- */
+int spacer_patchify(const uint8_t* frames, void* out, int F, int Hpx, int Wpx, int patch, int tpatch, int merge,
+                    int Kpad, spacer_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Per-token log-probs (TR:353-366) from fp32 logits rows: logp[r] = logits[r, tgt[r]] - logsumexp(logits[r,:]).
+ * Also returns lse.  Backward overwrites logits in place with dlogits = (softmax - onehot) * g[r] as bf16
+ * into `dlogits` ([rows, ldd] bf16) for the lm_head backward GEMMs.
+ * ---------------------------------------------------------------------------------------------- */
+int spacer_logprob_fwd(const float* logits, long ld, const int64_t* targets, float* logp, float* lse, int rows,
+                       int vocab, spacer_stream_t stream);
+int spacer_logprob_bwd(const float* logits, long ld, const int64_t* targets, const float* lse, const float* g,
+                       void* dlogits, long ldd, int rows, int vocab, spacer_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GRPO loss (TR:551-552, 640-643, 682): per-token k3 KL, clipped-free ratio loss, masked row means.
+ * logp/ref_logp fp32 [G, C], mask int32 [G, C], adv fp32 [G].  Writes loss[0], mean_kl[0] and
+ * dlogp fp32 [G, C] = d loss / d logp.  rows with an all-zero mask contribute NaN exactly as the reference.
+ * ---------------------------------------------------------------------------------------------- */
+int spacer_grpo_loss(const float* logp, const float* ref_logp, const float* adv, const int* mask, float beta,
+                     float* loss, float* mean_kl, float* dlogp, int G, int C, spacer_stream_t stream);
+
+/* First-EOS completion mask (TR:493-498). ids int64 [G, C] -> mask int32 [G, C], lengths int32 [G]. */
+int spacer_completion_mask(const int64_t* ids, int eos_id, int* mask, int* lengths, int G, int C,
+                           spacer_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Sampling (HF generate with do_sample, temperature 1, top_k, top_p; TR:277-284).  logits fp32 [B, vocab].
+ * One token per row into out_ids[b].  finished[b] != 0 rows emit pad_id.  Philox counter = (seed, step, b).
+ * suppress_eos != 0 forbids eos_id (fixed-length throughput mode).
+ * ---------------------------------------------------------------------------------------------- */
+int spacer_sample_top_p(const float* logits, long ld, int B, int vocab, int top_k, float top_p, float temperature,
+                        uint64_t seed, const int* step_dev, int eos_id, int pad_id, int suppress_eos, int* finished,
+                        int64_t* out_ids, float* out_logp, void* workspace, long workspace_bytes,
+                        spacer_stream_t stream);
+long spacer_sample_workspace_bytes(int B, int vocab);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimizer: global grad-norm (sum of squares into acc[0]) and fused AdamW on fp32 master weights with
+ * bf16 shadow refresh.  Replaces DeepSpeed's clip + AdamW step behind HF Trainer.training_step.
+ * ---------------------------------------------------------------------------------------------- */
+int spacer_sumsq_f32(const float* g, long n, float* acc, spacer_stream_t stream);
+int spacer_adamw_step(float* master, void* shadow_bf16, float* m, float* v, const float* grad, long n, float lr,
+                      float beta1, float beta2, float eps, float weight_decay, float bias_c1, float bias_c2,
+                      const float* sumsq_dev, float max_norm, float grad_scale, spacer_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPACER_HIP_H */

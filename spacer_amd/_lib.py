@@ -1,0 +1,97 @@
+"""ctypes binding of libspacer_hip.so (the C-ABI declared in include/spacer_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing the import of anything that needs
+it raises, loudly.  Build it with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C spacer_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspacer_hip.so")
+
+SPACER_ACT_NONE, SPACER_ACT_QUICK_GELU, SPACER_ACT_GELU_ERF, SPACER_ACT_SILU = 0, 1, 2, 3
+
+
+class SpacerError(RuntimeError):
+    pass
+
+
+class GemmEpilogue(C.Structure):
+    _fields_ = [("bias", C.c_void_p), ("residual", C.c_void_p), ("ldr", C.c_long), ("out_f32", C.c_int),
+                ("act", C.c_int), ("alpha", C.c_float)]
+
+
+class AttnSegment(C.Structure):
+    _fields_ = [("q_start", C.c_int), ("q_len", C.c_int), ("pre_start", C.c_int), ("pre_len", C.c_int)]
+
+
+_p, _i, _l, _f, _u64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint64
+
+# name -> argtypes; every entry returns int.  Kept in the order of include/spacer_hip.h.
+SIGNATURES = {
+    "spacer_gemm_bf16_nt": [_p, _l, _p, _l, _p, _l, _i, _i, _i, C.POINTER(GemmEpilogue), _p],
+    "spacer_gemm_skinny_bf16": [_p, _l, _p, _l, _p, _l, _i, _i, _i, C.POINTER(GemmEpilogue), _p],
+    "spacer_transpose_bf16": [_p, _l, _p, _l, _i, _i, _i, _p],
+    "spacer_rmsnorm_fwd": [_p, _i, _p, _p, _p, _i, _i, _f, _p],
+    "spacer_rmsnorm_bwd": [_p, _i, _p, _p, _p, _p, _i, _p, _i, _i, _p],
+    "spacer_layernorm_fwd": [_p, _i, _p, _p, _p, _p, _p, _i, _i, _f, _p],
+    "spacer_layernorm_bwd": [_p, _i, _p, _p, _p, _p, _p, _i, _p, _p, _i, _i, _p],
+    "spacer_rope_inplace": [_p, _l, _p, _p, _i, _i, _i, _i, _p],
+    "spacer_attn_fwd": [_p, _p, _p, _p, _p, _l, _l, _l, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p],
+    "spacer_attn_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _l, _l, _l, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p],
+    "spacer_attn_decode": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p],
+    "spacer_swiglu_fwd": [_p, _p, _i, _i, _p],
+    "spacer_swiglu_bwd": [_p, _p, _p, _i, _i, _p],
+    "spacer_act_fwd": [_p, _p, _l, _i, _p],
+    "spacer_act_bwd": [_p, _p, _p, _l, _i, _p],
+    "spacer_bias_grad": [_p, _l, _p, _i, _i, _p],
+    "spacer_cast_f32_to_bf16": [_p, _p, _l, _p],
+    "spacer_cast_bf16_to_f32": [_p, _p, _l, _p],
+    "spacer_cast_f32_to_bf16_strided": [_p, _l, _p, _l, _i, _i, _p],
+    "spacer_embed_fwd": [_p, _p, _p, _p, _p, _i, _i, _p],
+    "spacer_embed_bwd": [_p, _p, _p, _p, _p, _i, _i, _p],
+    "spacer_patchify": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "spacer_logprob_fwd": [_p, _l, _p, _p, _p, _i, _i, _p],
+    "spacer_logprob_bwd": [_p, _l, _p, _p, _p, _p, _l, _i, _i, _p],
+    "spacer_grpo_loss": [_p, _p, _p, _p, _f, _p, _p, _p, _i, _i, _p],
+    "spacer_completion_mask": [_p, _i, _p, _p, _i, _i, _p],
+    "spacer_sample_top_p": [_p, _l, _i, _i, _i, _f, _f, _u64, _p, _i, _i, _i, _p, _p, _p, _p, _l, _p],
+    "spacer_decode_rope_table": [_p, _p, _f, _p, _p, _i, _i, _p],
+    "spacer_decode_qkv_finish": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "spacer_swiglu_f32_fwd": [_p, _p, _i, _i, _p],
+    "spacer_sumsq_f32": [_p, _l, _p, _p],
+    "spacer_adamw_step": [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _f, _p, _f, _f, _p],
+}
+OTHER_SYMBOLS = ["spacer_last_error", "spacer_version", "spacer_sample_workspace_bytes"]
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load (once) and type the shared library.  Raises SpacerError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SpacerError(
+            f"{LIB_PATH} not found: the HIP extension is not built (run __graft_entry__.build()). "
+            "spacer_amd has no CPU fallback for the hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    lib.spacer_last_error.restype = C.c_char_p
+    lib.spacer_version.restype = C.c_int
+    lib.spacer_sample_workspace_bytes.argtypes = [_i, _i]
+    lib.spacer_sample_workspace_bytes.restype = C.c_long
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise SpacerError(f"{what} failed (code {rc}): {load().spacer_last_error().decode()}")

@@ -1,0 +1,477 @@
+// Flash-style attention for gfx950 (MFMA 16x16x32 bf16, LDS-staged tiles, online softmax): forward, and a
+// two-kernel backward (dQ by query-block owners, dK/dV by key-block owners).
+//
+// One set of kernels serves the three attention shapes on the SG-RLVR hot path (include/spacer_hip.h
+// "segments"):
+//   * ViT per-temporal-grid non-causal attention, head_dim 80 (HF VisionAttention via cu_seqlens)
+//   * LLM causal GQA prefill, head_dim 128
+//   * shared-prefix scoring: K rollouts attend one prompt's keys + their own causal keys
+//     (== K independent causal rows prompt+completion_k, SG_RLVR_trainer.py:527, without re-running the prompt)
+//
+// Forward decomposition: workgroup = 4 waves = 128 query rows of one (segment, q-head); each wave owns 32 rows
+// (two 16-column MFMA blocks).  Per 64-key tile:
+//   S^T = K . Q^T      (A = K frag from LDS, B = Q frag held in registers)   -> lane holds S^T[key][q = lane&15]
+//   online softmax per q column: in-lane max over 16 scores + 2 cross-lane shuffles (lanes l, l^16, l^32, l^48)
+//   O^T += V^T . P^T   (A = V^T frag from the transposed LDS tile, B = P^T straight from the S^T registers:
+//                       the contraction order over keys is permuted identically on both operands, so no
+//                       lane exchange / LDS round trip is needed for P)
+// O^T keeps q on lane&15, the index the softmax statistics live on, so rescaling is a per-lane multiply.
+// K and V tiles are prefetched into registers one tile ahead (global loads stay in flight under the MFMAs)
+// and written to LDS after the barrier (V is transposed on the way).
+#include "attn_common.h"
+
+namespace {
+
+constexpr int BQ = 128;   // query rows per workgroup (fwd, dQ)
+constexpr int BKV = 64;   // keys per tile
+
+struct AttnArgs {
+    const bf16_t* q; const bf16_t* k; const bf16_t* v; bf16_t* o; float* lse;
+    const bf16_t* d_o; float* delta; bf16_t* dq; float* dk; float* dv;
+    long q_stride, kv_stride, o_stride;
+    const spacer_attn_segment* segs;
+    int num_segs, nqb, T, Hq, Hkv, causal;
+    float scale;
+};
+
+// tile t of a query block's key list: prefix tiles first, then own keys
+struct KeyTile { int start_abs, len, rel0; bool own; };
+__device__ __forceinline__ KeyTile key_tile(const spacer_attn_segment& seg, int n_pre, int own_len, int t) {
+    KeyTile kt;
+    if (t < n_pre) { kt.own = false; kt.rel0 = t * BKV; kt.start_abs = seg.pre_start; kt.len = seg.pre_len; }
+    else { kt.own = true; kt.rel0 = (t - n_pre) * BKV; kt.start_abs = seg.q_start; kt.len = own_len; }
+    return kt;
+}
+
+// ================================================================================================ forward
+template <int D>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
+    constexpr int DC = (D + 31) / 32;      // 32-wide contraction chunks for QK^T (D=80 -> 3, zero padded)
+    constexpr int DF = D / 16;             // 16-wide d blocks of O^T
+    __shared__ __attribute__((aligned(16))) char smem[AT_RM_BYTES + AT_T_BYTES(D)];
+    char* k_lds = smem;
+    char* vt_lds = smem + AT_RM_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int seg_id = blockIdx.x / a.nqb, qb = blockIdx.x % a.nqb;
+    const int h = blockIdx.y, hk = h / (a.Hq / a.Hkv);
+    const spacer_attn_segment seg = a.segs[seg_id];
+    const int qb0 = qb * BQ;
+    if (qb0 >= seg.q_len) return;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int wq0 = qb0 + wave * 32;
+
+    bf16x8 qf[2][DC];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        int qi = wq0 + f * 16 + l15;
+        qi = qi < seg.q_len ? qi : seg.q_len - 1;
+        const bf16_t* qp = a.q + (long)(seg.q_start + qi) * a.q_stride + (long)h * D;
+#pragma unroll
+        for (int dc = 0; dc < DC; ++dc) qf[f][dc] = frag_global<D>(qp, dc, lane);
+    }
+
+    f32x4 oacc[2][DF];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int d = 0; d < DF; ++d) oacc[f][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+
+    const int own_len = a.causal ? min(seg.q_len, qb0 + BQ) : seg.q_len;
+    const int n_pre = (seg.pre_len + BKV - 1) / BKV, n_tiles = n_pre + (own_len + BKV - 1) / BKV;
+
+    uint4 kreg[4], vreg[4];
+    {
+        const KeyTile kt = key_tile(seg, n_pre, own_len, 0);
+        const long off = (long)(kt.start_abs + kt.rel0) * a.kv_stride + (long)hk * D;
+        tile_load<D>(kreg, a.k + off, a.kv_stride, kt.len - kt.rel0, tid);
+        tile_load<D>(vreg, a.v + off, a.kv_stride, kt.len - kt.rel0, tid);
+    }
+    for (int t = 0; t < n_tiles; ++t) {
+        const KeyTile kt = key_tile(seg, n_pre, own_len, t);
+        __syncthreads();
+        tile_store<D, true, false>(kreg, k_lds, nullptr, tid);
+        tile_store<D, false, true>(vreg, nullptr, vt_lds, tid);
+        __syncthreads();
+        if (t + 1 < n_tiles) {
+            const KeyTile nx = key_tile(seg, n_pre, own_len, t + 1);
+            const long off = (long)(nx.start_abs + nx.rel0) * a.kv_stride + (long)hk * D;
+            tile_load<D>(kreg, a.k + off, a.kv_stride, nx.len - nx.rel0, tid);
+            tile_load<D>(vreg, a.v + off, a.kv_stride, nx.len - nx.rel0, tid);
+        }
+        // wave-level skip: causal tile entirely above this wave's last row
+        if (kt.own && a.causal && kt.rel0 > wq0 + 31) continue;
+
+        // ---- S^T = K . Q^T : st[kf][f] holds keys kf*16 + g*4 + r for q column f*16 + l15
+        f32x4 st[4][2];
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf) {
+            st[kf][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; st[kf][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dc = 0; dc < DC; ++dc) {
+                const bf16x8 kfr = frag_rm(k_lds, kf, dc, lane);
+                st[kf][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[0][dc], st[kf][0], 0, 0, 0);
+                st[kf][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[1][dc], st[kf][1], 0, 0, 0);
+            }
+        }
+
+        // ---- mask + online softmax (per q column = per lane&15, replicated over the 4 lane groups)
+        bf16x8 pf[2][2];   // [f][32-key half]
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const int qi = wq0 + f * 16 + l15;           // query index relative to the segment
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kr = kt.rel0 + kf * 16 + g * 4 + r;
+                    float s = st[kf][f][r] * a.scale;
+                    const bool ok = kr < kt.len && !(kt.own && a.causal && kr > qi);
+                    s = ok ? s : -INFINITY;
+                    st[kf][f][r] = s;
+                    mx = fmaxf(mx, s);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[f], mx);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __expf(m_run[f] - m_use);     // m_run = -inf -> 0
+            float psum = 0.f;
+            float p[4][4];
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { p[kf][r] = __expf(st[kf][f][r] - m_use); psum += p[kf][r]; }
+            l_run[f] = l_run[f] * alpha + psum;
+            m_run[f] = m_new;
+#pragma unroll
+            for (int d = 0; d < DF; ++d) oacc[f][d] *= alpha;
+            pf[f][0] = pack_slots(p[0], p[1]);
+            pf[f][1] = pack_slots(p[2], p[3]);
+        }
+
+        // ---- O^T += V^T . P^T
+#pragma unroll
+        for (int df = 0; df < DF; ++df)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const bf16x8 vf = frag_t(vt_lds, df, c, lane);
+                oacc[0][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[0][c], oacc[0][df], 0, 0, 0);
+                oacc[1][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[1][c], oacc[1][df], 0, 0, 0);
+            }
+    }
+
+    // ---- epilogue: O[q][d] = O^T[d][q] / l ; lane owns q = l15, d = df*16 + g*4 + r (4 consecutive dims)
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        float l = l_run[f];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const int qi = wq0 + f * 16 + l15;
+        if (qi >= seg.q_len) continue;
+        const float inv = 1.f / l;
+        const long tok = seg.q_start + qi;
+        bf16_t* op = a.o + tok * a.o_stride + (long)h * D;
+#pragma unroll
+        for (int df = 0; df < DF; ++df) {
+            const f32x4 v = oacc[f][df];
+            *(uint2*)(op + df * 16 + g * 4) = make_uint2(pack_bf2(v[0] * inv, v[1] * inv), pack_bf2(v[2] * inv, v[3] * inv));
+        }
+        if (a.lse && g == 0) a.lse[(long)h * a.T + tok] = m_run[f] + logf(l);
+    }
+}
+
+// ================================================================================================ backward
+// delta[h][t] = sum_d dO[t,h,d] * O[t,h,d]
+template <int D>
+__global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs a) {
+    constexpr int PER = D / 8;                       // 16-byte chunks per (token, head)
+    constexpr int GRP = (PER <= 8) ? 8 : 16;         // lanes cooperating on one (token, head)
+    const long total = (long)a.T * a.Hq;
+    const int sub = threadIdx.x % GRP;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) / GRP; i < total; i += (long)gridDim.x * 256 / GRP) {
+        const long t = i / a.Hq; const int h = (int)(i % a.Hq);   // group-uniform: all GRP lanes share i
+        float s = 0.f;
+        if (sub < PER) {
+            const uint4 x = *(const uint4*)(a.o + t * a.o_stride + (long)h * D + sub * 8);
+            const uint4 y = *(const uint4*)(a.d_o + t * a.o_stride + (long)h * D + sub * 8);
+            s = bf_lo(x.x) * bf_lo(y.x) + bf_hi(x.x) * bf_hi(y.x) + bf_lo(x.y) * bf_lo(y.y) + bf_hi(x.y) * bf_hi(y.y) +
+                bf_lo(x.z) * bf_lo(y.z) + bf_hi(x.z) * bf_hi(y.z) + bf_lo(x.w) * bf_lo(y.w) + bf_hi(x.w) * bf_hi(y.w);
+        }
+#pragma unroll
+        for (int o = GRP / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (sub == 0) a.delta[(long)h * a.T + t] = s;
+    }
+}
+
+// ---- dQ: same decomposition as forward; per key tile
+//   S^T = K Q^T ; P^T = exp(scale S^T - lse[q]) ; dP^T = V dO^T ; dS^T = P^T (dP^T - delta[q]) scale
+//   dQ^T += K^T dS^T   (A = K^T frag from the transposed image, B = dS^T from registers)
+template <int D>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
+    constexpr int DC = (D + 31) / 32, DF = D / 16;
+    __shared__ __attribute__((aligned(16))) char smem[2 * AT_RM_BYTES + AT_T_BYTES(D)];
+    char* k_lds = smem; char* v_lds = smem + AT_RM_BYTES; char* kt_lds = smem + 2 * AT_RM_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int seg_id = blockIdx.x / a.nqb, qb = blockIdx.x % a.nqb;
+    const int h = blockIdx.y, hk = h / (a.Hq / a.Hkv);
+    const spacer_attn_segment seg = a.segs[seg_id];
+    const int qb0 = qb * BQ;
+    if (qb0 >= seg.q_len) return;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int wq0 = qb0 + wave * 32;
+
+    bf16x8 qf[2][DC], dof[2][DC];
+    float lse_q[2], dl_q[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        int qi = wq0 + f * 16 + l15;
+        qi = qi < seg.q_len ? qi : seg.q_len - 1;
+        const long tok = seg.q_start + qi;
+        const bf16_t* qp = a.q + tok * a.q_stride + (long)h * D;
+        const bf16_t* dp = a.d_o + tok * a.o_stride + (long)h * D;
+#pragma unroll
+        for (int dc = 0; dc < DC; ++dc) { qf[f][dc] = frag_global<D>(qp, dc, lane); dof[f][dc] = frag_global<D>(dp, dc, lane); }
+        lse_q[f] = a.lse[(long)h * a.T + tok];
+        dl_q[f] = a.delta[(long)h * a.T + tok];
+    }
+    f32x4 acc[2][DF];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int d = 0; d < DF; ++d) acc[f][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int own_len = a.causal ? min(seg.q_len, qb0 + BQ) : seg.q_len;
+    const int n_pre = (seg.pre_len + BKV - 1) / BKV, n_tiles = n_pre + (own_len + BKV - 1) / BKV;
+
+    for (int t = 0; t < n_tiles; ++t) {
+        const KeyTile kt = key_tile(seg, n_pre, own_len, t);
+        uint4 kreg[4], vreg[4];
+        const long off = (long)(kt.start_abs + kt.rel0) * a.kv_stride + (long)hk * D;
+        tile_load<D>(kreg, a.k + off, a.kv_stride, kt.len - kt.rel0, tid);
+        tile_load<D>(vreg, a.v + off, a.kv_stride, kt.len - kt.rel0, tid);
+        __syncthreads();
+        tile_store<D, true, true>(kreg, k_lds, kt_lds, tid);
+        tile_store<D, true, false>(vreg, v_lds, nullptr, tid);
+        __syncthreads();
+        if (kt.own && a.causal && kt.rel0 > wq0 + 31) continue;
+
+        bf16x8 dsf[2][2];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            f32x4 st[4], dp[4];
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf) {
+                st[kf] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[kf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int dc = 0; dc < DC; ++dc) {
+                    st[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rm(k_lds, kf, dc, lane), qf[f][dc], st[kf], 0, 0, 0);
+                    dp[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rm(v_lds, kf, dc, lane), dof[f][dc], dp[kf], 0, 0, 0);
+                }
+            }
+            const int qi = wq0 + f * 16 + l15;
+            float ds[4][4];
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kr = kt.rel0 + kf * 16 + g * 4 + r;
+                    const bool ok = kr < kt.len && !(kt.own && a.causal && kr > qi);
+                    const float p = ok ? __expf(st[kf][r] * a.scale - lse_q[f]) : 0.f;
+                    ds[kf][r] = p * (dp[kf][r] - dl_q[f]) * a.scale;
+                }
+            dsf[f][0] = pack_slots(ds[0], ds[1]);
+            dsf[f][1] = pack_slots(ds[2], ds[3]);
+        }
+#pragma unroll
+        for (int df = 0; df < DF; ++df)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const bf16x8 ktf = frag_t(kt_lds, df, c, lane);
+                acc[0][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[0][c], acc[0][df], 0, 0, 0);
+                acc[1][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[1][c], acc[1][df], 0, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const int qi = wq0 + f * 16 + l15;
+        if (qi >= seg.q_len) continue;
+        bf16_t* op = a.dq + (long)(seg.q_start + qi) * a.q_stride + (long)h * D;
+#pragma unroll
+        for (int df = 0; df < DF; ++df) {
+            const f32x4 v = acc[f][df];
+            *(uint2*)(op + df * 16 + g * 4) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+        }
+    }
+}
+
+// ---- dK/dV: workgroup = 64 keys of segment `ks` (own range) x kv head x ONE attending segment `qs`;
+// wave w owns keys w*16..w*16+15 (K, V fragments in registers).  For every q-head of the GQA group and
+// every 64-row query tile of `qs` that can see these keys:
+//   S = Q K^T ; P = exp(scale S - lse[q]) ; dP = dO V^T ; dS = P (dP - delta[q]) scale
+//   dV^T += dO^T P   ;   dK^T += Q^T dS          (A = transposed Q / dO image, B = P / dS from registers)
+// Results are added to fp32 dk/dv with atomics (several attending segments share a prompt's keys).
+template <int D>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
+    constexpr int DC = (D + 31) / 32, DF = D / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 RM + 2 T images + 512 B of row statistics
+    char* q_lds = smem; char* do_lds = smem + AT_RM_BYTES;
+    char* qt_lds = smem + 2 * AT_RM_BYTES; char* dot_lds = qt_lds + AT_T_BYTES(D);
+    float* stat = (float*)(dot_lds + AT_T_BYTES(D));   // [0..63] lse, [64..127] delta
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nkb = a.nqb;                              // key blocks per segment (host passes ceil(max_q_len/64))
+    const int ks_id = blockIdx.x / nkb, kb = blockIdx.x % nkb, hk = blockIdx.y, qs_id = blockIdx.z;
+    const spacer_attn_segment ks = a.segs[ks_id], qs = a.segs[qs_id];
+    const int kb0 = kb * BKV;
+    if (kb0 >= ks.q_len) return;
+    const int key_abs0 = ks.q_start + kb0;
+    const bool own = (ks_id == qs_id);
+    // valid key window [kv_lo, kv_hi) in absolute token index for this attending segment
+    int kv_lo = key_abs0, kv_hi = min(key_abs0 + BKV, ks.q_start + ks.q_len);
+    if (!own) {
+        kv_lo = max(kv_lo, qs.pre_start); kv_hi = min(kv_hi, qs.pre_start + qs.pre_len);
+        if (kv_lo >= kv_hi) return;
+    }
+    const int l15 = lane & 15, g = lane >> 4;
+    const int my_key_abs = key_abs0 + wave * 16 + l15;        // key this lane's column refers to
+    const int my_key_c = min(my_key_abs, ks.q_start + ks.q_len - 1);
+    const bool key_ok = my_key_abs >= kv_lo && my_key_abs < kv_hi;
+    const int my_key_rel = kb0 + wave * 16 + l15;
+
+    bf16x8 kf[DC], vf[DC];
+    {
+        const bf16_t* kp = a.k + (long)my_key_c * a.kv_stride + (long)hk * D;
+        const bf16_t* vp = a.v + (long)my_key_c * a.kv_stride + (long)hk * D;
+#pragma unroll
+        for (int dc = 0; dc < DC; ++dc) { kf[dc] = frag_global<D>(kp, dc, lane); vf[dc] = frag_global<D>(vp, dc, lane); }
+    }
+    f32x4 dka[DF], dva[DF];
+#pragma unroll
+    for (int d = 0; d < DF; ++d) { dka[d] = (f32x4){0.f, 0.f, 0.f, 0.f}; dva[d] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    const int q_first = (own && a.causal) ? (kb0 / BKV) * BKV : 0;   // first query row that can see key kb0
+    const int rep = a.Hq / a.Hkv;
+    for (int hh = 0; hh < rep; ++hh) {
+        const int h = hk * rep + hh;
+        for (int q0 = q_first; q0 < qs.q_len; q0 += BKV) {
+            uint4 qreg[4], dreg[4];
+            const long tok0 = qs.q_start + q0;
+            tile_load<D>(qreg, a.q + tok0 * a.q_stride + (long)h * D, a.q_stride, qs.q_len - q0, tid);
+            tile_load<D>(dreg, a.d_o + tok0 * a.o_stride + (long)h * D, a.o_stride, qs.q_len - q0, tid);
+            __syncthreads();
+            tile_store<D, true, true>(qreg, q_lds, qt_lds, tid);
+            tile_store<D, true, true>(dreg, do_lds, dot_lds, tid);
+            if (tid < 128) {
+                const int r = tid & 63;
+                const long tk = min(tok0 + r, (long)qs.q_start + qs.q_len - 1);
+                stat[tid] = (tid < 64 ? a.lse : a.delta)[(long)h * a.T + tk];
+            }
+            __syncthreads();
+
+            float pv[4][4], dsv[4][4];
+#pragma unroll
+            for (int qf = 0; qf < 4; ++qf) {
+                f32x4 st = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int dc = 0; dc < DC; ++dc) {
+                    st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rm(q_lds, qf, dc, lane), kf[dc], st, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rm(do_lds, qf, dc, lane), vf[dc], dp, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qr = qf * 16 + g * 4 + r, qi = q0 + qr;     // lane holds S[q = qr][key = l15]
+                    const bool ok = key_ok && qi < qs.q_len && !(own && a.causal && my_key_rel > qi);
+                    const float p = ok ? __expf(st[r] * a.scale - stat[qr]) : 0.f;
+                    pv[qf][r] = p;
+                    dsv[qf][r] = p * (dp[r] - stat[64 + qr]) * a.scale;
+                }
+            }
+            const bf16x8 pf0 = pack_slots(pv[0], pv[1]), pf1 = pack_slots(pv[2], pv[3]);
+            const bf16x8 sf0 = pack_slots(dsv[0], dsv[1]), sf1 = pack_slots(dsv[2], dsv[3]);
+#pragma unroll
+            for (int df = 0; df < DF; ++df) {
+                dva[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t(dot_lds, df, 0, lane), pf0, dva[df], 0, 0, 0);
+                dva[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t(dot_lds, df, 1, lane), pf1, dva[df], 0, 0, 0);
+                dka[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t(qt_lds, df, 0, lane), sf0, dka[df], 0, 0, 0);
+                dka[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t(qt_lds, df, 1, lane), sf1, dka[df], 0, 0, 0);
+            }
+        }
+    }
+    // lane holds dK^T / dV^T [d = df*16 + g*4 + r][key = l15]
+    if (key_ok) {
+        float* kp = a.dk + ((long)my_key_abs * a.Hkv + hk) * D;
+        float* vp = a.dv + ((long)my_key_abs * a.Hkv + hk) * D;
+#pragma unroll
+        for (int df = 0; df < DF; ++df)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                atomicAdd(kp + df * 16 + g * 4 + r, dka[df][r]);
+                atomicAdd(vp + df * 16 + g * 4 + r, dva[df][r]);
+            }
+    }
+}
+
+int check_common(const char* who, long q_stride, long kv_stride, long o_stride, int Hq, int Hkv, int D) {
+    SP_REQUIRE(D == 80 || D == 128, SPACER_EINVAL, "%s: head_dim %d unsupported (80 or 128)", who, D);
+    SP_REQUIRE(Hkv > 0 && Hq % Hkv == 0, SPACER_EINVAL, "%s: Hq=%d not a multiple of Hkv=%d", who, Hq, Hkv);
+    SP_REQUIRE(q_stride % 8 == 0 && kv_stride % 8 == 0 && o_stride % 8 == 0, SPACER_EINVAL,
+               "%s: token strides must keep 16-byte aligned rows", who);
+    return SPACER_OK;
+}
+
+}  // namespace
+
+extern "C" int spacer_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, long q_stride,
+                               long kv_stride, long o_stride, const spacer_attn_segment* segs_dev, int num_segs,
+                               int max_q_len, int T, int Hq, int Hkv, int D, int causal, float scale,
+                               spacer_stream_t stream) {
+    if (int rc = check_common("attn_fwd", q_stride, kv_stride, o_stride, Hq, Hkv, D)) return rc;
+    if (num_segs <= 0 || max_q_len <= 0) return SPACER_OK;
+    AttnArgs a = {};
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (bf16_t*)o; a.lse = lse;
+    a.q_stride = q_stride; a.kv_stride = kv_stride; a.o_stride = o_stride; a.segs = segs_dev; a.num_segs = num_segs;
+    a.nqb = cdiv(max_q_len, BQ); a.T = T; a.Hq = Hq; a.Hkv = Hkv; a.causal = causal; a.scale = scale;
+    const dim3 grid(num_segs * a.nqb, Hq);
+    if (D == 128) hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(attn_fwd_kernel<80>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    SP_CHECK_LAUNCH();
+    return SPACER_OK;
+}
+
+extern "C" int spacer_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                               const float* lse, float* delta, void* dq, float* dk, float* dv, long q_stride,
+                               long kv_stride, long o_stride, const spacer_attn_segment* segs_dev, int num_segs,
+                               int max_q_len, int T, int Hq, int Hkv, int D, int causal, float scale,
+                               spacer_stream_t stream) {
+    if (int rc = check_common("attn_bwd", q_stride, kv_stride, o_stride, Hq, Hkv, D)) return rc;
+    if (num_segs <= 0 || max_q_len <= 0) return SPACER_OK;
+    AttnArgs a = {};
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (bf16_t*)o; a.lse = (float*)lse;
+    a.d_o = (const bf16_t*)d_o; a.delta = delta; a.dq = (bf16_t*)dq; a.dk = dk; a.dv = dv;
+    a.q_stride = q_stride; a.kv_stride = kv_stride; a.o_stride = o_stride; a.segs = segs_dev; a.num_segs = num_segs;
+    a.T = T; a.Hq = Hq; a.Hkv = Hkv; a.causal = causal; a.scale = scale;
+    hipStream_t s = (hipStream_t)stream;
+    const int dgrid = (int)(((long)T * Hq * 16 + 255) / 256 < 4096 ? ((long)T * Hq * 16 + 255) / 256 : 4096);
+    a.nqb = cdiv(max_q_len, BQ);
+    const dim3 qgrid(num_segs * a.nqb, Hq);
+    AttnArgs b = a;
+    b.nqb = cdiv(max_q_len, BKV);
+    const dim3 kgrid(num_segs * b.nqb, Hkv, num_segs);
+    if (D == 128) {
+        hipLaunchKernelGGL(attn_delta_kernel<128>, dim3(dgrid), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, qgrid, dim3(256), 0, s, a);
+        static const int once128 = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AT_RM_BYTES + 2 * AT_T_BYTES(128) + 512);
+        (void)once128;
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, kgrid, dim3(256), 2 * AT_RM_BYTES + 2 * AT_T_BYTES(128) + 512, s, b);
+    } else {
+        hipLaunchKernelGGL(attn_delta_kernel<80>, dim3(dgrid), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<80>, qgrid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<80>, kgrid, dim3(256), 2 * AT_RM_BYTES + 2 * AT_T_BYTES(80) + 512, s, b);
+    }
+    SP_CHECK_LAUNCH();
+    return SPACER_OK;
+}

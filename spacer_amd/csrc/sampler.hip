@@ -1,0 +1,200 @@
+// Token sampling for the rollout loop: temperature -> top-k -> top-p -> multinomial, the warper chain HF
+// generate applies for the reference's GenerationConfig (SG_RLVR_trainer.py:277-284: do_sample, top_p 0.95,
+// temperature 1, and the era-default top_k = 50).  One 1024-thread workgroup per sequence:
+//   1. exact k-th largest logit by 4-pass radix select on order-preserving keys (wave-aggregated LDS atomics)
+//   2. candidates (logit >= k-th, ties kept as HF does) gathered to LDS, bitonic-sorted (value desc, index asc)
+//   3. nucleus: keep rank i while the descending exclusive cumulative probability < top_p  (== HF's
+//      "remove ascending cumsum <= 1 - top_p", min_tokens_to_keep = 1)
+//   4. inverse-CDF draw with a Philox4x32-10 uniform keyed by (seed, step, row)
+#include "common.h"
+
+namespace {
+
+constexpr int SNT = 1024;
+constexpr int CAP = 1024;    // candidate capacity (top_k <= CAP; ties beyond CAP are dropped)
+
+__device__ __forceinline__ uint32_t okey(float x) {
+    const uint32_t u = __float_as_uint(x);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    c[1] = (uint32_t)p1; c[3] = (uint32_t)p0; c[0] = n0; c[2] = n2;
+}
+__device__ __forceinline__ float philox_uniform(uint64_t seed, uint32_t step, uint32_t row) {
+    uint32_t c[4] = {step, row, 0x5bd1e995u, 0u};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+    return (float)(c[0] >> 8) * (1.0f / 16777216.0f);   // [0, 1)
+}
+
+__device__ __forceinline__ float block_excl_scan(float v, float* wsum, float& total) {
+    // exclusive prefix over SNT threads; wsum = 16 floats of LDS
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    __syncthreads();
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    float base = 0.f, tot = 0.f;
+    for (int i = 0; i < SNT / 64; ++i) { if (i < w) base += wsum[i]; tot += wsum[i]; }
+    total = tot;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(SNT) void sample_kernel(const float* __restrict__ logits, long ld, int vocab, int top_k,
+                                                     float top_p, float inv_temp, uint64_t seed,
+                                                     const int* __restrict__ step_dev, int eos, int pad, int suppress_eos,
+                                                     int* __restrict__ finished, int64_t* __restrict__ out_ids,
+                                                     float* __restrict__ out_logp) {
+    __shared__ int hist[256];
+    __shared__ int sel_bin, sel_k, ncand;
+    __shared__ float cval[CAP];
+    __shared__ int cidx[CAP];
+    __shared__ float wsum[SNT / 64];
+    __shared__ float red[32];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    if (finished && finished[b]) {
+        if (tid == 0) { out_ids[b] = pad; if (out_logp) out_logp[b] = 0.f; }
+        return;
+    }
+    const float* row = logits + (long)b * ld;
+    auto val = [&](int i) -> float {
+        const float x = row[i] * inv_temp;
+        return (suppress_eos && i == eos) ? -INFINITY : x;
+    };
+
+    // ---- 1. radix select of the k-th largest key
+    uint32_t prefix = 0;
+    int k = top_k;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        for (int i = tid; i < 256; i += SNT) hist[i] = 0;
+        __syncthreads();
+        for (int i0 = 0; i0 < vocab; i0 += SNT) {
+            const int i = i0 + tid;
+            bool live = i < vocab;
+            uint32_t key = live ? okey(val(i)) : 0u;
+            if (pass > 0) live = live && ((key >> (shift + 8)) == prefix);
+            const int bin = (key >> shift) & 255;
+            unsigned long long act = __ballot(live);
+            while (act) {                                   // wave-aggregated histogram update
+                const int leader = __ffsll((long long)act) - 1;
+                const int lb = __shfl(bin, leader, 64);
+                const unsigned long long same = __ballot(live && bin == lb);
+                if (lane == leader) atomicAdd(&hist[lb], __popcll(same));
+                act &= ~same;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int cum = 0, bsel = 0;
+            for (int bb = 255; bb >= 0; --bb) {
+                if (cum + hist[bb] >= k) { bsel = bb; break; }
+                cum += hist[bb];
+            }
+            sel_bin = bsel; sel_k = k - cum;
+        }
+        __syncthreads();
+        prefix = (prefix << 8) | (uint32_t)sel_bin;
+        k = sel_k;
+        __syncthreads();
+    }
+    const uint32_t kth = prefix;
+
+    // ---- 2. gather candidates
+    if (tid == 0) ncand = 0;
+    __syncthreads();
+    for (int i = tid; i < vocab; i += SNT) {
+        const float x = val(i);
+        if (okey(x) >= kth) {
+            const int slot = atomicAdd(&ncand, 1);
+            if (slot < CAP) { cval[slot] = x; cidx[slot] = i; }
+        }
+    }
+    __syncthreads();
+    const int n = min(ncand, CAP);
+    int np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    for (int i = n + tid; i < np2; i += SNT) { cval[i] = -INFINITY; cidx[i] = 0x7fffffff; }
+    __syncthreads();
+    // bitonic sort: descending value, ascending index on ties
+    for (int sz = 2; sz <= np2; sz <<= 1)
+        for (int st = sz >> 1; st > 0; st >>= 1) {
+            for (int i = tid; i < np2; i += SNT) {
+                const int j = i ^ st;
+                if (j > i) {
+                    const bool desc = ((i & sz) == 0);
+                    const float vi = cval[i], vj = cval[j];
+                    const int ii = cidx[i], ij = cidx[j];
+                    const bool i_first = (vi > vj) || (vi == vj && ii < ij);   // i should precede j in final order
+                    if (i_first != desc) { cval[i] = vj; cval[j] = vi; cidx[i] = ij; cidx[j] = ii; }
+                }
+            }
+            __syncthreads();
+        }
+
+    // ---- 3. nucleus over the sorted candidates (n <= CAP <= SNT: one candidate per thread)
+    const float vmax = cval[0];
+    const float p = (tid < n) ? __expf(cval[tid] - vmax) : 0.f;
+    float Z;
+    const float excl = block_excl_scan(p, wsum, Z);
+    const bool keep = (tid < n) && (tid == 0 || excl < top_p * Z);
+    const float pk = keep ? p : 0.f;
+    float Zk;
+    const float exk = block_excl_scan(pk, wsum, Zk);
+
+    // ---- 4. draw
+    const float u = philox_uniform(seed, (uint32_t)*step_dev, (uint32_t)b) * Zk;
+    __shared__ int chosen;
+    if (tid == 0) chosen = -1;
+    __syncthreads();
+    if (keep && exk <= u && u < exk + pk) chosen = tid;     // at most one thread satisfies this
+    __syncthreads();
+    if (chosen < 0) {   // numeric edge (u == Zk after rounding): take the last kept candidate
+        const int cand = keep ? tid : -1;
+        int best = cand;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) best = max(best, __shfl_xor(best, o, 64));
+        if (lane == 0) atomicMax(&chosen, best);
+        __syncthreads();
+    }
+    const int tok = cidx[chosen];
+    if (out_logp) {     // log-prob of the drawn token under the full (untruncated) softmax
+        float m = -INFINITY;
+        for (int i = tid; i < vocab; i += SNT) m = fmaxf(m, val(i));
+        const float M = block_max(m, red);
+        float s = 0.f;
+        for (int i = tid; i < vocab; i += SNT) s += __expf(val(i) - M);
+        const float S = block_sum(s, red);
+        if (tid == 0) out_logp[b] = cval[chosen] - M - logf(S);
+    }
+    if (tid == 0) {
+        out_ids[b] = tok;
+        if (finished && tok == eos) finished[b] = 1;
+    }
+}
+
+}  // namespace
+
+extern "C" long spacer_sample_workspace_bytes(int B, int vocab) { (void)B; (void)vocab; return 0; }
+
+extern "C" int spacer_sample_top_p(const float* logits, long ld, int B, int vocab, int top_k, float top_p,
+                                   float temperature, uint64_t seed, const int* step_dev, int eos_id, int pad_id,
+                                   int suppress_eos, int* finished, int64_t* out_ids, float* out_logp, void* workspace,
+                                   long workspace_bytes, spacer_stream_t stream) {
+    (void)workspace; (void)workspace_bytes;
+    SP_REQUIRE(top_k >= 1 && top_k <= CAP, SPACER_EINVAL,
+               "sample_top_p: top_k=%d must be in 1..%d (full-vocabulary nucleus, top_k=0, is not implemented yet)", top_k, CAP);
+    SP_REQUIRE(top_p > 0.f && top_p <= 1.f && temperature > 0.f, SPACER_EINVAL, "sample_top_p: bad top_p/temperature");
+    SP_REQUIRE(vocab >= top_k, SPACER_EINVAL, "sample_top_p: vocab < top_k");
+    if (B <= 0) return SPACER_OK;
+    hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(SNT), 0, (hipStream_t)stream, logits, ld, vocab, top_k, top_p,
+                       1.f / temperature, seed, step_dev, eos_id, pad_id, suppress_eos, finished, out_ids, out_logp);
+    SP_CHECK_LAUNCH();
+    return SPACER_OK;
+}

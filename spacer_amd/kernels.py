@@ -1,0 +1,333 @@
+"""Thin torch-tensor front end over the C-ABI (include/spacer_hip.h).
+
+PyTorch is used here for device memory and the current HIP stream only; every function launches
+hand-written gfx950 kernels from libspacer_hip.so on ``torch.cuda.current_stream()``.  There is no
+eager / CPU fallback: tensors must live on a GPU and the library must be built.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import (SPACER_ACT_GELU_ERF, SPACER_ACT_NONE, SPACER_ACT_QUICK_GELU, SPACER_ACT_SILU,  # noqa: F401
+                   AttnSegment, GemmEpilogue, SpacerError, check)
+
+BF16 = torch.bfloat16
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
+    if t is None:
+        return C.c_void_p(0)
+    if not t.is_cuda:
+        raise SpacerError("spacer_amd kernels need GPU tensors (there is no CPU path)")
+    return C.c_void_p(t.data_ptr())
+
+
+def _rowmajor(t: torch.Tensor) -> int:
+    assert t.dim() == 2 and t.stride(1) == 1, "expected a row-major 2-D view"
+    return t.stride(0)
+
+
+# ----------------------------------------------------------------------------------------- GEMM
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = None, bias=None, residual=None,
+            act: int = SPACER_ACT_NONE, out_dtype=BF16, alpha: float = 1.0) -> torch.Tensor:
+    """out[M,N] = act(alpha * a[M,K] @ b[N,K]^T + bias) + residual.  a, b bf16; out bf16 or fp32."""
+    M, K = a.shape
+    N, K2 = b.shape
+    assert K == K2 and a.dtype == BF16 and b.dtype == BF16
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=out_dtype)
+    assert out.dtype in (BF16, torch.float32)
+    if residual is not None:
+        assert residual.dtype == out.dtype
+    epi = GemmEpilogue(_ptr(bias), _ptr(residual), _rowmajor(residual) if residual is not None else 0,
+                       1 if out.dtype == torch.float32 else 0, act, alpha)
+    check(_lib.load().spacer_gemm_bf16_nt(_ptr(a), _rowmajor(a), _ptr(b), _rowmajor(b), _ptr(out), _rowmajor(out),
+                                          M, N, K, C.byref(epi), _stream()), "gemm_bf16_nt")
+    return out
+
+
+def gemm_skinny_acc(a: torch.Tensor, b: torch.Tensor, c32: torch.Tensor) -> torch.Tensor:
+    """c32[M,N] (fp32) += a[M,K] @ b[N,K]^T for M <= 64 (decode)."""
+    M, K = a.shape
+    N = b.shape[0]
+    assert c32.dtype == torch.float32 and a.dtype == BF16 and b.dtype == BF16
+    check(_lib.load().spacer_gemm_skinny_bf16(_ptr(a), _rowmajor(a), _ptr(b), _rowmajor(b), _ptr(c32), _rowmajor(c32),
+                                              M, N, K, None, _stream()), "gemm_skinny_bf16")
+    return c32
+
+
+def transpose_pad(x: torch.Tensor, rpad: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x[R,C] bf16 -> out[C, Rpad] with zero fill (Rpad defaults to R rounded up to 64)."""
+    R, Cc = x.shape
+    if rpad is None:
+        rpad = (R + 63) // 64 * 64
+    if out is None:
+        out = torch.empty(Cc, rpad, device=x.device, dtype=BF16)
+    check(_lib.load().spacer_transpose_bf16(_ptr(x), _rowmajor(x), _ptr(out), _rowmajor(out), R, Cc, rpad, _stream()),
+          "transpose_bf16")
+    return out
+
+
+# ----------------------------------------------------------------------------------------- norms
+def rmsnorm_fwd(x, w, eps, *, rstd=None, out=None):
+    rows, cols = x.shape
+    if out is None:
+        out = torch.empty(rows, cols, device=x.device, dtype=BF16)
+    check(_lib.load().spacer_rmsnorm_fwd(_ptr(x), int(x.dtype == torch.float32), _ptr(w), _ptr(out), _ptr(rstd), rows,
+                                         cols, eps, _stream()), "rmsnorm_fwd")
+    return out
+
+
+def rmsnorm_bwd(x, w, dy, rstd, dx, dw, *, accumulate=True):
+    rows, cols = x.shape
+    assert dx.dtype == x.dtype and dw.dtype == torch.float32
+    check(_lib.load().spacer_rmsnorm_bwd(_ptr(x), int(x.dtype == torch.float32), _ptr(w), _ptr(dy), _ptr(rstd), _ptr(dx),
+                                         int(accumulate), _ptr(dw), rows, cols, _stream()), "rmsnorm_bwd")
+    return dx
+
+
+def layernorm_fwd(x, w, b, eps=1e-6, *, mean=None, rstd=None, out=None):
+    rows, cols = x.shape
+    if out is None:
+        out = torch.empty(rows, cols, device=x.device, dtype=BF16)
+    check(_lib.load().spacer_layernorm_fwd(_ptr(x), int(x.dtype == torch.float32), _ptr(w), _ptr(b), _ptr(out), _ptr(mean),
+                                           _ptr(rstd), rows, cols, eps, _stream()), "layernorm_fwd")
+    return out
+
+
+def layernorm_bwd(x, w, dy, mean, rstd, dx, dw, db, *, accumulate=True):
+    rows, cols = x.shape
+    check(_lib.load().spacer_layernorm_bwd(_ptr(x), int(x.dtype == torch.float32), _ptr(w), _ptr(dy), _ptr(mean), _ptr(rstd),
+                                           _ptr(dx), int(accumulate), _ptr(dw), _ptr(db), rows, cols, _stream()),
+          "layernorm_bwd")
+    return dx
+
+
+# ----------------------------------------------------------------------------------------- rotary
+def rope_(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, heads: int, head_dim: int, *, inverse=False):
+    """In-place rotary on the first ``heads`` heads of every token row of x (2-D [tokens, >= heads*head_dim])."""
+    tokens = x.shape[0]
+    assert cos.dtype == torch.float32 and cos.shape == (tokens, head_dim) and cos.is_contiguous() and sin.is_contiguous()
+    check(_lib.load().spacer_rope_inplace(_ptr(x), x.stride(0), _ptr(cos), _ptr(sin), tokens, heads, head_dim,
+                                          int(inverse), _stream()), "rope_inplace")
+    return x
+
+
+# ----------------------------------------------------------------------------------------- attention
+def make_segments(segs: Sequence[Sequence[int]], device) -> torch.Tensor:
+    """[(q_start, q_len, pre_start, pre_len), ...] -> int32 device tensor [n, 4]."""
+    return torch.tensor(list(segs), dtype=torch.int32, device=device).reshape(-1, 4).contiguous()
+
+
+def attn_fwd(q, k, v, segs: torch.Tensor, max_q_len: int, Hq: int, Hkv: int, D: int, causal: bool, scale: float,
+             *, out=None, lse=None):
+    """q [T, >=Hq*D] view, k/v [T, >=Hkv*D] views (row stride = token stride).  Returns (o [T,Hq*D], lse [Hq,T])."""
+    T = q.shape[0]
+    if out is None:
+        out = torch.empty(T, Hq * D, device=q.device, dtype=BF16)
+    if lse is None:
+        lse = torch.empty(Hq, T, device=q.device, dtype=torch.float32)
+    assert k.stride(0) == v.stride(0)
+    check(_lib.load().spacer_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), q.stride(0), k.stride(0),
+                                      out.stride(0), _ptr(segs), segs.shape[0], max_q_len, T, Hq, Hkv, D, int(causal),
+                                      scale, _stream()), "attn_fwd")
+    return out, lse
+
+
+def attn_bwd(q, k, v, o, d_o, lse, segs, max_q_len, Hq, Hkv, D, causal, scale, *, dq, dk32, dv32, delta=None):
+    """dq bf16 in q's layout; dk32/dv32 fp32 [T, Hkv*D] zeroed by the caller."""
+    T = q.shape[0]
+    if delta is None:
+        delta = torch.empty(Hq, T, device=q.device, dtype=torch.float32)
+    assert o.stride(0) == d_o.stride(0) and dq.stride(0) == q.stride(0) and k.stride(0) == v.stride(0)
+    assert dk32.is_contiguous() and dv32.is_contiguous() and dk32.dtype == torch.float32
+    check(_lib.load().spacer_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(d_o), _ptr(lse), _ptr(delta), _ptr(dq),
+                                      _ptr(dk32), _ptr(dv32), q.stride(0), k.stride(0), o.stride(0), _ptr(segs),
+                                      segs.shape[0], max_q_len, T, Hq, Hkv, D, int(causal), scale, _stream()), "attn_bwd")
+    return dq, dk32, dv32
+
+
+def attn_decode(q, prefix_k, prefix_v, prefix_len, prompt_of, tail_k, tail_v, tail_len_dev, Hq, Hkv, D, scale, *, out=None):
+    B = q.shape[0]
+    if out is None:
+        out = torch.empty(B, Hq * D, device=q.device, dtype=BF16)
+    check(_lib.load().spacer_attn_decode(_ptr(q), _ptr(prefix_k), _ptr(prefix_v), _ptr(prefix_len), _ptr(prompt_of),
+                                         _ptr(tail_k), _ptr(tail_v), _ptr(tail_len_dev), _ptr(out), B, prefix_k.shape[1],
+                                         tail_k.shape[1], Hq, Hkv, D, scale, _stream()), "attn_decode")
+    return out
+
+
+# ----------------------------------------------------------------------------------------- element-wise
+def swiglu_fwd(gu, *, out=None):
+    rows, two_i = gu.shape
+    if out is None:
+        out = torch.empty(rows, two_i // 2, device=gu.device, dtype=BF16)
+    check(_lib.load().spacer_swiglu_fwd(_ptr(gu), _ptr(out), rows, two_i // 2, _stream()), "swiglu_fwd")
+    return out
+
+
+def swiglu_bwd(gu, dy, *, out=None):
+    rows, two_i = gu.shape
+    if out is None:
+        out = torch.empty_like(gu)
+    check(_lib.load().spacer_swiglu_bwd(_ptr(gu), _ptr(dy), _ptr(out), rows, two_i // 2, _stream()), "swiglu_bwd")
+    return out
+
+
+def act_fwd(x, act, *, out=None):
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.load().spacer_act_fwd(_ptr(x), _ptr(out), x.numel(), act, _stream()), "act_fwd")
+    return out
+
+
+def act_bwd(x, dy, act, *, out=None):
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.load().spacer_act_bwd(_ptr(x), _ptr(dy), _ptr(out), x.numel(), act, _stream()), "act_bwd")
+    return out
+
+
+def bias_grad_(dy, db32):
+    rows, cols = dy.shape
+    check(_lib.load().spacer_bias_grad(_ptr(dy), _rowmajor(dy), _ptr(db32), rows, cols, _stream()), "bias_grad")
+    return db32
+
+
+def cast_bf16(x32, *, out=None):
+    if out is None:
+        out = torch.empty(x32.shape, device=x32.device, dtype=BF16)
+    check(_lib.load().spacer_cast_f32_to_bf16(_ptr(x32), _ptr(out), x32.numel(), _stream()), "cast_f32_to_bf16")
+    return out
+
+
+def cast_bf16_strided(x32, out):
+    rows, cols = x32.shape
+    check(_lib.load().spacer_cast_f32_to_bf16_strided(_ptr(x32), _rowmajor(x32), _ptr(out), _rowmajor(out), rows, cols,
+                                                      _stream()), "cast_f32_to_bf16_strided")
+    return out
+
+
+def cast_f32(x, *, out=None):
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    check(_lib.load().spacer_cast_bf16_to_f32(_ptr(x), _ptr(out), x.numel(), _stream()), "cast_bf16_to_f32")
+    return out
+
+
+def embed_fwd(ids, table, video, video_row_of_token, *, out=None):
+    T, H = ids.shape[0], table.shape[1]
+    if out is None:
+        out = torch.empty(T, H, device=table.device, dtype=torch.float32)
+    check(_lib.load().spacer_embed_fwd(_ptr(ids), _ptr(table), _ptr(video), _ptr(video_row_of_token), _ptr(out), T, H,
+                                       _stream()), "embed_fwd")
+    return out
+
+
+def embed_bwd(ids, video_row_of_token, d_out, d_table32, d_video32):
+    T, H = d_out.shape
+    check(_lib.load().spacer_embed_bwd(_ptr(ids), _ptr(video_row_of_token), _ptr(d_out), _ptr(d_table32), _ptr(d_video32),
+                                       T, H, _stream()), "embed_bwd")
+
+
+def patchify(frames_u8, patch=14, tpatch=2, merge=2, kpad=1216, *, out=None):
+    F, Cc, Hpx, Wpx = frames_u8.shape
+    assert Cc == 3 and frames_u8.dtype == torch.uint8 and frames_u8.is_contiguous()
+    gt, gh, gw = (F + tpatch - 1) // tpatch, Hpx // patch, Wpx // patch
+    if out is None:
+        out = torch.empty(gt * gh * gw, kpad, device=frames_u8.device, dtype=BF16)
+    check(_lib.load().spacer_patchify(_ptr(frames_u8), _ptr(out), F, Hpx, Wpx, patch, tpatch, merge, kpad, _stream()),
+          "patchify")
+    return out, (gt, gh, gw)
+
+
+# ----------------------------------------------------------------------------------------- loss
+def logprob_fwd(logits32, targets, *, logp=None, lse=None):
+    rows, vocab = logits32.shape
+    if logp is None:
+        logp = torch.empty(rows, device=logits32.device, dtype=torch.float32)
+    if lse is None:
+        lse = torch.empty(rows, device=logits32.device, dtype=torch.float32)
+    check(_lib.load().spacer_logprob_fwd(_ptr(logits32), _rowmajor(logits32), _ptr(targets), _ptr(logp), _ptr(lse), rows,
+                                         vocab, _stream()), "logprob_fwd")
+    return logp, lse
+
+
+def logprob_bwd(logits32, targets, lse, g, *, out=None):
+    rows, vocab = logits32.shape
+    if out is None:
+        out = torch.empty(rows, vocab, device=logits32.device, dtype=BF16)
+    check(_lib.load().spacer_logprob_bwd(_ptr(logits32), _rowmajor(logits32), _ptr(targets), _ptr(lse), _ptr(g), _ptr(out),
+                                         _rowmajor(out), rows, vocab, _stream()), "logprob_bwd")
+    return out
+
+
+def grpo_loss(logp, ref_logp, adv, mask, beta):
+    G, Cc = logp.shape
+    dev = logp.device
+    loss = torch.empty(1, device=dev, dtype=torch.float32)
+    kl = torch.empty(1, device=dev, dtype=torch.float32)
+    dlogp = torch.empty(G, Cc, device=dev, dtype=torch.float32)
+    check(_lib.load().spacer_grpo_loss(_ptr(logp), _ptr(ref_logp), _ptr(adv), _ptr(mask), beta, _ptr(loss), _ptr(kl),
+                                       _ptr(dlogp), G, Cc, _stream()), "grpo_loss")
+    return loss, kl, dlogp
+
+
+def completion_mask(ids, eos_id):
+    G, Cc = ids.shape
+    mask = torch.empty(G, Cc, device=ids.device, dtype=torch.int32)
+    lens = torch.empty(G, device=ids.device, dtype=torch.int32)
+    check(_lib.load().spacer_completion_mask(_ptr(ids), eos_id, _ptr(mask), _ptr(lens), G, Cc, _stream()), "completion_mask")
+    return mask, lens
+
+
+# ----------------------------------------------------------------------------------------- decode helpers
+def sample_top_p(logits32, step_dev, *, top_k=50, top_p=0.95, temperature=1.0, seed=0, eos_id=-1, pad_id=0,
+                 suppress_eos=False, finished=None, out_ids=None, out_logp=None):
+    B, vocab = logits32.shape
+    if out_ids is None:
+        out_ids = torch.empty(B, device=logits32.device, dtype=torch.int64)
+    check(_lib.load().spacer_sample_top_p(_ptr(logits32), _rowmajor(logits32), B, vocab, top_k, top_p, temperature, seed,
+                                          _ptr(step_dev), eos_id, pad_id, int(suppress_eos), _ptr(finished), _ptr(out_ids),
+                                          _ptr(out_logp), None, 0, _stream()), "sample_top_p")
+    return out_ids
+
+
+def decode_rope_table(pos_base, step_dev, theta, cos, sin):
+    B, D = cos.shape
+    check(_lib.load().spacer_decode_rope_table(_ptr(pos_base), _ptr(step_dev), theta, _ptr(cos), _ptr(sin), B, D, _stream()),
+          "decode_rope_table")
+
+
+def decode_qkv_finish(acc32, bias, cos, sin, q_out, tail_k, tail_v, tail_len_dev, Hq, Hkv, D):
+    B = acc32.shape[0]
+    check(_lib.load().spacer_decode_qkv_finish(_ptr(acc32), _ptr(bias), _ptr(cos), _ptr(sin), _ptr(q_out), _ptr(tail_k),
+                                               _ptr(tail_v), _ptr(tail_len_dev), B, Hq, Hkv, D, tail_k.shape[1], _stream()),
+          "decode_qkv_finish")
+
+
+def swiglu_f32_fwd(acc32, out):
+    B, two_i = acc32.shape
+    check(_lib.load().spacer_swiglu_f32_fwd(_ptr(acc32), _ptr(out), B, two_i // 2, _stream()), "swiglu_f32_fwd")
+    return out
+
+
+# ----------------------------------------------------------------------------------------- optimizer
+def sumsq_(g32, acc):
+    check(_lib.load().spacer_sumsq_f32(_ptr(g32), g32.numel(), _ptr(acc), _stream()), "sumsq_f32")
+
+
+def adamw_step_(master, shadow, m, v, grad, *, lr, beta1, beta2, eps, weight_decay, step, sumsq=None, max_norm=0.0,
+                grad_scale=1.0):
+    bc1, bc2 = 1.0 - beta1 ** step, 1.0 - beta2 ** step
+    check(_lib.load().spacer_adamw_step(_ptr(master), _ptr(shadow), _ptr(m), _ptr(v), _ptr(grad), master.numel(), lr, beta1,
+                                        beta2, eps, weight_decay, bc1, bc2, _ptr(sumsq), max_norm, grad_scale, _stream()),
+          "adamw_step")

@@ -1,0 +1,398 @@
+"""GPU parity tests for every C-ABI kernel: HIP result vs the fp32 oracle / a plain torch fp32 restatement of
+the same op on the same seeded inputs.  Integer outputs are compared bit-exactly; floating point within the
+tolerance written next to each assert (bf16 outputs: a few bf16 ulps of the fp32 result)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import grpo_ref as GR          # noqa: E402
+from oracle import qwen2vl_fp32 as O       # noqa: E402
+from spacer_amd import kernels as K        # noqa: E402
+
+BF = torch.bfloat16
+
+
+def rnd(shape, dev, seed, scale=1.0, dtype=BF):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(dev)
+
+
+def assert_close(got, want, atol, rtol, what=""):
+    got, want = got.float().cpu(), want.float().cpu()
+    err = (got - want).abs()
+    tol = atol + rtol * want.abs()
+    bad = err > tol
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} off, max err {err.max():.4g} (tol {atol}+{rtol}*|x|)"
+
+
+# ----------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (200, 320, 1216), (1040, 3584, 5120),
+                                   (17, 1000, 128), (4160, 1280, 1216), (333, 152064 // 8, 256)])
+def test_gemm_nt_plain(dev, M, N, K):
+    a, b = rnd((M, K), dev, 1), rnd((N, K), dev, 2)
+    # asymmetric operands (guide: transpose-detecting check)
+    b[:, 0] += 1.0
+    got = K_gemm(a, b)
+    want = a.float() @ b.float().t()
+    assert_close(got, want, atol=0.02 * math.sqrt(K) * 0.1 + 0.02, rtol=1e-2, what=f"gemm {M}x{N}x{K}")
+
+
+def K_gemm(a, b, **kw):
+    return K.gemm_nt(a, b, **kw)
+
+
+def test_gemm_nt_epilogues(dev):
+    M, N, Kd = 300, 640, 320
+    a, b = rnd((M, Kd), dev, 3, 0.5), rnd((N, Kd), dev, 4, 0.1)
+    bias = rnd((N,), dev, 5)
+    base = a.float() @ b.float().t()
+    # bias + quick_gelu, bf16 out
+    got = K.gemm_nt(a, b, bias=bias, act=K.SPACER_ACT_QUICK_GELU)
+    assert_close(got, O.quick_gelu(base + bias.float()), 2e-2, 1e-2, "bias+quick_gelu")
+    got = K.gemm_nt(a, b, bias=bias, act=K.SPACER_ACT_GELU_ERF)
+    assert_close(got, O.gelu_erf(base + bias.float()), 2e-2, 1e-2, "bias+gelu")
+    # fp32 out + fp32 residual (the residual-stream form) and in-place accumulate
+    res = rnd((M, N), dev, 6, dtype=torch.float32)
+    got = K.gemm_nt(a, b, residual=res, out_dtype=torch.float32)
+    assert_close(got, base + res, 2e-3, 1e-3, "f32 residual")
+    acc = res.clone()
+    K.gemm_nt(a, b, out=acc, residual=acc)
+    assert_close(acc, base + res, 2e-3, 1e-3, "f32 accumulate")
+    # bf16 residual, strided views
+    big = rnd((M, 2 * N), dev, 7)
+    got = K.gemm_nt(a, b, residual=big[:, N:])
+    assert_close(got, base + big[:, N:].float(), 3e-2, 1e-2, "bf16 residual strided")
+    assert K.gemm_nt(a, b, alpha=0.5).float().sub(0.5 * base).abs().max() < 5e-2
+
+
+def test_gemm_rejects_bad_k(dev):
+    a, b = rnd((64, 96), dev, 1), rnd((64, 96), dev, 2)
+    with pytest.raises(K.SpacerError):
+        K.gemm_nt(a, b)
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 3584, 3584), (8, 4608, 3584), (64, 2048, 1536), (33, 1000, 256), (64, 512, 18944)])
+def test_gemm_skinny(dev, M, N, K):
+    a, b = rnd((M, K), dev, 1, 0.5), rnd((N, K), dev, 2, 0.05)
+    c0 = rnd((M, N), dev, 3, dtype=torch.float32)
+    c = c0.clone()
+    K_mod = __import__("spacer_amd.kernels", fromlist=["x"])
+    K_mod.gemm_skinny_acc(a, b, c)
+    assert_close(c, c0 + a.float() @ b.float().t(), 5e-3, 2e-3, "skinny")
+
+
+def test_transpose_pad(dev):
+    x = rnd((200, 136), dev, 1)
+    t = K.transpose_pad(x, 256)
+    assert t.shape == (136, 256)
+    assert torch.equal(t[:, :200], x.t()) and float(t[:, 200:].float().abs().sum()) == 0.0
+
+
+# ----------------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("f32", [True, False])
+@pytest.mark.parametrize("rows,cols", [(77, 256), (300, 3584), (5, 1280)])
+def test_rmsnorm(dev, f32, rows, cols):
+    x = rnd((rows, cols), dev, 1, 2.0, torch.float32 if f32 else BF)
+    w = rnd((cols,), dev, 2) + 1
+    rstd = torch.empty(rows, device=dev)
+    y = K.rmsnorm_fwd(x, w, 1e-6, rstd=rstd)
+    assert_close(y, O.rms_norm(x.cpu(), w.cpu(), 1e-6), 1e-2, 1e-2, "rmsnorm fwd")
+    # backward vs autograd of the oracle
+    dy = rnd((rows, cols), dev, 3)
+    xr = x.float().cpu().requires_grad_(True); wr = w.float().cpu().requires_grad_(True)
+    O.rms_norm(xr, wr, 1e-6).backward(dy.float().cpu())
+    dx0 = rnd((rows, cols), dev, 4, dtype=x.dtype)
+    dx = dx0.clone(); dw = torch.zeros(cols, device=dev)
+    K.rmsnorm_bwd(x, w, dy, rstd, dx, dw, accumulate=True)
+    tol = 1e-3 if f32 else 3e-2
+    assert_close(dx, dx0.float().cpu() + xr.grad, tol, 1e-2, "rmsnorm dx")
+    assert_close(dw, wr.grad, 2e-2 * math.sqrt(rows), 1e-2, "rmsnorm dw")
+
+
+@pytest.mark.parametrize("f32", [True, False])
+def test_layernorm(dev, f32):
+    rows, cols = 130, 1280
+    x = rnd((rows, cols), dev, 1, 2.0, torch.float32 if f32 else BF) + 0.5
+    w = rnd((cols,), dev, 2) + 1; b = rnd((cols,), dev, 5)
+    mean = torch.empty(rows, device=dev); rstd = torch.empty(rows, device=dev)
+    y = K.layernorm_fwd(x, w, b, 1e-6, mean=mean, rstd=rstd)
+    assert_close(y, O.layer_norm(x.cpu(), w.cpu(), b.cpu()), 1e-2, 1e-2, "layernorm fwd")
+    dy = rnd((rows, cols), dev, 3)
+    xr = x.float().cpu().requires_grad_(True); wr = w.float().cpu().requires_grad_(True); br = b.float().cpu().requires_grad_(True)
+    O.layer_norm(xr, wr, br).backward(dy.float().cpu())
+    dx = torch.zeros_like(x); dw = torch.zeros(cols, device=dev); db = torch.zeros(cols, device=dev)
+    K.layernorm_bwd(x, w, dy, mean, rstd, dx, dw, db, accumulate=False)
+    assert_close(dx, xr.grad, 1e-3 if f32 else 3e-2, 1e-2, "layernorm dx")
+    assert_close(dw, wr.grad, 0.3, 1e-2, "layernorm dw")
+    assert_close(db, br.grad, 0.3, 1e-2, "layernorm db")
+
+
+# ----------------------------------------------------------------------------------------------- rotary
+@pytest.mark.parametrize("D,heads,extra", [(128, 5, 2), (80, 8, 4)])
+def test_rope(dev, D, heads, extra):
+    T = 37
+    x = rnd((T, (heads + extra) * D), dev, 1)
+    ang = rnd((T, D // 2), dev, 2, 3.0, torch.float32)
+    cos = torch.cat([ang.cos(), ang.cos()], 1).contiguous(); sin = torch.cat([ang.sin(), ang.sin()], 1).contiguous()
+    xr = x.float().view(T, heads + extra, D)[:, :heads]
+    want = xr * cos[:, None] + O._rot_half(xr.cpu()).to(dev) * sin[:, None]
+    y = x.clone()
+    K.rope_(y, cos, sin, heads, D)
+    assert_close(y.view(T, heads + extra, D)[:, :heads], want, 2e-2, 1e-2, "rope")
+    assert torch.equal(y.view(T, heads + extra, D)[:, heads:], x.view(T, heads + extra, D)[:, heads:])
+    # inverse is the transpose: <R x, g> == <x, R^T g>
+    g = rnd((T, (heads + extra) * D), dev, 3)
+    gt = g.clone(); K.rope_(gt, cos, sin, heads, D, inverse=True)
+    lhs = (want * g.float().view(T, heads + extra, D)[:, :heads]).sum()
+    rhs = (xr * gt.float().view(T, heads + extra, D)[:, :heads]).sum()
+    assert abs(float(lhs - rhs)) < 2e-2 * abs(float(lhs)) + 1.0
+
+
+# ----------------------------------------------------------------------------------------------- attention
+def dense_mask(segs, T, causal):
+    m = torch.zeros(T, T, dtype=torch.bool)
+    for qs, ql, ps, pl in segs:
+        for i in range(ql):
+            m[qs + i, ps:ps + pl] = True
+            m[qs + i, qs:qs + (i + 1 if causal else ql)] = True
+    return m
+
+
+def attn_ref(q, k, v, mask, Hq, Hkv, D, scale):
+    T = q.shape[0]
+    qh = q.float().view(T, Hq, D).transpose(0, 1)
+    kh = k.float().view(T, Hkv, D).repeat_interleave(Hq // Hkv, 1).transpose(0, 1)
+    vh = v.float().view(T, Hkv, D).repeat_interleave(Hq // Hkv, 1).transpose(0, 1)
+    s = (qh @ kh.transpose(1, 2)) * scale
+    s = s.masked_fill(~mask.to(s.device), float("-inf"))
+    return (torch.softmax(s, -1) @ vh).transpose(0, 1).reshape(T, Hq * D)
+
+
+ATTN_CASES = [
+    # (name, D, Hq, Hkv, causal, segments)
+    ("vit_frames", 80, 4, 4, False, [(0, 24, 0, 0), (24, 24, 0, 0), (48, 24, 0, 0)]),
+    ("vit_520", 80, 2, 2, False, [(0, 520, 0, 0), (520, 520, 0, 0)]),
+    ("causal_small", 128, 2, 1, True, [(0, 50, 0, 0)]),
+    ("causal_300_gqa", 128, 6, 2, True, [(0, 300, 0, 0)]),
+    ("shared_prefix", 128, 4, 2, True, [(0, 45, 0, 0), (45, 6, 0, 45), (51, 6, 0, 45), (57, 6, 0, 45)]),
+    ("shared_prefix_big", 128, 7, 1, True, [(0, 200, 0, 0), (200, 130, 0, 200), (330, 130, 0, 200), (460, 70, 0, 200)]),
+]
+
+
+@pytest.mark.parametrize("case", ATTN_CASES, ids=[c[0] for c in ATTN_CASES])
+def test_attention_fwd_bwd(dev, case):
+    name, D, Hq, Hkv, causal, segs = case
+    T = max(s[0] + s[1] for s in segs)
+    W = (Hq + 2 * Hkv) * D
+    qkv = rnd((T, W), dev, 1, 0.7)
+    q, k, v = qkv[:, :Hq * D], qkv[:, Hq * D:(Hq + Hkv) * D], qkv[:, (Hq + Hkv) * D:]
+    scale = D ** -0.5
+    sd = K.make_segments(segs, dev)
+    mq = max(s[1] for s in segs)
+    o, lse = K.attn_fwd(q, k, v, sd, mq, Hq, Hkv, D, causal, scale)
+    mask = dense_mask(segs, T, causal)
+    qr, kr, vr = (t.float().detach().clone().requires_grad_(True) for t in (q, k, v))
+    want = attn_ref(qr, kr, vr, mask, Hq, Hkv, D, scale)
+    assert_close(o, want.detach(), 2e-2, 2e-2, f"{name} fwd")
+    # lse check
+    s = (qr.view(T, Hq, D).transpose(0, 1) @ kr.view(T, Hkv, D).repeat_interleave(Hq // Hkv, 1).transpose(0, 1).transpose(1, 2)) * scale
+    s = s.masked_fill(~mask.to(dev), float("-inf"))
+    assert_close(lse, torch.logsumexp(s, -1).detach(), 2e-2, 1e-3, f"{name} lse")
+    # backward
+    d_o = rnd((T, Hq * D), dev, 2, 0.5)
+    want.backward(d_o.float())
+    dqkv = torch.zeros_like(qkv)
+    dk32 = torch.zeros(T, Hkv * D, device=dev); dv32 = torch.zeros(T, Hkv * D, device=dev)
+    K.attn_bwd(q, k, v, o, d_o, lse, sd, mq, Hq, Hkv, D, causal, scale, dq=dqkv[:, :Hq * D], dk32=dk32, dv32=dv32)
+    gs = float(qr.grad.abs().max())
+    assert_close(dqkv[:, :Hq * D], qr.grad, 0.03 * gs + 1e-3, 3e-2, f"{name} dq")
+    assert_close(dk32, kr.grad, 0.03 * float(kr.grad.abs().max()) + 1e-3, 3e-2, f"{name} dk")
+    assert_close(dv32, vr.grad, 0.03 * float(vr.grad.abs().max()) + 1e-3, 3e-2, f"{name} dv")
+
+
+def test_attention_forced_rescale(dev):
+    """Spike one key so the running max jumps at a late tile (rescale branch is exercised)."""
+    D, Hq, Hkv, T = 128, 1, 1, 256
+    qkv = rnd((T, 3 * D), dev, 5, 0.3)
+    qkv[200, D:2 * D] = qkv[255, :D] * 30      # key 200 aligned with query 255
+    q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    sd = K.make_segments([(0, T, 0, 0)], dev)
+    o, _ = K.attn_fwd(q, k, v, sd, T, Hq, Hkv, D, True, D ** -0.5)
+    want = attn_ref(q, k, v, dense_mask([(0, T, 0, 0)], T, True), Hq, Hkv, D, D ** -0.5)
+    assert_close(o, want, 2e-2, 2e-2, "forced rescale")
+
+
+def test_attention_decode(dev):
+    D, Hq, Hkv, B, nP, Pmax, Cmax = 128, 6, 2, 5, 2, 70, 16
+    q = rnd((B, Hq * D), dev, 1, 0.7)
+    pk, pv = rnd((nP, Pmax, Hkv, D), dev, 2, 0.7), rnd((nP, Pmax, Hkv, D), dev, 3, 0.7)
+    tk, tv = rnd((B, Cmax, Hkv, D), dev, 4, 0.7), rnd((B, Cmax, Hkv, D), dev, 5, 0.7)
+    plen = torch.tensor([70, 33], dtype=torch.int32, device=dev)
+    pof = torch.tensor([0, 0, 1, 1, 1], dtype=torch.int32, device=dev)
+    for tl in (0, 9):
+        tld = torch.tensor([tl], dtype=torch.int32, device=dev)
+        o = K.attn_decode(q, pk, pv, plen, pof, tk, tv, tld, Hq, Hkv, D, D ** -0.5)
+        for b in range(B):
+            P = int(plen[pof[b]])
+            kk = torch.cat([pk[pof[b], :P], tk[b, :tl + 1]]).float()       # [L, Hkv, D]
+            vv = torch.cat([pv[pof[b], :P], tv[b, :tl + 1]]).float()
+            qq = q[b].float().view(Hq, D)
+            kk = kk.repeat_interleave(Hq // Hkv, 1); vv = vv.repeat_interleave(Hq // Hkv, 1)
+            s = torch.einsum("hd,lhd->hl", qq, kk) * D ** -0.5
+            want = torch.einsum("hl,lhd->hd", torch.softmax(s, -1), vv).reshape(-1)
+            assert_close(o[b], want, 2e-2, 2e-2, f"decode attn b={b} tl={tl}")
+
+
+# ----------------------------------------------------------------------------------------------- element-wise
+def test_swiglu_act_bias_cast(dev):
+    rows, I = 50, 512
+    gu = rnd((rows, 2 * I), dev, 1)
+    y = K.swiglu_fwd(gu)
+    g, u = gu.float()[:, :I], gu.float()[:, I:]
+    assert_close(y, torch.nn.functional.silu(g) * u, 1e-2, 1e-2, "swiglu fwd")
+    dy = rnd((rows, I), dev, 2)
+    gr = gu.float().clone().requires_grad_(True)
+    (torch.nn.functional.silu(gr[:, :I]) * gr[:, I:]).backward(dy.float())
+    assert_close(K.swiglu_bwd(gu, dy), gr.grad, 2e-2, 1e-2, "swiglu bwd")
+    x = rnd((rows, I), dev, 3, 2.0)
+    for act, fn in ((K.SPACER_ACT_QUICK_GELU, O.quick_gelu), (K.SPACER_ACT_GELU_ERF, O.gelu_erf)):
+        assert_close(K.act_fwd(x, act), fn(x.float()), 1e-2, 1e-2, "act fwd")
+        xr = x.float().clone().requires_grad_(True)
+        fn(xr).backward(dy.float())
+        assert_close(K.act_bwd(x, dy, act), xr.grad, 2e-2, 1e-2, "act bwd")
+    db = torch.ones(I, device=dev)
+    K.bias_grad_(dy, db)
+    assert_close(db, 1 + dy.float().sum(0), 5e-2, 1e-3, "bias grad")
+    f = rnd((37, 20), dev, 4, dtype=torch.float32)
+    assert torch.equal(K.cast_bf16(f), f.to(BF)) and torch.equal(K.cast_f32(f.to(BF)), f.to(BF).float())
+    big = torch.zeros(37, 64, device=dev, dtype=BF)
+    K.cast_bf16_strided(f, big[:, 8:28])
+    assert torch.equal(big[:, 8:28], f.to(BF)) and float(big[:, :8].float().abs().sum()) == 0
+
+
+def test_embed(dev):
+    V, H, T = 300, 64, 40
+    table = rnd((V, H), dev, 1); video = rnd((10, H), dev, 2)
+    ids = torch.randint(0, V, (T,), generator=torch.Generator().manual_seed(3)).to(dev)
+    vrow = torch.full((T,), -1, dtype=torch.int32); vrow[5:15] = torch.arange(10, dtype=torch.int32); vrow = vrow.to(dev)
+    out = K.embed_fwd(ids, table, video, vrow)
+    want = table[ids].float(); want[5:15] = video.float()
+    assert torch.equal(out, want)
+    d_out = rnd((T, H), dev, 4, dtype=torch.float32)
+    dt = torch.zeros(V, H, device=dev); dvid = torch.zeros(10, H, device=dev)
+    K.embed_bwd(ids, vrow, d_out, dt, dvid)
+    wt = torch.zeros(V, H, device=dev); txt = vrow < 0
+    wt.index_add_(0, ids[txt], d_out[txt])
+    assert_close(dt, wt, 1e-5, 1e-5, "embed bwd table")
+    assert torch.equal(dvid, d_out[5:15])
+
+
+def test_patchify_matches_oracle(dev):
+    cfg = O.make_config(hidden=64, layers=1, heads=1, kv_heads=1, intermediate=64, vocab=10, vit_dim=80, vit_depth=1,
+                        vit_heads=1, vit_mlp=80)
+    for F in (4, 3):
+        fr = torch.randint(0, 256, (F, 3, 56, 84), generator=torch.Generator().manual_seed(F), dtype=torch.uint8)
+        want, grid = O.patchify_frames(fr, cfg)
+        got, g2 = K.patchify(fr.to(dev), kpad=1216)
+        assert tuple(g2) == tuple(grid)
+        assert_close(got[:, :1176], want, 2e-2, 1e-2, "patchify")
+        assert float(got[:, 1176:].float().abs().sum()) == 0
+
+
+# ----------------------------------------------------------------------------------------------- loss
+def test_logprob(dev):
+    rows, V = 33, 152064 // 16 + 3
+    lgp = torch.zeros(rows, (V + 3) // 4 * 4, device=dev)      # row stride must be a multiple of 4 floats
+    lgp[:, :V] = rnd((rows, V), dev, 1, 3.0, torch.float32)
+    lg = lgp[:, :V]
+    tgt = torch.randint(0, V, (rows,), generator=torch.Generator().manual_seed(2)).to(dev)
+    lp, lse = K.logprob_fwd(lg, tgt)
+    want = torch.log_softmax(lg.double(), -1).gather(1, tgt[:, None]).squeeze(1)
+    assert_close(lp, want, 2e-5, 1e-5, "logprob fwd")
+    g = rnd((rows,), dev, 3, dtype=torch.float32)
+    dl = K.logprob_bwd(lg, tgt, lse, g)
+    wantd = (torch.softmax(lg.double(), -1) - torch.nn.functional.one_hot(tgt, V)) * g[:, None]
+    assert_close(dl, wantd, 1e-5, 1e-2, "logprob bwd")
+
+
+def test_grpo_loss_and_mask(dev):
+    G, Cc, beta = 8, 70, 0.04
+    gen = torch.Generator().manual_seed(0)
+    lp = -torch.rand(G, Cc, generator=gen) * 3
+    ref = lp + torch.randn(G, Cc, generator=gen) * 0.5
+    ref[0, 0] = lp[0, 0] + 15; ref[0, 1] = lp[0, 1] - 15          # clamp edges
+    ids = torch.randint(5, 100, (G, Cc), generator=gen); ids[1, 10] = 7; ids[1, 20] = 7; ids[2, 0] = 7; ids[3, Cc - 1] = 7
+    mask = GR.completion_mask(ids, 7)
+    m2, lens = K.completion_mask(ids.to(dev), 7)
+    assert torch.equal(m2.cpu(), mask) and torch.equal(lens.cpu().long(), mask.sum(1))
+    adv = torch.randn(G, generator=gen)
+    loss_o, grad_o = GR.grpo_loss_and_grad(lp, ref, adv, mask, beta)
+    loss, kl, dlp = K.grpo_loss(lp.to(dev), ref.to(dev), adv.to(dev), m2, beta)
+    assert_close(loss, loss_o.reshape(1), 1e-5, 1e-5, "grpo loss")
+    assert_close(kl, GR.kl_metric(lp, ref, mask).reshape(1), 1e-5, 1e-5, "kl metric")
+    assert_close(dlp, grad_o, 1e-7, 1e-4, "grpo dlogp")
+
+
+def test_adamw_and_sumsq(dev):
+    n = 10007
+    p0 = rnd((n,), dev, 1, dtype=torch.float32); g = rnd((n,), dev, 2, 3.0, dtype=torch.float32)
+    ref_p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref_p], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    p = p0.clone(); m = torch.zeros_like(p); v = torch.zeros_like(p); sh = torch.empty(n, device=dev, dtype=BF)
+    for step in (1, 2, 3):
+        acc = torch.zeros(1, device=dev)
+        K.sumsq_(g, acc)
+        assert_close(acc, (g.double() ** 2).sum().reshape(1), 1e-2, 1e-5, "sumsq")
+        ref_p.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_([ref_p], 5.0)
+        opt.step()
+        K.adamw_step_(p, sh, m, v, g, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, step=step,
+                      sumsq=acc, max_norm=5.0)
+        assert_close(p, ref_p.data, 1e-6, 1e-5, f"adamw step {step}")
+        assert torch.equal(sh, p.to(BF))
+
+
+# ----------------------------------------------------------------------------------------------- sampler
+def test_sampler_support_and_distribution(dev):
+    V, B = 5000, 64
+    g = torch.Generator().manual_seed(0)
+    base = torch.randn(V, generator=g) * 2
+    logits = base.repeat(B, 1).to(dev).contiguous()
+    step = torch.zeros(1, dtype=torch.int32, device=dev)
+    # exact support: HF chain = top_k 50 then top_p 0.95 (remove ascending cumsum <= 0.05)
+    tk = torch.topk(base, 50)
+    pr = torch.softmax(tk.values.double(), 0)
+    asc = torch.flip(pr, [0]).cumsum(0)
+    removed = int((asc <= 1 - 0.95).sum())
+    support = set(tk.indices[:50 - removed].tolist())
+    probs = (pr[:50 - removed] / pr[:50 - removed].sum()).numpy()
+    counts = {}
+    n_draw = 0
+    for s in range(60):
+        step.fill_(s)
+        ids = K.sample_top_p(logits, step, top_k=50, top_p=0.95, seed=1234)
+        for t in ids.tolist():
+            assert t in support, f"token {t} outside the nucleus"
+            counts[t] = counts.get(t, 0) + 1
+        n_draw += B
+    # chi-square on the 8 most likely tokens + rest
+    import numpy as np
+    order = tk.indices[:50 - removed].tolist()
+    obs = np.array([counts.get(t, 0) for t in order[:8]] + [sum(counts.get(t, 0) for t in order[8:])], dtype=float)
+    exp = np.array(list(probs[:8]) + [probs[8:].sum()]) * n_draw
+    chi2 = float(((obs - exp) ** 2 / exp).sum())
+    assert chi2 < 40.0, (chi2, obs, exp)          # 8 dof, p ~ 1e-5
+    # determinism for a fixed (seed, step); eos suppression and finished rows
+    step.fill_(3)
+    a = K.sample_top_p(logits, step, seed=7); b = K.sample_top_p(logits, step, seed=7)
+    assert torch.equal(a, b)
+    top = int(base.argmax())
+    fin = torch.zeros(B, dtype=torch.int32, device=dev); fin[5] = 1
+    ids = K.sample_top_p(logits, step, top_k=1, top_p=1.0, eos_id=top, pad_id=4242, finished=fin)
+    assert int(ids[5]) == 4242 and all(int(t) == top for i, t in enumerate(ids.tolist()) if i != 5)
+    assert int(fin.sum()) == B                      # every live row drew eos
+    ids = K.sample_top_p(logits, step, top_k=1, top_p=1.0, eos_id=top, suppress_eos=True)
+    assert all(int(t) != top for t in ids.tolist())
