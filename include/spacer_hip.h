@@ -150,6 +150,11 @@ int spacer_bias_grad(const void* dy, long ld, float* db, int rows, int cols, spa
 /* out_bf16 = f32 (cast), and f32 accumulate/copy helpers for attention grads */
 int spacer_cast_f32_to_bf16(const float* in, void* out, long n, spacer_stream_t stream);
 int spacer_cast_bf16_to_f32(const void* in, float* out, long n, spacer_stream_t stream);
+/* out[i,:] = src[idx[i],:] (bf16) and dst[idx[i],:] += src[i,:] (bf16 -> fp32 atomics): select / scatter the hidden
+ * rows whose logits the loss reads (TR:528 keeps only positions prompt_length-1 .. end). */
+int spacer_gather_rows_bf16(const void* src, long ld, const int* idx, void* out, int n, int cols, spacer_stream_t stream);
+int spacer_scatter_add_rows_f32(const void* src, const int* idx, float* dst, long ld, int n, int cols,
+                                spacer_stream_t stream);
 int spacer_cast_f32_to_bf16_strided(const float* in, long ld_in, void* out, long ld_out, int rows, int cols,
                                     spacer_stream_t stream);
 
@@ -174,7 +179,7 @@ int spacer_patchify(const uint8_t* frames, void* out, int F, int Hpx, int Wpx, i
 
 /* ------------------------------------------------------------------------------------------------
  * Per-token log-probs (TR:353-366) from fp32 logits rows: logp[r] = logits[r, tgt[r]] - logsumexp(logits[r,:]).
- * Also returns lse.  Backward overwrites logits in place with dlogits = (softmax - onehot) * g[r] as bf16
+ * Also returns lse.  Backward writes dlogits = (onehot(tgt) - softmax) * g[r] (= g[r] * d logp / d logits) as bf16
  * into `dlogits` ([rows, ldd] bf16) for the lm_head backward GEMMs.
  * ---------------------------------------------------------------------------------------------- */
 int spacer_logprob_fwd(const float* logits, long ld, const int64_t* targets, float* logp, float* lse, int rows,

@@ -51,6 +51,8 @@ SIGNATURES = {
     "spacer_cast_f32_to_bf16": [_p, _p, _l, _p],
     "spacer_cast_bf16_to_f32": [_p, _p, _l, _p],
     "spacer_cast_f32_to_bf16_strided": [_p, _l, _p, _l, _i, _i, _p],
+    "spacer_gather_rows_bf16": [_p, _l, _p, _p, _i, _i, _p],
+    "spacer_scatter_add_rows_f32": [_p, _p, _p, _l, _i, _i, _p],
     "spacer_embed_fwd": [_p, _p, _p, _p, _p, _i, _i, _p],
     "spacer_embed_bwd": [_p, _p, _p, _p, _p, _i, _i, _p],
     "spacer_patchify": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],

@@ -281,7 +281,9 @@ extern "C" int spacer_attn_decode(const void* q, const void* prefix_k, const voi
     switch (rep) {
         case 1: LAUNCH(1); break;
         case 2: LAUNCH(2); break;
+        case 3: LAUNCH(3); break;
         case 4: LAUNCH(4); break;
+        case 5: LAUNCH(5); break;
         case 6: LAUNCH(6); break;
         case 7: LAUNCH(7); break;
         case 8: LAUNCH(8); break;

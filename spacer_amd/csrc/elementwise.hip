@@ -237,6 +237,28 @@ __global__ __launch_bounds__(NT) void patchify_kernel(const uint8_t* __restrict_
     }
 }
 
+// ------------------------------------------------------------------ row gather / scatter-add (logit positions)
+__global__ __launch_bounds__(NT) void gather_rows_kernel(const bf16_t* __restrict__ src, long ld, const int* __restrict__ idx,
+                                                         bf16_t* __restrict__ out, int n, int cols) {
+    const int per = cols >> 3;
+    const long total = (long)n * per;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const long r = i / per; const int c = (int)(i % per) * 8;
+        *(uint4*)(out + r * cols + c) = *(const uint4*)(src + (long)idx[r] * ld + c);
+    }
+}
+__global__ __launch_bounds__(NT) void scatter_add_rows_kernel(const bf16_t* __restrict__ src, const int* __restrict__ idx,
+                                                              float* __restrict__ dst, long ld, int n, int cols) {
+    const int per = cols >> 2;
+    const long total = (long)n * per;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const long r = i / per; const int c = (int)(i % per) * 4;
+        const uint2 v = *(const uint2*)(src + r * cols + c);
+        float* p = dst + (long)idx[r] * ld + c;
+        atomicAdd(p, bf_lo(v.x)); atomicAdd(p + 1, bf_hi(v.x)); atomicAdd(p + 2, bf_lo(v.y)); atomicAdd(p + 3, bf_hi(v.y));
+    }
+}
+
 // ------------------------------------------------------------------ transpose with zero padding
 // out[c, r] = in[r, c] for r < R, 0 for R <= r < Rpad.   64x64 tiles through LDS.
 __global__ __launch_bounds__(NT) void transpose_kernel(const bf16_t* __restrict__ in, long ld_in,
@@ -358,6 +380,24 @@ extern "C" int spacer_patchify(const uint8_t* frames, void* out, int F, int Hpx,
     const int gt = (F + tpatch - 1) / tpatch, gh = Hpx / patch, gw = Wpx / patch;
     hipLaunchKernelGGL(patchify_kernel, dim3(grid_for((long)gt * gh * gw * Kpad)), dim3(NT), 0, (hipStream_t)stream,
                        frames, (bf16_t*)out, F, Hpx, Wpx, patch, tpatch, merge, Kpad, gt, gh, gw);
+    SP_CHECK_LAUNCH();
+    return SPACER_OK;
+}
+extern "C" int spacer_gather_rows_bf16(const void* src, long ld, const int* idx, void* out, int n, int cols,
+                                       spacer_stream_t stream) {
+    SP_REQUIRE(cols % 8 == 0 && ld % 8 == 0, SPACER_EINVAL, "gather_rows: cols/ld must be multiples of 8");
+    if (n <= 0) return SPACER_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((long)n * cols / 8)), dim3(NT), 0, (hipStream_t)stream,
+                       (const bf16_t*)src, ld, idx, (bf16_t*)out, n, cols);
+    SP_CHECK_LAUNCH();
+    return SPACER_OK;
+}
+extern "C" int spacer_scatter_add_rows_f32(const void* src, const int* idx, float* dst, long ld, int n, int cols,
+                                           spacer_stream_t stream) {
+    SP_REQUIRE(cols % 4 == 0, SPACER_EINVAL, "scatter_add_rows: cols must be a multiple of 4");
+    if (n <= 0) return SPACER_OK;
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid_for((long)n * cols / 4)), dim3(NT), 0, (hipStream_t)stream,
+                       (const bf16_t*)src, idx, dst, ld, n, cols);
     SP_CHECK_LAUNCH();
     return SPACER_OK;
 }

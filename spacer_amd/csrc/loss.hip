@@ -38,7 +38,7 @@ __global__ __launch_bounds__(NT) void logprob_fwd_kernel(const float* __restrict
     }
 }
 
-// dlogits[r, v] = (softmax(r)[v] - [v == tgt[r]]) * g[r]   (bf16 out, feeds the lm_head backward GEMMs)
+// dlogits[r, v] = d logp[r] / d logits[r, v] * g[r] = ([v == tgt[r]] - softmax(r)[v]) * g[r]   (bf16 out)
 __global__ __launch_bounds__(NT) void logprob_bwd_kernel(const float* __restrict__ logits, long ld,
                                                          const int64_t* __restrict__ tgt, const float* __restrict__ lse,
                                                          const float* __restrict__ g, bf16_t* __restrict__ dl, long ldd,
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(NT) void logprob_bwd_kernel(const float* __restrict
     for (int row = blockIdx.y; row < rows; row += gridDim.y) {
         const float* p = logits + (long)row * ld;
         bf16_t* o = dl + (long)row * ldd;
-        const float L = lse[row], gr = g[row];
+        const float L = lse[row], gr = -g[row];   // kernel computes (softmax - onehot) * (-g)
         const int t = (int)tgt[row];
         for (int i = blockIdx.x * NT + threadIdx.x; i < v4; i += gridDim.x * NT) {
             const float4 x = *(const float4*)(p + i * 4);

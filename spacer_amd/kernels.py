@@ -223,6 +223,23 @@ def cast_f32(x, *, out=None):
     return out
 
 
+def gather_rows(src, idx32, *, out=None):
+    n, cols = idx32.shape[0], src.shape[1]
+    if out is None:
+        out = torch.empty(n, cols, device=src.device, dtype=BF16)
+    check(_lib.load().spacer_gather_rows_bf16(_ptr(src), _rowmajor(src), _ptr(idx32), _ptr(out), n, cols, _stream()),
+          "gather_rows_bf16")
+    return out
+
+
+def scatter_add_rows_(src, idx32, dst32):
+    n, cols = src.shape
+    assert src.is_contiguous() and dst32.dtype == torch.float32
+    check(_lib.load().spacer_scatter_add_rows_f32(_ptr(src), _ptr(idx32), _ptr(dst32), _rowmajor(dst32), n, cols, _stream()),
+          "scatter_add_rows_f32")
+    return dst32
+
+
 def embed_fwd(ids, table, video, video_row_of_token, *, out=None):
     T, H = ids.shape[0], table.shape[1]
     if out is None:

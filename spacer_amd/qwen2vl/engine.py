@@ -1,0 +1,280 @@
+"""Qwen2-VL forward / backward expressed as a sequence of libspacer_hip.so launches.
+
+This replaces what the reference obtains from HF ``Qwen2VLForConditionalGeneration`` + autograd + flash-attn
+(SG_RLVR_trainer.py:357 ``model(input_ids, **kwargs).logits`` and ``loss.backward()``).  Python only orders
+the launches and owns the buffers; every tensor op is a hand-written gfx950 kernel.
+
+Conventions
+  * residual stream fp32, GEMM operands / activations bf16, gradients of parameters fp32 (accumulated in place)
+  * one token-packed batch per call; attention structure given as segments (see include/spacer_hip.h)
+  * no recompute: 288 GB of HBM holds every layer's activations for a 5.5k-token prompt group (~27 GB)
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from .. import kernels as K
+from . import positions as POS
+from .config import Qwen2VLConfig
+from .weights import FlatParams
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+class Qwen2VLEngine:
+    def __init__(self, cfg: Qwen2VLConfig, params: FlatParams):
+        self.cfg = cfg
+        self.W = params
+        self.dev = params.flat.device
+        self._wT: Dict[str, torch.Tensor] = {}
+
+    # ------------------------------------------------------------------ helpers
+    def invalidate_cache(self) -> None:
+        """Call after the optimizer rewrites the bf16 weights: drops the cached W^T copies."""
+        self._wT.clear()
+
+    def wT(self, name: str) -> torch.Tensor:
+        """W^T ([in, out], contraction dim = out) for the dX GEMMs; built on first use per optimizer step."""
+        t = self._wT.get(name)
+        if t is None:
+            w = self.W[name]
+            assert w.shape[0] % 64 == 0, f"{name}: output dim must be a multiple of 64 for the dX GEMM"
+            t = K.transpose_pad(w, w.shape[0])
+            self._wT[name] = t
+        return t
+
+    @staticmethod
+    def _dw(gw: torch.Tensor, dy: torch.Tensor, x: torch.Tensor) -> None:
+        """gw[N,K] (fp32) += dy[T,N]^T @ x[T,K]  via two zero-padded transposes and the NT GEMM."""
+        K.gemm_nt(K.transpose_pad(dy), K.transpose_pad(x), out=gw, residual=gw)
+
+    def _zeros(self, *shape, dtype=F32):
+        return torch.zeros(*shape, device=self.dev, dtype=dtype)
+
+    def _empty(self, *shape, dtype=F32):
+        return torch.empty(*shape, device=self.dev, dtype=dtype)
+
+    # ================================================================== vision tower
+    def vit_forward(self, pix: torch.Tensor, grids: Sequence[Tuple[int, int, int]], tape: Optional[dict] = None):
+        """pix bf16 [Np, patch_kpad] (spacer_patchify output) -> merged video embeds bf16 [Np/4, hidden]."""
+        cfg, W = self.cfg, self.W
+        D, Hh, hd = cfg.vit_dim, cfg.vit_heads, cfg.vit_head_dim
+        Np = pix.shape[0]
+        cos, sin = POS.vit_tables(grids, cfg, self.dev)
+        seg_list = POS.vit_segments(grids)
+        segs = K.make_segments(seg_list, self.dev)
+        max_q = max(s[1] for s in seg_list)
+        scale = hd ** -0.5
+        x = K.gemm_nt(pix, W["vit.patch_w"], out_dtype=F32)
+        blocks: List[dict] = []
+        for i in range(cfg.vit_depth):
+            p = f"vit.{i}."
+            mean1, rstd1 = self._empty(Np), self._empty(Np)
+            h = K.layernorm_fwd(x, W[p + "n1_w"], W[p + "n1_b"], 1e-6, mean=mean1, rstd=rstd1)
+            qkv = K.gemm_nt(h, W[p + "qkv_w"], bias=W[p + "qkv_b"])
+            K.rope_(qkv, cos, sin, 2 * Hh, hd)
+            o, lse = K.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], segs, max_q, Hh, Hh, hd, False, scale)
+            x_mid = K.gemm_nt(o, W[p + "proj_w"], bias=W[p + "proj_b"], residual=x, out_dtype=F32)
+            mean2, rstd2 = self._empty(Np), self._empty(Np)
+            h2 = K.layernorm_fwd(x_mid, W[p + "n2_w"], W[p + "n2_b"], 1e-6, mean=mean2, rstd=rstd2)
+            f1 = K.gemm_nt(h2, W[p + "fc1_w"], bias=W[p + "fc1_b"])
+            a = K.act_fwd(f1, K.SPACER_ACT_QUICK_GELU)
+            x_out = K.gemm_nt(a, W[p + "fc2_w"], bias=W[p + "fc2_b"], residual=x_mid, out_dtype=F32)
+            if tape is not None:
+                blocks.append(dict(x_in=x, mean1=mean1, rstd1=rstd1, h=h, qkv=qkv, o=o, lse=lse, x_mid=x_mid, mean2=mean2,
+                                   rstd2=rstd2, h2=h2, f1=f1, a=a))
+            x = x_out
+        mean, rstd = self._empty(Np), self._empty(Np)
+        hm = K.layernorm_fwd(x, W["merger.ln_w"], W["merger.ln_b"], 1e-6, mean=mean, rstd=rstd)
+        m4 = cfg.merge ** 2
+        hm4 = hm.view(Np // m4, m4 * D)
+        m1 = K.gemm_nt(hm4, W["merger.m0_w"], bias=W["merger.m0_b"])
+        g = K.act_fwd(m1, K.SPACER_ACT_GELU_ERF)
+        out = K.gemm_nt(g, W["merger.m2_w"], bias=W["merger.m2_b"])
+        if tape is not None:
+            tape.update(pix=pix, blocks=blocks, x_last=x, mean=mean, rstd=rstd, hm4=hm4, m1=m1, g=g, cos=cos, sin=sin,
+                        segs=segs, max_q=max_q)
+        return out
+
+    def vit_backward(self, tape: dict, d_out: torch.Tensor, G: FlatParams) -> None:
+        """d_out bf16 [Nv, hidden] = gradient of the merged video embeds; accumulates into G (fp32)."""
+        cfg, W = self.cfg, self.W
+        D, Hh, hd = cfg.vit_dim, cfg.vit_heads, cfg.vit_head_dim
+        Np = tape["pix"].shape[0]
+        scale = hd ** -0.5
+        cos, sin, segs, max_q = tape["cos"], tape["sin"], tape["segs"], tape["max_q"]
+        # merger
+        d_g = K.gemm_nt(d_out, self.wT("merger.m2_w"))
+        self._dw(G["merger.m2_w"], d_out, tape["g"]); K.bias_grad_(d_out, G["merger.m2_b"])
+        d_m1 = K.act_bwd(tape["m1"], d_g, K.SPACER_ACT_GELU_ERF)
+        d_hm4 = K.gemm_nt(d_m1, self.wT("merger.m0_w"))
+        self._dw(G["merger.m0_w"], d_m1, tape["hm4"]); K.bias_grad_(d_m1, G["merger.m0_b"])
+        dx = self._empty(Np, D)
+        K.layernorm_bwd(tape["x_last"], W["merger.ln_w"], d_hm4.view(Np, D), tape["mean"], tape["rstd"], dx,
+                        G["merger.ln_w"], G["merger.ln_b"], accumulate=False)
+        for i in reversed(range(cfg.vit_depth)):
+            p = f"vit.{i}."
+            t = tape["blocks"][i]
+            dyb = K.cast_bf16(dx)
+            d_a = K.gemm_nt(dyb, self.wT(p + "fc2_w"))
+            self._dw(G[p + "fc2_w"], dyb, t["a"]); K.bias_grad_(dyb, G[p + "fc2_b"])
+            d_f1 = K.act_bwd(t["f1"], d_a, K.SPACER_ACT_QUICK_GELU)
+            d_h2 = K.gemm_nt(d_f1, self.wT(p + "fc1_w"))
+            self._dw(G[p + "fc1_w"], d_f1, t["h2"]); K.bias_grad_(d_f1, G[p + "fc1_b"])
+            K.layernorm_bwd(t["x_mid"], W[p + "n2_w"], d_h2, t["mean2"], t["rstd2"], dx, G[p + "n2_w"], G[p + "n2_b"])
+            dyb = K.cast_bf16(dx)
+            d_o = K.gemm_nt(dyb, self.wT(p + "proj_w"))
+            self._dw(G[p + "proj_w"], dyb, t["o"]); K.bias_grad_(dyb, G[p + "proj_b"])
+            qkv = t["qkv"]
+            d_qkv = torch.empty_like(qkv)
+            dk32, dv32 = self._zeros(Np, D), self._zeros(Np, D)
+            K.attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], t["o"], d_o, t["lse"], segs, max_q, Hh, Hh, hd, False,
+                       scale, dq=d_qkv[:, :D], dk32=dk32, dv32=dv32)
+            K.cast_bf16_strided(dk32, d_qkv[:, D:2 * D]); K.cast_bf16_strided(dv32, d_qkv[:, 2 * D:])
+            K.rope_(d_qkv, cos, sin, 2 * Hh, hd, inverse=True)
+            d_h = K.gemm_nt(d_qkv, self.wT(p + "qkv_w"))
+            self._dw(G[p + "qkv_w"], d_qkv, t["h"]); K.bias_grad_(d_qkv, G[p + "qkv_b"])
+            K.layernorm_bwd(t["x_in"], W[p + "n1_w"], d_h, t["mean1"], t["rstd1"], dx, G[p + "n1_w"], G[p + "n1_b"])
+            tape["blocks"][i] = None
+        self._dw(G["vit.patch_w"], K.cast_bf16(dx), tape["pix"])
+
+    # ================================================================== language model
+    def llm_forward(self, x: torch.Tensor, cos, sin, segs, max_q: int, *, tape: Optional[list] = None, kv_sink=None):
+        """x fp32 [T, hidden] input embeddings -> fp32 [T, hidden] before the final norm."""
+        cfg, W = self.cfg, self.W
+        Hq, Hkv, D, I = cfg.heads, cfg.kv_heads, cfg.head_dim, cfg.intermediate
+        T = x.shape[0]
+        qd, kd = Hq * D, Hkv * D
+        scale = D ** -0.5
+        for i in range(cfg.layers):
+            p = f"llm.{i}."
+            rstd1 = self._empty(T)
+            h = K.rmsnorm_fwd(x, W[p + "ln1_w"], cfg.rms_eps, rstd=rstd1)
+            qkv = K.gemm_nt(h, W[p + "qkv_w"], bias=W[p + "qkv_b"])
+            K.rope_(qkv, cos, sin, Hq + Hkv, D)
+            q, k, v = qkv[:, :qd], qkv[:, qd:qd + kd], qkv[:, qd + kd:]
+            o, lse = K.attn_fwd(q, k, v, segs, max_q, Hq, Hkv, D, True, scale)
+            if kv_sink is not None:
+                kv_sink(i, k, v)
+            x_mid = K.gemm_nt(o, W[p + "o_w"], residual=x, out_dtype=F32)
+            rstd2 = self._empty(T)
+            h2 = K.rmsnorm_fwd(x_mid, W[p + "ln2_w"], cfg.rms_eps, rstd=rstd2)
+            gu = K.gemm_nt(h2, W[p + "gu_w"])
+            a = K.swiglu_fwd(gu)
+            x_out = K.gemm_nt(a, W[p + "down_w"], residual=x_mid, out_dtype=F32)
+            if tape is not None:
+                tape.append(dict(x_in=x, rstd1=rstd1, h=h, qkv=qkv, o=o, lse=lse, x_mid=x_mid, rstd2=rstd2, h2=h2, gu=gu, a=a))
+            x = x_out
+        return x
+
+    def llm_backward(self, tape: list, dx: torch.Tensor, G: FlatParams, cos, sin, segs, max_q: int) -> torch.Tensor:
+        """dx fp32 [T, hidden] = grad of the pre-final-norm stream (updated in place); returns d(embeddings)."""
+        cfg, W = self.cfg, self.W
+        Hq, Hkv, D = cfg.heads, cfg.kv_heads, cfg.head_dim
+        T = dx.shape[0]
+        qd, kd = Hq * D, Hkv * D
+        scale = D ** -0.5
+        for i in reversed(range(cfg.layers)):
+            p = f"llm.{i}."
+            t = tape[i]
+            dyb = K.cast_bf16(dx)
+            d_a = K.gemm_nt(dyb, self.wT(p + "down_w"))
+            self._dw(G[p + "down_w"], dyb, t["a"])
+            d_gu = K.swiglu_bwd(t["gu"], d_a)
+            d_h2 = K.gemm_nt(d_gu, self.wT(p + "gu_w"))
+            self._dw(G[p + "gu_w"], d_gu, t["h2"])
+            K.rmsnorm_bwd(t["x_mid"], W[p + "ln2_w"], d_h2, t["rstd2"], dx, G[p + "ln2_w"])
+            dyb = K.cast_bf16(dx)
+            d_o = K.gemm_nt(dyb, self.wT(p + "o_w"))
+            self._dw(G[p + "o_w"], dyb, t["o"])
+            qkv = t["qkv"]
+            d_qkv = torch.empty_like(qkv)
+            dk32, dv32 = self._zeros(T, kd), self._zeros(T, kd)
+            K.attn_bwd(qkv[:, :qd], qkv[:, qd:qd + kd], qkv[:, qd + kd:], t["o"], d_o, t["lse"], segs, max_q, Hq, Hkv, D,
+                       True, scale, dq=d_qkv[:, :qd], dk32=dk32, dv32=dv32)
+            K.cast_bf16_strided(dk32, d_qkv[:, qd:qd + kd]); K.cast_bf16_strided(dv32, d_qkv[:, qd + kd:])
+            K.rope_(d_qkv, cos, sin, Hq + Hkv, D, inverse=True)
+            d_h = K.gemm_nt(d_qkv, self.wT(p + "qkv_w"))
+            self._dw(G[p + "qkv_w"], d_qkv, t["h"]); K.bias_grad_(d_qkv, G[p + "qkv_b"])
+            K.rmsnorm_bwd(t["x_in"], W[p + "ln1_w"], d_h, t["rstd1"], dx, G[p + "ln1_w"])
+            tape[i] = None
+        return dx
+
+    # ================================================================== embeddings
+    def embed(self, ids: torch.Tensor, video: Optional[torch.Tensor]):
+        """ids int64 [T] (device); video bf16 [Nv, hidden] rows replace placeholder tokens in order."""
+        cfg = self.cfg
+        vrow = None
+        if video is not None:
+            is_vis = (ids == cfg.video_token_id) | (ids == cfg.image_token_id)
+            vrow = torch.where(is_vis, torch.cumsum(is_vis.int(), 0, dtype=torch.int32) - 1,
+                               torch.full_like(ids, -1, dtype=torch.int32)).int().contiguous()
+        return K.embed_fwd(ids, self.W["llm.embed"], video, vrow), vrow
+
+    # ================================================================== group scoring (policy / reference logps)
+    @staticmethod
+    def group_layout(P: int, Kn: int, C: int):
+        """Token layout [prompt | comp_0 | ... | comp_{K-1}] -> (segments, rows whose logits predict completions)."""
+        segs = [(0, P, 0, 0)] + [(P + k * C, C, 0, P) for k in range(Kn)]
+        t = torch.arange(C)
+        sel = torch.stack([torch.where(t == 0, torch.full_like(t, P - 1), P + k * C + t - 1) for k in range(Kn)])
+        return segs, sel.reshape(-1).int()
+
+    def score_group(self, prompt_ids: torch.Tensor, completion_ids: torch.Tensor, pix: Optional[torch.Tensor], grids,
+                    *, tape: Optional[dict] = None, era_rule: bool = False) -> torch.Tensor:
+        """Per-token log-probs [K, C] of K completions of one prompt (SG_RLVR_trainer.py:353-366,527-528),
+        computed with the prompt shared: the prompt runs once and every rollout attends its keys."""
+        cfg = self.cfg
+        Kn, C = completion_ids.shape
+        P = prompt_ids.numel()
+        T = P + Kn * C
+        vit_tape = {} if tape is not None else None
+        video = self.vit_forward(pix, grids, vit_tape) if pix is not None else None
+        ids = torch.cat([prompt_ids.reshape(-1), completion_ids.reshape(-1)])
+        x0, vrow = self.embed(ids, video)
+        pos3, delta = POS.mrope_positions(prompt_ids.tolist(), list(grids or []), cfg, era_rule)
+        comp_pos = (P + delta) + torch.arange(C)                       # same for every rollout
+        pos_all = torch.cat([pos3] + [comp_pos.view(1, C).expand(3, C)] * Kn, dim=1)
+        cos, sin = POS.mrope_tables(pos_all, cfg, self.dev)
+        seg_list, sel = self.group_layout(P, Kn, C)
+        segs = K.make_segments(seg_list, self.dev)
+        sel = sel.to(self.dev)
+        max_q = max(P, C)
+        llm_tape = [] if tape is not None else None
+        x = self.llm_forward(x0, cos, sin, segs, max_q, tape=llm_tape)
+        rstd_f = self._empty(T)
+        hn = K.rmsnorm_fwd(x, self.W["llm.norm_w"], cfg.rms_eps, rstd=rstd_f)
+        hsel = K.gather_rows(hn, sel)
+        logits = K.gemm_nt(hsel, self.W["llm.lm_head"], out_dtype=F32)
+        targets = completion_ids.reshape(-1).contiguous()
+        logp, lse = K.logprob_fwd(logits, targets)
+        if tape is not None:
+            tape.update(vit=vit_tape, llm=llm_tape, ids=ids, vrow=vrow, cos=cos, sin=sin, segs=segs, max_q=max_q, sel=sel,
+                        x_final=x, rstd_f=rstd_f, hsel=hsel, logits=logits, targets=targets, lse=lse, T=T,
+                        has_video=video is not None)
+        return logp.view(Kn, C)
+
+    def backward_group(self, tape: dict, dlogp: torch.Tensor, G: FlatParams) -> None:
+        """Back-propagates d loss / d logp (fp32 [K, C]) through lm_head, the LLM, the embeddings and the ViT."""
+        cfg, W = self.cfg, self.W
+        T, H = tape["T"], cfg.hidden
+        dlogits = K.logprob_bwd(tape["logits"], tape["targets"], tape["lse"], dlogp.reshape(-1).contiguous())
+        tape["logits"] = None
+        d_hsel = K.gemm_nt(dlogits, self.wT("llm.lm_head"))
+        self._dw(G["llm.lm_head"], dlogits, tape["hsel"])
+        del dlogits
+        d_hn32 = self._zeros(T, H)
+        K.scatter_add_rows_(d_hsel, tape["sel"], d_hn32)
+        d_hn = K.cast_bf16(d_hn32)
+        dx = d_hn32                                                     # reuse the buffer for the stream gradient
+        K.rmsnorm_bwd(tape["x_final"], W["llm.norm_w"], d_hn, tape["rstd_f"], dx, G["llm.norm_w"], accumulate=False)
+        dx = self.llm_backward(tape["llm"], dx, G, tape["cos"], tape["sin"], tape["segs"], tape["max_q"])
+        d_video = None
+        if tape["has_video"]:
+            nv = int((tape["vrow"] >= 0).sum())
+            d_video = self._zeros(nv, H)
+        K.embed_bwd(tape["ids"], tape["vrow"], dx, G["llm.embed"], d_video)
+        if d_video is not None:
+            self.vit_backward(tape["vit"], K.cast_bf16(d_video), G)

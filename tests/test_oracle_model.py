@@ -1,0 +1,67 @@
+"""CPU: the fp32 oracle reproduces HF transformers' Qwen2-VL (golden vectors generated in the authoring
+container by scripts/make_golden_model.py; HF is the third-party model the reference trainer calls).
+Tolerance: fp32 round-off of a 2-layer model, 5e-5 absolute on logits/log-probs."""
+import torch
+
+from golden_util import load_tiny
+from oracle import qwen2vl_fp32 as O
+
+
+def test_vit_matches_hf():
+    g = load_tiny()
+    rows, grid = O.patchify_frames(g["frames"], g["cfg"])
+    assert tuple(grid) == g["grid"]
+    out = O.vit_forward(g["w"], g["cfg"], rows, [grid])
+    assert torch.allclose(out, g["hf_vit"], atol=2e-5, rtol=1e-4)
+
+
+def test_logits_and_logps_match_hf():
+    g = load_tiny()
+    rows, grid = O.patchify_frames(g["frames"], g["cfg"])
+    ids = torch.cat([g["prompt"], g["completions"][0]])
+    lg = O.full_logits(g["w"], g["cfg"], ids, rows, [grid])
+    assert (lg - g["hf_logits_row0"]).abs().max() < 5e-5
+    lp = O.completion_logps(g["w"], g["cfg"], g["prompt"], g["completions"], rows, [grid])
+    assert (lp - g["hf_logps"]).abs().max() < 5e-5
+
+
+def test_mrope_positions_match_hf_and_era_rule():
+    g = load_tiny()
+    ids = torch.cat([g["prompt"], g["completions"][0]]).tolist()
+    pos, delta = O.mrope_position_ids(ids, [g["grid"]], g["cfg"])
+    assert torch.equal(pos, g["hf_pos"]) and delta == g["hf_delta"]
+    # era (transformers 4.x) rule agrees when gt <= max(gh, gw)/merge, and differs for a long thin video
+    pos_e, _ = O.mrope_position_ids(ids, [g["grid"]], g["cfg"], era_rule=True)
+    assert torch.equal(pos_e, pos)
+    cfg = g["cfg"]
+    thin = [cfg["video_token_id"]] * (8 * 1 * 1) + [5, 6]
+    p5, _ = O.mrope_position_ids(thin, [(8, 2, 2)], cfg)
+    p4, _ = O.mrope_position_ids(thin, [(8, 2, 2)], cfg, era_rule=True)
+    assert int(p5[0, -2]) == 1 and int(p4[0, -2]) == 8
+
+
+def test_shared_prefix_mask_equals_independent_rows():
+    """The engine's packed layout (prompt once, K rollouts attending it) is the same function as K independent
+    causal rows -- checked here on the oracle itself so the GPU test can rely on either form."""
+    g = load_tiny()
+    cfg, w = g["cfg"], g["w"]
+    rows, grid = O.patchify_frames(g["frames"], cfg)
+    ve = O.vit_forward(w, cfg, rows, [grid])
+    P, (Kn, C) = g["prompt"].numel(), g["completions"].shape
+    ids = torch.cat([g["prompt"], g["completions"].reshape(-1)])
+    e = O.embed_with_video(w, cfg, ids, ve)
+    pos3, delta = O.mrope_position_ids(g["prompt"].tolist(), [grid], cfg)
+    comp = (P + delta + torch.arange(C)).view(1, C).expand(3, C)
+    pos = torch.cat([pos3] + [comp] * Kn, 1)
+    T = P + Kn * C
+    mask = torch.zeros(T, T, dtype=torch.bool)
+    mask[:P, :P] = torch.ones(P, P, dtype=torch.bool).tril()
+    for k in range(Kn):
+        a = P + k * C
+        mask[a:a + C, :P] = True
+        mask[a:a + C, a:a + C] = torch.ones(C, C, dtype=torch.bool).tril()
+    lg = O.llm_forward(w, cfg, e, pos, mask)
+    lp = torch.log_softmax(lg, -1)
+    got = torch.stack([torch.stack([lp[P - 1 if t == 0 else P + k * C + t - 1, g["completions"][k, t]] for t in range(C)])
+                       for k in range(Kn)])
+    assert (got - g["hf_logps"]).abs().max() < 5e-5
