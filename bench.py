@@ -1,0 +1,199 @@
+#!/usr/bin/env python
+"""Headline benchmark: GRPO samples/sec (K=8 rollouts), Qwen2-VL-7B, 16-frame video, on N MI355X.
+
+    python bench.py --gpus 1 --steps 2 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one full SG-RLVR step over the rank's prompt groups on synthetic seeded inputs:
+patchify -> ViT -> prefill -> batched decode of all rollouts (C tokens, EOS suppressed) -> reference + policy
+scoring -> GRPO loss -> backward through lm_head / LLM / ViT -> gradient all-reduce (N > 1) -> AdamW.
+Nothing is skipped or cached inside the timed region.  Weak scaling: every rank runs the same number of groups.
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task statement) with two extra objects:
+  roofline      bf16 MFMA roofline of the dominant kernel (gemm_bf16_nt_kernel), measured live with HIP events on
+                the launch stream over the timed region: sum(2*M*N*K) / sum(duration)
+  cpu_baseline  the fp32 oracle (oracle/qwen2vl_fp32.py, kind "port") timed on the host cores on a bounded sample
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (model preset, frames, H, W, text tokens, K, completion len, prompt groups per GPU)
+    "cfg3": ("Qwen2-VL-7B", 16, 280, 364, 360, 8, 512, 8),     # BASELINE.json configs[2]: the config the metric is quoted on
+    "cfg2": ("Qwen2-VL-2B", 8, 280, 364, 360, 4, 512, 4),      # configs[1]
+    "cfg4": ("Qwen2-VL-7B", 16, 280, 364, 360, 8, 512, 1),     # configs[3]: 1 group per GPU, as the reference script
+    "tiny": ("tiny", 4, 56, 84, 24, 4, 32, 2),
+}
+MFMA_PEAK_TFLOPS = 2500.0     # dense bf16, MI355X_MICROARCH.md
+ALGO_TF_PER_SAMPLE = {"cfg3": 53.1, "cfg4": 53.1}   # SURVEY 8(d), temporal branch off
+
+
+def cpu_baseline(cfg, seconds_budget: float = 20.0):
+    """Oracle timed on the host: one decoder layer + one ViT block of the benchmark's shapes over a small token
+    batch; FLOP rate extrapolated to the algorithmic FLOPs of one sample."""
+    from oracle import qwen2vl_fp32 as O
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    one = O.make_config(hidden=cfg.hidden, layers=1, heads=cfg.heads, kv_heads=cfg.kv_heads, intermediate=cfg.intermediate,
+                        vocab=1024, vit_dim=cfg.vit_dim, vit_depth=1, vit_heads=cfg.vit_heads, vit_mlp=cfg.vit_mlp,
+                        head_dim=cfg.head_dim)
+    w = O.random_weights(one, seed=1234)
+    T = 256
+    x = torch.randn(T, cfg.hidden) * 0.02
+    pos = torch.arange(T).view(1, T).expand(3, T)
+    per_layer = 2 * T * (cfg.hidden * cfg.qkv_dim + cfg.heads * cfg.head_dim * cfg.hidden + 3 * cfg.hidden * cfg.intermediate) \
+        + 4 * T * T * cfg.heads * cfg.head_dim // 2
+    with torch.no_grad():
+        O.llm_forward(w, one, x, pos, return_hidden=True)
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds_budget or n < 2:
+            O.llm_forward(w, one, x, pos, return_hidden=True)
+            n += 1
+        dt = time.perf_counter() - t0
+    rate = per_layer * n / dt / 1e12      # TFLOP/s on the host
+    return rate, threads, f"{n} fp32 forwards of one {cfg.hidden}-wide decoder layer over {T} tokens ({dt:.1f} s)"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--groups", type=int, default=None, help="prompt groups per GPU per step (default: workload's)")
+    ap.add_argument("--completion-len", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--phase-times", action="store_true", help="print per-phase wall times (adds synchronisations)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+        pg = dist.group.WORLD
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+
+    from spacer_amd import kernels as K
+    from spacer_amd.grpo import GRPOEngine, GRPOHyper, group_advantages, length_bonus, temporal_bonus
+    from spacer_amd.qwen2vl.config import PRESETS
+    from spacer_amd.qwen2vl.weights import FlatParams, random_init_
+    from spacer_amd.rollout import SamplingParams
+    from spacer_amd.synthetic import make_prompt, synthetic_frames, synthetic_rewards
+
+    preset, F, Hpx, Wpx, n_text, Kgen, C, groups = WORKLOADS[args.workload]
+    groups = args.groups or groups
+    C = args.completion_len or C
+    cfg = PRESETS[preset]
+    hyper = GRPOHyper(num_generations=Kgen, temporal=False, len_control=True, total_steps=1000)
+    params = FlatParams.empty(cfg, dev)
+    random_init_(params, seed=1234)
+    ge = GRPOEngine(cfg, params, hyper, process_group=pg)
+    sp = SamplingParams(max_new_tokens=C, top_k=50, top_p=0.95, temperature=1.0, seed=1234 + rank, suppress_eos=True)
+    frames = [synthetic_frames(rank * groups + g, F, Hpx, Wpx, dev) for g in range(groups)]   # resident in HBM
+    phase = {}
+
+    def tick(name, t0):
+        if args.phase_times:
+            torch.cuda.synchronize()
+            phase[name] = phase.get(name, 0.0) + time.perf_counter() - t0
+            return time.perf_counter()
+        return t0
+
+    def step(step_idx):
+        t0 = time.perf_counter()
+        prompts = [make_prompt(cfg, rank * groups + g, F, Hpx, Wpx, n_text, dev, frames_u8=frames[g])[0] for g in range(groups)]
+        comp = ge.roll.generate(prompts, Kgen, sp, use_graph=not args.no_graph)
+        t0 = tick("rollout", t0)
+        for g in range(groups):
+            cg = comp[g * Kgen:(g + 1) * Kgen]
+            rpf = synthetic_rewards(step_idx, rank * groups + g, Kgen)
+            rewards, _ = temporal_bonus(rpf, None, False, True)
+            rewards = length_bonus(rewards, rpf, torch.full((Kgen,), C), hyper.len_control)
+            adv, _ = group_advantages(rewards, Kgen)
+            ge.score_and_backward(prompts[g], cg, adv.to(dev), grad_scale=1.0 / groups)
+        t0 = tick("score+backward", t0)
+        ge.reduce_gradients()
+        ge.optimizer_step(world)
+        tick("reduce+adamw", t0)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    phase.clear()
+    K.PROFILER.reset(enabled=True)
+    barrier()
+    t_start = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    K.PROFILER.enabled = False
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    prof = K.PROFILER.summary()
+
+    if rank == 0:
+        samples = groups * Kgen * world * args.steps
+        value = samples / elapsed
+        gemm = prof.get("gemm_bf16_nt_kernel", dict(tflops=0.0, launches=0, seconds=0.0, flops=0.0))
+        out = {
+            "metric": "GRPO samples/sec (K=8 rollouts) Qwen2-VL-7B 16-frame" if args.workload in ("cfg3", "cfg4")
+            else f"GRPO samples/sec ({args.workload})",
+            "value": round(value, 4), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {preset} random-init bf16, {F} frames {Hpx}x{Wpx}, {n_text} text tokens, "
+                                   f"K={Kgen}, C={C} (EOS suppressed), {groups} prompt groups/GPU, full step "
+                                   f"(rollout+ref/policy scoring+backward+AdamW)",
+                       "global_batch": groups * Kgen * world, "parallelism": f"dp{world}", "decode_graph": not args.no_graph},
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_kernel", "achieved": round(gemm["tflops"], 2),
+                         "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gemm["tflops"] / MFMA_PEAK_TFLOPS, 4),
+                         "traffic": None, "launches": gemm["launches"],
+                         "avg_launch_us": round(1e6 * gemm["seconds"] / max(1, gemm["launches"]), 2),
+                         "share_of_step": round(gemm["seconds"] / elapsed, 3)},
+            "kernels": {k: {"tflops": round(v["tflops"], 2), "launches": v["launches"], "seconds": round(v["seconds"], 4)}
+                        for k, v in prof.items()},
+        }
+        if args.workload in ALGO_TF_PER_SAMPLE:
+            out["step_algorithmic_tflops"] = round(ALGO_TF_PER_SAMPLE[args.workload] * value / world, 2)
+        if args.phase_times:
+            out["phase_seconds_per_step"] = {k: round(v / args.steps, 3) for k, v in phase.items()}
+        if not args.no_cpu_baseline and world == 1:
+            rate, cores, sample = cpu_baseline(cfg)
+            tf_sample = ALGO_TF_PER_SAMPLE.get(args.workload)
+            out["cpu_baseline"] = {"value": (rate / tf_sample) if tf_sample else None, "unit": "samples/s", "cores": cores,
+                                   "kind": "port", "sample": sample + f"; host rate {rate * 1e3:.1f} GFLOP/s"
+                                   + (f" extrapolated to {tf_sample} TFLOP/sample" if tf_sample else "")}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

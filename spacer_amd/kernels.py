@@ -35,9 +35,53 @@ def _rowmajor(t: torch.Tensor) -> int:
     return t.stride(0)
 
 
+class _Profiler:
+    """Live per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
+    Disabled by default; when enabled every profiled launch is bracketed by two events."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []
+
+    def reset(self, enabled: bool = False):
+        self.records = []
+        self.enabled = enabled
+
+    def begin(self):
+        if not self.enabled:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream())
+        return e
+
+    def end(self, name: str, start, flops: float = 0.0, nbytes: float = 0.0):
+        if start is None:
+            return
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream())
+        self.records.append((name, start, e, flops, nbytes))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, s, e, flops, nbytes in self.records:
+            d = out.setdefault(name, dict(seconds=0.0, flops=0.0, bytes=0.0, launches=0))
+            d["seconds"] += s.elapsed_time(e) * 1e-3
+            d["flops"] += flops
+            d["bytes"] += nbytes
+            d["launches"] += 1
+        for d in out.values():
+            d["tflops"] = d["flops"] / d["seconds"] / 1e12 if d["seconds"] > 0 else 0.0
+            d["gbps"] = d["bytes"] / d["seconds"] / 1e9 if d["seconds"] > 0 else 0.0
+        return out
+
+
+PROFILER = _Profiler()
+
+
 # ----------------------------------------------------------------------------------------- GEMM
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = None, bias=None, residual=None,
-            act: int = SPACER_ACT_NONE, out_dtype=BF16, alpha: float = 1.0) -> torch.Tensor:
+            act: int = SPACER_ACT_NONE, out_dtype=BF16, alpha: float = 1.0, algo_k: Optional[int] = None) -> torch.Tensor:
     """out[M,N] = act(alpha * a[M,K] @ b[N,K]^T + bias) + residual.  a, b bf16; out bf16 or fp32."""
     M, K = a.shape
     N, K2 = b.shape
@@ -49,8 +93,11 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = N
         assert residual.dtype == out.dtype
     epi = GemmEpilogue(_ptr(bias), _ptr(residual), _rowmajor(residual) if residual is not None else 0,
                        1 if out.dtype == torch.float32 else 0, act, alpha)
+    t0 = PROFILER.begin()
     check(_lib.load().spacer_gemm_bf16_nt(_ptr(a), _rowmajor(a), _ptr(b), _rowmajor(b), _ptr(out), _rowmajor(out),
                                           M, N, K, C.byref(epi), _stream()), "gemm_bf16_nt")
+    ka = algo_k or K       # algorithmic contraction length (dW GEMMs run on a zero-padded token dim)
+    PROFILER.end("gemm_bf16_nt_kernel", t0, 2.0 * M * N * ka, 2.0 * (M * ka + N * ka) + out.element_size() * M * N)
     return out
 
 

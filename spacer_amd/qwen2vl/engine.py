@@ -24,10 +24,11 @@ BF16, F32 = torch.bfloat16, torch.float32
 
 
 class Qwen2VLEngine:
-    def __init__(self, cfg: Qwen2VLConfig, params: FlatParams):
+    def __init__(self, cfg: Qwen2VLConfig, params: FlatParams, cache_wT: bool = False):
         self.cfg = cfg
         self.W = params
         self.dev = params.flat.device
+        self.cache_wT = cache_wT          # True trades +1x weight memory for skipping the per-use transposes
         self._wT: Dict[str, torch.Tensor] = {}
 
     # ------------------------------------------------------------------ helpers
@@ -42,13 +43,14 @@ class Qwen2VLEngine:
             w = self.W[name]
             assert w.shape[0] % 64 == 0, f"{name}: output dim must be a multiple of 64 for the dX GEMM"
             t = K.transpose_pad(w, w.shape[0])
-            self._wT[name] = t
+            if self.cache_wT:
+                self._wT[name] = t
         return t
 
     @staticmethod
     def _dw(gw: torch.Tensor, dy: torch.Tensor, x: torch.Tensor) -> None:
         """gw[N,K] (fp32) += dy[T,N]^T @ x[T,K]  via two zero-padded transposes and the NT GEMM."""
-        K.gemm_nt(K.transpose_pad(dy), K.transpose_pad(x), out=gw, residual=gw)
+        K.gemm_nt(K.transpose_pad(dy), K.transpose_pad(x), out=gw, residual=gw, algo_k=dy.shape[0])
 
     def _zeros(self, *shape, dtype=F32):
         return torch.zeros(*shape, device=self.dev, dtype=dtype)

@@ -1,0 +1,174 @@
+"""Rollout engine: K sampled completions per prompt (replaces ``model.generate`` at SG_RLVR_trainer.py:463,473).
+
+What the reference pays for K rollouts -- the ViT and the prompt prefill K times, a Python iteration and a
+full-vocabulary sort per token -- is restructured for one MI355X:
+  * ViT + prefill run ONCE per prompt; the prompt's K/V (post-rotary) are kept per layer and shared by the K
+    rollouts of that prompt (decode attention reads [shared prompt KV | per-rollout tail KV]);
+  * all prompts x K rollouts decode together as one batch of <= 64 rows, so each decode step streams the
+    weights from HBM exactly once (skinny split-K GEMMs with fp32 accumulation);
+  * one decode step = a fixed launch sequence whose step-dependent scalars live in device memory, captured
+    once in a hipGraph and replayed (``use_graph``).
+Sampling semantics: temperature -> top_k -> top_p -> multinomial (HF warper order), EOS then pad.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import kernels as K
+from .qwen2vl import positions as POS
+from .qwen2vl.engine import Qwen2VLEngine
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+@dataclass
+class PromptInput:
+    ids: torch.Tensor                    # int64 [P] on device (unpadded prompt tokens)
+    pix: Optional[torch.Tensor] = None   # bf16 [Np, patch_kpad] from spacer_patchify, or None for text-only
+    grids: Optional[Sequence[Tuple[int, int, int]]] = None
+
+
+@dataclass
+class SamplingParams:
+    max_new_tokens: int = 1024
+    top_k: int = 50          # era default of transformers 4.x GenerationConfig; HF 5.x: None
+    top_p: float = 0.95      # SG_RLVR_trainer.py:280
+    temperature: float = 1.0  # :281
+    seed: int = 0
+    suppress_eos: bool = False   # fixed-length "throughput mode" of BASELINE.md
+    era_rule: bool = False
+
+
+class RolloutEngine:
+    MAX_ROWS = 64   # rows per skinny-GEMM call
+
+    def __init__(self, engine: Qwen2VLEngine):
+        self.e = engine
+        self.cfg = engine.cfg
+        self.dev = engine.dev
+        self._graph = None
+        self._graph_key = None
+
+    # ------------------------------------------------------------------ prefill
+    def _prefill(self, prompts: List[PromptInput], era_rule: bool):
+        cfg, e = self.cfg, self.e
+        L, Hkv, D = cfg.layers, cfg.kv_heads, cfg.head_dim
+        nP = len(prompts)
+        Pmax = max(p.ids.numel() for p in prompts)
+        pk = torch.zeros(L, nP, Pmax, Hkv, D, device=self.dev, dtype=BF16)
+        pv = torch.zeros_like(pk)
+        first_logits = torch.empty(nP, cfg.vocab, device=self.dev, dtype=F32)
+        plen, pos_base = [], []
+        for pi, pr in enumerate(prompts):
+            P = pr.ids.numel()
+            video = e.vit_forward(pr.pix, pr.grids) if pr.pix is not None else None
+            x0, _ = e.embed(pr.ids, video)
+            pos3, delta = POS.mrope_positions(pr.ids.tolist(), list(pr.grids or []), cfg, era_rule)
+            cos, sin = POS.mrope_tables(pos3, cfg, self.dev)
+            segs = K.make_segments([(0, P, 0, 0)], self.dev)
+
+            def sink(layer, k, v, pi=pi, P=P):
+                pk[layer, pi, :P].view(P, Hkv * D).copy_(k)
+                pv[layer, pi, :P].view(P, Hkv * D).copy_(v)
+
+            x = e.llm_forward(x0, cos, sin, segs, P, kv_sink=sink)
+            hn = K.rmsnorm_fwd(x[P - 1:P], e.W["llm.norm_w"], cfg.rms_eps)
+            K.gemm_nt(hn, e.W["llm.lm_head"], out=first_logits[pi:pi + 1])
+            plen.append(P)
+            pos_base.append(P + delta)
+        return pk, pv, first_logits, plen, pos_base
+
+    # ------------------------------------------------------------------ one decode step (graph-capturable)
+    def _decode_step(self, st: dict, sp: SamplingParams) -> None:
+        cfg, W = self.cfg, self.e.W
+        Hq, Hkv, D, I = cfg.heads, cfg.kv_heads, cfg.head_dim, cfg.intermediate
+        B = st["B"]
+        x = K.embed_fwd(st["cur_tok"], W["llm.embed"], None, None, out=st["x"])
+        K.decode_rope_table(st["pos_base"], st["step"], cfg.rope_theta, st["cos"], st["sin"])
+        scale = D ** -0.5
+        for i in range(cfg.layers):
+            p = f"llm.{i}."
+            h = K.rmsnorm_fwd(x, W[p + "ln1_w"], cfg.rms_eps, out=st["h"])
+            K.gemm_skinny_acc(h, W[p + "qkv_w"], st["acc_qkv"])
+            K.decode_qkv_finish(st["acc_qkv"], W[p + "qkv_b"], st["cos"], st["sin"], st["q"], st["tk"][i], st["tv"][i],
+                                st["tail_len"], Hq, Hkv, D)
+            o = K.attn_decode(st["q"], st["pk"][i], st["pv"][i], st["plen"], st["prompt_of"], st["tk"][i], st["tv"][i],
+                              st["tail_len"], Hq, Hkv, D, scale, out=st["o"])
+            K.gemm_skinny_acc(o, W[p + "o_w"], x)
+            h2 = K.rmsnorm_fwd(x, W[p + "ln2_w"], cfg.rms_eps, out=st["h"])
+            K.gemm_skinny_acc(h2, W[p + "gu_w"], st["acc_gu"])
+            a = K.swiglu_f32_fwd(st["acc_gu"], st["a"])
+            K.gemm_skinny_acc(a, W[p + "down_w"], x)
+        hn = K.rmsnorm_fwd(x, W["llm.norm_w"], cfg.rms_eps, out=st["h"])
+        st["logits"].zero_()
+        K.gemm_skinny_acc(hn, W["llm.lm_head"], st["logits"])
+        st["step"].add_(1)
+        st["tail_len"].add_(1)
+        K.sample_top_p(st["logits"], st["step"], top_k=sp.top_k, top_p=sp.top_p, temperature=sp.temperature, seed=sp.seed,
+                       eos_id=cfg.eos_token_id, pad_id=cfg.pad_token_id, suppress_eos=sp.suppress_eos,
+                       finished=st["finished"], out_ids=st["cur_tok"])
+
+    # ------------------------------------------------------------------ public
+    @torch.no_grad()
+    def generate(self, prompts: List[PromptInput], num_generations: int, sp: SamplingParams, *, use_graph: bool = True,
+                 stats: Optional[dict] = None) -> torch.Tensor:
+        """Returns completion ids int64 [len(prompts) * num_generations, C] (EOS kept, pad_token_id after it),
+        rows ordered prompt-major like HF's num_return_sequences expansion."""
+        cfg = self.cfg
+        nP, Kn, C = len(prompts), num_generations, sp.max_new_tokens
+        B = nP * Kn
+        if B > self.MAX_ROWS:
+            outs = []
+            per = max(1, self.MAX_ROWS // Kn)
+            for a in range(0, nP, per):
+                outs.append(self.generate(prompts[a:a + per], Kn, sp, use_graph=use_graph, stats=stats))
+            return torch.cat(outs, 0)
+        dev = self.dev
+        pk, pv, first_logits, plen, pos_base = self._prefill(prompts, sp.era_rule)
+        L, Hkv, D, H = cfg.layers, cfg.kv_heads, cfg.head_dim, cfg.hidden
+        st = dict(
+            B=B, pk=pk, pv=pv,
+            plen=torch.tensor(plen, dtype=torch.int32, device=dev),
+            prompt_of=torch.arange(B, dtype=torch.int32, device=dev) // Kn,
+            pos_base=torch.tensor(pos_base, dtype=torch.int32, device=dev).repeat_interleave(Kn).contiguous(),
+            tk=torch.zeros(L, B, C, Hkv, D, device=dev, dtype=BF16), tv=torch.zeros(L, B, C, Hkv, D, device=dev, dtype=BF16),
+            tail_len=torch.zeros(1, dtype=torch.int32, device=dev), step=torch.zeros(1, dtype=torch.int32, device=dev),
+            finished=torch.zeros(B, dtype=torch.int32, device=dev), cur_tok=torch.empty(B, dtype=torch.int64, device=dev),
+            x=torch.empty(B, H, device=dev, dtype=F32), h=torch.empty(B, H, device=dev, dtype=BF16),
+            q=torch.empty(B, cfg.heads * D, device=dev, dtype=BF16), o=torch.empty(B, cfg.heads * D, device=dev, dtype=BF16),
+            a=torch.empty(B, cfg.intermediate, device=dev, dtype=BF16),
+            acc_qkv=torch.zeros(B, cfg.qkv_dim, device=dev, dtype=F32),
+            acc_gu=torch.zeros(B, 2 * cfg.intermediate, device=dev, dtype=F32),
+            cos=torch.empty(B, D, device=dev, dtype=F32), sin=torch.empty(B, D, device=dev, dtype=F32),
+            logits=torch.empty(B, cfg.vocab, device=dev, dtype=F32),
+        )
+        out = torch.full((B, C), cfg.pad_token_id, dtype=torch.int64, device=dev)
+        # token 0 of every rollout comes from the prompt's last-position logits (K independent draws per prompt)
+        st["logits"].copy_(first_logits.repeat_interleave(Kn, 0))
+        K.sample_top_p(st["logits"], st["step"], top_k=sp.top_k, top_p=sp.top_p, temperature=sp.temperature, seed=sp.seed,
+                       eos_id=cfg.eos_token_id, pad_id=cfg.pad_token_id, suppress_eos=sp.suppress_eos,
+                       finished=st["finished"], out_ids=st["cur_tok"])
+        out[:, 0].copy_(st["cur_tok"])
+        graph = None
+        n_steps = 0
+        for s in range(1, C):
+            if use_graph and graph is None and s == 2:       # step 1 ran eagerly (warm-up); capture step 2, replay after
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    self._decode_step(st, sp)
+                graph.replay()                                # capture records only; this runs step 2
+            elif graph is not None:
+                graph.replay()
+            else:
+                self._decode_step(st, sp)
+            out[:, s].copy_(st["cur_tok"])
+            n_steps += 1
+            if not sp.suppress_eos and s % 32 == 0 and bool(st["finished"].all()):
+                break
+        if stats is not None:
+            stats["decode_steps"] = stats.get("decode_steps", 0) + n_steps
+            stats["graph"] = graph is not None
+        return out

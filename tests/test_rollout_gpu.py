@@ -1,0 +1,123 @@
+"""GPU: rollout (prefill + batched decode + sampler, eager and hipGraph) and one full GRPO step on the tiny model.
+
+Sampling cannot be bit-compared with HF's RNG stream; parity is defined on teacher-forced quantities:
+  * greedy decode (top_k = 1): every emitted token must be an arg-max of the ORACLE's next-token logits for the
+    emitted prefix, up to the bf16 noise budget (oracle logit of the chosen token within 3e-2 of the oracle max);
+  * the decode path (skinny GEMMs, KV cache, decode attention) and the scoring path (packed prefill kernels) must
+    agree on the log-prob of the same tokens within 1e-2;
+  * hipGraph replay == eager launch sequence, bit for bit."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from golden_util import load_tiny                      # noqa: E402
+from oracle import grpo_ref as GR                      # noqa: E402
+from oracle import qwen2vl_fp32 as O                   # noqa: E402
+from spacer_amd import kernels as K                    # noqa: E402
+from spacer_amd.grpo import GRPOEngine, GRPOHyper, group_advantages, length_bonus, temporal_bonus  # noqa: E402
+from spacer_amd.qwen2vl.config import TINY             # noqa: E402
+from spacer_amd.qwen2vl.weights import FlatParams, export_state_dict, load_state_dict  # noqa: E402
+from spacer_amd.rollout import PromptInput, RolloutEngine, SamplingParams  # noqa: E402
+from spacer_amd.qwen2vl.engine import Qwen2VLEngine    # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def tiny(dev):
+    g = load_tiny()
+    params = FlatParams.empty(TINY, dev)
+    load_state_dict(params, g["w"])
+    wb = {k: v.float().cpu() for k, v in export_state_dict(params).items()}
+    wb["visual.patch_embed.proj.weight"] = wb["visual.patch_embed.proj.weight"].reshape(TINY.vit_dim, -1)
+    pix, grid = K.patchify(g["frames"].to(dev), kpad=TINY.patch_kpad)
+    rows, _ = O.patchify_frames(g["frames"], g["cfg"])
+    prompts = [PromptInput(g["prompt"].to(dev), pix, [tuple(grid)]), PromptInput(g["prompt"][-9:].to(dev), None, None)]
+    return dict(g=g, params=params, wb=wb, prompts=prompts, rows=rows.to(torch.bfloat16).float(), grid=tuple(grid))
+
+
+def test_greedy_rollout_is_oracle_argmax(tiny, dev):
+    eng = Qwen2VLEngine(TINY, tiny["params"])
+    roll = RolloutEngine(eng)
+    sp = SamplingParams(max_new_tokens=7, top_k=1, top_p=1.0, suppress_eos=True)
+    out = roll.generate(tiny["prompts"], 2, sp, use_graph=False)
+    assert out.shape == (4, 7)
+    assert torch.equal(out[0], out[1]) and torch.equal(out[2], out[3])          # greedy: the K rollouts coincide
+    g = tiny["g"]
+    for pi, (pids, rows, grids) in enumerate(((g["prompt"], tiny["rows"], [tiny["grid"]]), (g["prompt"][-9:], None, None))):
+        comp = out[2 * pi].cpu()
+        ids = torch.cat([pids, comp])
+        lg = O.full_logits(tiny["wb"], g["cfg"], ids, rows, grids)
+        P = pids.numel()
+        for t in range(7):
+            row = lg[P - 1 + t].clone()
+            row[TINY.eos_token_id] = float("-inf")
+            assert float(row.max() - row[comp[t]]) < 3e-2, (pi, t, float(row.max() - row[comp[t]]))
+
+
+def test_graph_replay_equals_eager_and_scoring_agrees(tiny, dev):
+    eng = Qwen2VLEngine(TINY, tiny["params"])
+    roll = RolloutEngine(eng)
+    sp = SamplingParams(max_new_tokens=12, top_k=50, top_p=0.95, seed=11, suppress_eos=True)
+    a = roll.generate(tiny["prompts"], 3, sp, use_graph=False)
+    st = {}
+    b = roll.generate(tiny["prompts"], 3, sp, use_graph=True, stats=st)
+    assert st["graph"] and torch.equal(a, b)
+    assert len({tuple(r.tolist()) for r in a[:3]}) > 1                           # sampling: rollouts of one prompt differ
+    # log-prob of the sampled tokens: scoring path (packed, shared prefix) vs the oracle
+    lp = eng.score_group(tiny["prompts"][0].ids, a[:3], tiny["prompts"][0].pix, tiny["prompts"][0].grids)
+    want = O.completion_logps(tiny["wb"], tiny["g"]["cfg"], tiny["g"]["prompt"], a[:3].cpu(), tiny["rows"], [tiny["grid"]])
+    assert (lp.cpu() - want).abs().max() < 1e-2
+
+
+def test_eos_stops_and_pads(tiny, dev):
+    eng = Qwen2VLEngine(TINY, tiny["params"])
+    roll = RolloutEngine(eng)
+    sp = SamplingParams(max_new_tokens=40, top_k=50, top_p=0.95, seed=3)
+    out = roll.generate(tiny["prompts"][1:], 8, sp)
+    mask, lens = K.completion_mask(out, TINY.eos_token_id)
+    for r in range(out.shape[0]):
+        n = int(lens[r])
+        if n < out.shape[1]:
+            assert int(out[r, n - 1]) == TINY.eos_token_id
+            assert bool((out[r, n:] == TINY.pad_token_id).all())
+
+
+def test_full_grpo_step_matches_oracle(tiny, dev):
+    """loss, KL, d loss/d logp and the AdamW update direction of one step, against the restated trainer math."""
+    g = tiny["g"]
+    hyper = GRPOHyper(num_generations=3, beta=0.04, learning_rate=1e-3, max_grad_norm=5.0, temporal=False, len_control=True)
+    params = FlatParams(TINY, tiny["params"].flat.clone(), tiny["params"].specs)
+    ge = GRPOEngine(TINY, params, hyper)
+    # perturb the policy so that policy != ref (KL term active)
+    torch.manual_seed(0)
+    ge.policy["llm.1.down_w"].add_(torch.randn_like(ge.policy["llm.1.down_w"]) * 0.02)
+    ge.master["llm.1.down_w"].copy_(ge.policy["llm.1.down_w"].float())
+    comp = g["completions"].clone()
+    comp[1, 3] = TINY.eos_token_id                                               # one rollout stops early
+    rpf = torch.tensor([[1.0, 1.0], [0.0, 1.0], [1.9, 0.0]])
+    rewards, _ = temporal_bonus(rpf, None, hyper.temporal, True)
+    mask_o = GR.completion_mask(comp, TINY.eos_token_id)
+    rewards = length_bonus(rewards, rpf, mask_o.sum(1), hyper.len_control)
+    adv, _ = group_advantages(rewards, 3)
+    adv_o, _ = GR.group_advantages(GR.length_bonus(GR.temporal_bonus(rpf, None, False, True)[0], rpf, mask_o, True), 3)
+    assert torch.allclose(adv, adv_o)
+    pr = tiny["prompts"][0]
+    before = ge.master["llm.1.down_w"].clone()
+    res = ge.score_and_backward(pr, comp.to(dev), adv.to(dev))
+    # oracle
+    wpol = {k: v.float().cpu() for k, v in export_state_dict(ge.policy).items()}
+    wpol["visual.patch_embed.proj.weight"] = wpol["visual.patch_embed.proj.weight"].reshape(TINY.vit_dim, -1)
+    lp_o = O.completion_logps(wpol, g["cfg"], g["prompt"], comp, tiny["rows"], [tiny["grid"]])
+    ref_o = O.completion_logps(tiny["wb"], g["cfg"], g["prompt"], comp, tiny["rows"], [tiny["grid"]])
+    loss_o, dlp_o = GR.grpo_loss_and_grad(lp_o, ref_o, adv, mask_o, hyper.beta)
+    assert torch.equal(res["mask"].cpu(), mask_o)
+    assert abs(float(res["loss"]) - float(loss_o)) < 5e-3
+    assert abs(float(res["kl"]) - float(GR.kl_metric(lp_o, ref_o, mask_o))) < 5e-3
+    gnorm_before = float(ge.G.flat.double().pow(2).sum().sqrt())
+    assert gnorm_before > 0
+    ge.optimizer_step()
+    assert abs(ge.grad_norm() - gnorm_before) < 1e-3 * gnorm_before
+    assert float(ge.G.flat.abs().max()) == 0.0
+    delta = ge.master["llm.1.down_w"] - before
+    assert float(delta.abs().max()) > 0 and float(delta.abs().max()) <= 1.01e-3 * 1.2   # |AdamW step 1| ~ lr
+    assert torch.equal(ge.policy["llm.1.down_w"], ge.master["llm.1.down_w"].to(torch.bfloat16))
