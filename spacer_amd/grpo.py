@@ -87,6 +87,17 @@ def lr_at(step: int, h: GRPOHyper) -> float:
     return h.learning_rate * 0.5 * (1.0 + math.cos(math.pi * prog))
 
 
+def allreduce_flat_(flat: torch.Tensor, pg, bucket_elems: int = 1 << 28) -> torch.Tensor:
+    """SUM all-reduce of one flat tensor in a few large buckets (1 GiB of fp32 each by default), all in flight at
+    once.  On MI355X the 8 GPUs are fully connected by point-to-point xGMI links, so collectives are per-link bound:
+    few, big messages; the mean (1/world) is folded into the optimizer's grad_scale instead of a second pass."""
+    import torch.distributed as dist
+    works = [dist.all_reduce(flat[a:a + bucket_elems], group=pg, async_op=True) for a in range(0, flat.numel(), bucket_elems)]
+    for w in works:
+        w.wait()
+    return flat
+
+
 # ------------------------------------------------------------------------------------- the step engine
 class GRPOEngine:
     """Owns policy + frozen reference weights, fp32 master / Adam state / gradients, and runs the step phases."""
@@ -131,14 +142,8 @@ class GRPOEngine:
     def reduce_gradients(self) -> None:
         """Data-parallel exchange: SUM all-reduce of the flat fp32 gradient over RCCL in large buckets (xGMI is
         per-link bound: few, big collectives).  The mean is folded into the optimizer's grad_scale."""
-        if self.pg is None:
-            return
-        import torch.distributed as dist
-        flat = self.G.flat
-        bucket = 1 << 28       # 256 Mi elements = 1 GiB fp32 per collective
-        works = [dist.all_reduce(flat[a:a + bucket], group=self.pg, async_op=True) for a in range(0, flat.numel(), bucket)]
-        for w in works:
-            w.wait()
+        if self.pg is not None:
+            allreduce_flat_(self.G.flat, self.pg)
 
     def optimizer_step(self, world_size: int = 1) -> float:
         """Global-norm clip (max_grad_norm) + AdamW on fp32 master, bf16 policy refreshed in the same kernel."""

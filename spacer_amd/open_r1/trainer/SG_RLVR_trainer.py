@@ -1,0 +1,378 @@
+"""``SGRLVRTrainer``: the drop-in surface of the reference trainer on the MI355X-native engine.
+
+Same class name, constructor keywords, ``train`` / ``compute_loss`` / ``save_model`` / ``log`` methods and metric keys
+as /root/reference/SpaceR-SG-RLVR/src/r1-v/src/open_r1/trainer/SG_RLVR_trainer.py (TR: ctor :137-153, compute_loss
+:384-686, log :688-695).  What differs, by design:
+  * no HF Trainer / DeepSpeed / trl underneath: the loop, AdamW and the data-parallel exchange are this repo's
+    (spacer_amd/grpo.py); ZeRO-3 is replaced by full replicas (288 GB HBM) + one flat RCCL all-reduce;
+  * ``compute_loss`` also back-propagates (rollout -> scoring -> loss -> backward are fused into one pass over the
+    group's tape); it returns the loss tensor for logging;
+  * the nine ``gather_for_metrics`` calls (TR:650-683) are one packed all-gather;
+  * the silent try/except fallbacks (TR:405-414, 526-547) are NOT reproduced: errors surface.
+``inputs`` = list of dataset rows with keys prompt, path, data_type, problem_type, solution, problem_id, ...
+Reward functions keep the reference plugin signature f(prompts=, completions=, video_path=, **columns) -> list[float].
+"""
+from __future__ import annotations
+
+import copy
+import json
+import os
+import time
+from collections import defaultdict
+from typing import Any, Callable, Dict, List, Optional, Sequence, Union
+
+import torch
+
+from ...grpo import GRPOEngine, GRPOHyper, group_advantages, length_bonus, temporal_bonus
+from ...qwen2vl.config import Qwen2VLConfig, preset_for
+from ...qwen2vl.weights import FlatParams, export_state_dict, load_state_dict
+from ...rollout import PromptInput, SamplingParams
+from ..config import GRPOConfig, GRPOScriptArguments
+
+RewardFunc = Callable[..., List[float]]
+
+
+# ----------------------------------------------------------------------------------------- prompt text
+def is_conversational(example: dict) -> bool:
+    p = example.get("prompt")
+    return isinstance(p, list) and len(p) > 0 and isinstance(p[0], dict) and "role" in p[0]
+
+
+def qwen2vl_chat_template(messages: Sequence[dict], add_generation_prompt: bool = True) -> str:
+    """Qwen2-VL's ChatML template (what ``processing_class.apply_chat_template`` renders): a default system turn,
+    ``<|vision_start|><|video_pad|><|vision_end|>`` / image markers for media parts, text parts verbatim."""
+    out = []
+    if not messages or messages[0].get("role") != "system":
+        out.append("<|im_start|>system\nYou are a helpful assistant.<|im_end|>\n")
+    for m in messages:
+        out.append(f"<|im_start|>{m['role']}\n")
+        c = m.get("content")
+        if isinstance(c, str):
+            out.append(c)
+        else:
+            for part in c or []:
+                t = part.get("type")
+                if t == "video" or "video" in part:
+                    out.append("<|vision_start|><|video_pad|><|vision_end|>")
+                elif t == "image" or "image" in part:
+                    out.append("<|vision_start|><|image_pad|><|vision_end|>")
+                elif "text" in part and part["text"] is not None:
+                    out.append(part["text"])
+        out.append("<|im_end|>\n")
+    if add_generation_prompt:
+        out.append("<|im_start|>assistant\n")
+    return "".join(out)
+
+
+def maybe_apply_chat_template(example: dict, processing_class) -> Dict[str, str]:
+    if not is_conversational(example):
+        return {"prompt": example["prompt"]}
+    if hasattr(processing_class, "apply_chat_template"):
+        return {"prompt": processing_class.apply_chat_template(example["prompt"], tokenize=False, add_generation_prompt=True)}
+    return {"prompt": qwen2vl_chat_template(example["prompt"], add_generation_prompt=True)}
+
+
+def remove_none_from_data(data):
+    """TR:368-376: datasets.map fills absent keys of content parts with None; drop them."""
+    for entry in data:
+        if isinstance(entry.get("content"), list):
+            for sub in entry["content"]:
+                if isinstance(sub, dict):
+                    for k in [k for k, v in sub.items() if v is None]:
+                        del sub[k]
+    return data
+
+
+def repeat_columns(inputs: List[dict], n: int) -> Dict[str, list]:
+    """TR:587-591: every dataset column except prompt/completion, each value repeated n times."""
+    out: Dict[str, list] = {k: [] for k in inputs[0].keys() if k not in ("prompt", "completion")}
+    for k in out:
+        for ex in inputs:
+            out[k].extend([ex[k]] * n)
+    return out
+
+
+# ----------------------------------------------------------------------------------------- packed metrics (C2)
+METRIC_SLOTS = 16
+
+
+def pack_metrics(completion_lengths, rewards_per_func, rewards, temporal_reward, std, mean_kl) -> torch.Tensor:
+    """One fp32 vector per rank instead of nine gathers: [n_funcs, mean len, mean reward, mean std, kl, temporal,
+    all_wrong flag, all_correct flag, per-func means ...]."""
+    nf = rewards_per_func.shape[1]
+    assert 8 + nf <= METRIC_SLOTS
+    v = torch.zeros(METRIC_SLOTS, dtype=torch.float32)
+    v[0] = nf
+    v[1] = float(completion_lengths.float().mean())
+    v[2] = float(rewards.mean())
+    v[3] = float(std.mean())
+    v[4] = float(mean_kl)
+    v[5] = float(temporal_reward)
+    v[6] = float(bool((rewards <= 1).all()))          # TR:665
+    v[7] = float(bool((rewards >= 2).all()))          # TR:668
+    v[8:8 + nf] = rewards_per_func.float().mean(0)
+    return v
+
+
+def reduce_metrics(stacked: torch.Tensor, func_names: Sequence[str], temporal: bool) -> Dict[str, float]:
+    """stacked [world, METRIC_SLOTS] -> the reference's metric dict (TR:650-683): means over ranks; all_wrong /
+    all_correct are the FRACTION OF RANKS whose whole group scored <= 1 / >= 2."""
+    m = stacked.float().mean(0)
+    out = {"completion_length": float(m[1])}
+    for i, n in enumerate(func_names):
+        out[f"rewards/{n}"] = float(m[8 + i])
+    out["all_wrong"] = float(m[6])
+    out["all_correct"] = float(m[7])
+    if temporal:
+        out["temporal_rewards"] = float(m[5])
+    out["reward"] = float(m[2])
+    out["reward_std"] = float(m[3])
+    out["kl"] = float(m[4])
+    return out
+
+
+def shard_indices(n_rows: int, rank: int, world: int, seed: int, epoch: int, shuffle: bool = True) -> List[int]:
+    """DistributedSampler semantics: one shared permutation per epoch, padded to a multiple of world, rank-strided."""
+    g = torch.Generator().manual_seed(seed + epoch)
+    order = torch.randperm(n_rows, generator=g).tolist() if shuffle else list(range(n_rows))
+    total = (n_rows + world - 1) // world * world
+    order += order[:total - n_rows]
+    return order[rank:total:world]
+
+
+# ----------------------------------------------------------------------------------------- the trainer
+class SGRLVRTrainer:
+    def __init__(self, model: Union[str, FlatParams], reward_funcs: Union[RewardFunc, List[RewardFunc]],
+                 args: Optional[GRPOConfig] = None, script_args: Optional[GRPOScriptArguments] = None, train_dataset=None,
+                 eval_dataset=None, processing_class=None, reward_processing_classes=None, callbacks=None,
+                 optimizers=(None, None), peft_config=None, max_pixels: Optional[int] = 12845056,
+                 min_pixels: Optional[int] = 3136, attn_implementation: str = "flash_attention_2", *,
+                 model_config: Optional[Qwen2VLConfig] = None, device=None, process_group=None):
+        if args is None:
+            name = model if isinstance(model, str) else "model"
+            args = GRPOConfig(output_dir=f"{name.split('/')[-1]}-GRPO")
+        self.args = args
+        self.script_args = script_args or GRPOScriptArguments()
+        if peft_config is not None:
+            raise NotImplementedError("PEFT adapters are outside the SG-RLVR hot path of this engine")
+        if any(isinstance(f, str) for f in (reward_funcs if isinstance(reward_funcs, list) else [reward_funcs])):
+            raise NotImplementedError("string reward_funcs (sequence-classification reward models) are not used by SpaceR")
+        if attn_implementation not in (None, "flash_attention_2", "sdpa", "eager"):
+            raise ValueError(f"unknown attn_implementation {attn_implementation!r}")
+        self._log_lines: List[str] = []
+        self._note(f"attn_implementation={attn_implementation!r} accepted and ignored: attention is libspacer_hip's flash kernel")
+        if getattr(args, "deepspeed", None):
+            self._note(f"--deepspeed {args.deepspeed} accepted and ignored: full replicas + flat RCCL all-reduce replace ZeRO-3")
+        self.device = device or torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        self.pg = process_group
+        self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        self.rank = torch.distributed.get_rank(process_group) if process_group is not None else 0
+
+        # ---- model (policy) and reference model (a frozen copy, TR:205-217)
+        if isinstance(model, str):
+            cfg = model_config or preset_for(model)
+            params = FlatParams.empty(cfg, self.device)
+            load_state_dict(params, _read_checkpoint(model))
+            self.model_id = model
+        else:
+            params, cfg = model, (model_config or model.cfg)
+            self.model_id = getattr(model, "name", "in-memory")
+        self.cfg = cfg
+        self.processing_class = processing_class
+        if processing_class is None:
+            raise ValueError("processing_class is required (AutoProcessor of the checkpoint, or any object with the same "
+                             "__call__ / batch_decode / eos_token_id / pad_token_id surface)")
+        self.reward_funcs = reward_funcs if isinstance(reward_funcs, list) else [reward_funcs]
+        self.reward_processing_classes = reward_processing_classes or [None] * len(self.reward_funcs)
+        self.max_prompt_length = args.max_prompt_length
+        self.max_completion_length = args.max_completion_length
+        self.num_generations = args.num_generations
+        self.shuffled_num_generations = self.num_generations // 2
+        self.temporal = bool(self.script_args.temporal)
+        self.len_control = bool(self.script_args.len_control)
+        self.beta = args.beta
+        self.train_dataset, self.eval_dataset = train_dataset, eval_dataset
+        n_rows = len(train_dataset) if train_dataset is not None else 0
+        per_step = max(1, self.world * args.per_device_train_batch_size * args.gradient_accumulation_steps)
+        total_steps = args.max_steps if args.max_steps > 0 else max(1, int(n_rows * args.num_train_epochs) // per_step)
+        hyper = GRPOHyper(num_generations=args.num_generations, beta=args.beta, learning_rate=args.learning_rate,
+                          weight_decay=args.weight_decay, adam_beta1=args.adam_beta1, adam_beta2=args.adam_beta2,
+                          adam_eps=args.adam_epsilon, max_grad_norm=args.max_grad_norm, temporal=self.temporal,
+                          len_control=self.len_control, lr_scheduler_type=args.lr_scheduler_type, total_steps=total_steps,
+                          warmup_steps=args.warmup_steps)
+        self.total_steps = total_steps
+        self.engine = GRPOEngine(cfg, params, hyper, process_group=process_group)
+        self._metrics: Dict[str, list] = defaultdict(list)
+        self.global_step = 0
+        self._sample_seed = args.seed * 1000003 + self.rank
+
+    # ------------------------------------------------------------------ small helpers
+    def _note(self, msg: str) -> None:
+        self._log_lines.append(msg)
+        if int(os.environ.get("RANK", "0")) == 0:
+            print("[spacer_amd] " + msg, flush=True)
+
+    def _prompt_input(self, proc_out: dict) -> PromptInput:
+        ids = proc_out["input_ids"]
+        if self.max_prompt_length is not None:                 # TR:432-440 (left truncation of ids)
+            ids = ids[:, -self.max_prompt_length:]
+        assert ids.shape[0] == 1, "one prompt per compute_loss call, as in the reference (per_device_train_batch_size 1)"
+        ids = ids[0].to(self.device).long()
+        pix, grids = None, None
+        key = "pixel_values_videos" if "pixel_values_videos" in proc_out else ("pixel_values" if "pixel_values" in proc_out else None)
+        if key is not None:
+            pv = proc_out[key].to(self.device)
+            pix = torch.zeros(pv.shape[0], self.cfg.patch_kpad, device=self.device, dtype=torch.bfloat16)
+            pix[:, :pv.shape[1]] = pv.to(torch.bfloat16)
+            g = proc_out["video_grid_thw" if key == "pixel_values_videos" else "image_grid_thw"]
+            grids = [tuple(int(v) for v in row) for row in g.tolist()]
+        return PromptInput(ids=ids, pix=pix, grids=grids)
+
+    def _run_rewards(self, inputs, prompts, completion_ids, n, video_path=None) -> torch.Tensor:
+        """TR:576-593 (and the shuffled twin :554-572): decode, wrap, call every reward function."""
+        texts = self.processing_class.batch_decode(completion_ids, skip_special_tokens=True)
+        completions = [[{"role": "assistant", "content": t}] for t in texts] if is_conversational(inputs[0]) else texts
+        rep_prompts = [p for p in prompts for _ in range(n)]
+        out = torch.zeros(len(rep_prompts), len(self.reward_funcs), dtype=torch.float32)
+        for i, fn in enumerate(self.reward_funcs):
+            kw = repeat_columns(inputs, n)
+            if video_path is not None:
+                vals = fn(prompts=rep_prompts, completions=completions, video_path=video_path, **kw)
+            else:
+                vals = fn(prompts=rep_prompts, completions=completions, **kw)
+            out[:, i] = torch.tensor([float(v) for v in vals], dtype=torch.float32)
+        return out
+
+    # ------------------------------------------------------------------ the step (TR:384-686)
+    def compute_loss(self, model, inputs, return_outputs=False, num_items_in_batch=None, *, grad_scale: float = 1.0):
+        if return_outputs:
+            raise ValueError("The GRPOTrainer does not support returning outputs")
+        from ...qwen_vl_utils.vision_process import process_vision_info
+        eng, G = self.engine, self.num_generations
+        prompts = [x["prompt"] for x in inputs]
+        video_path = inputs[0]["path"]
+        prompts_text = [maybe_apply_chat_template(ex, self.processing_class)["prompt"] for ex in inputs]
+        conv = remove_none_from_data(copy.deepcopy(inputs[0]["prompt"]))
+        if inputs[0]["data_type"] in ("image", "video"):
+            conv[0]["content"][0][inputs[0]["data_type"]] = inputs[0]["path"]
+        image_inputs, video_inputs, _ = process_vision_info(conv, return_video_kwargs=True)
+        call = dict(return_tensors="pt", padding=True, padding_side="left", add_special_tokens=False)
+        proc = self.processing_class(text=copy.deepcopy(prompts_text), images=image_inputs, videos=video_inputs, **call)
+        prompt = self._prompt_input(proc)
+        has_video = bool(video_inputs)
+        sp = SamplingParams(max_new_tokens=self.max_completion_length, top_k=self.args.top_k, top_p=0.95, temperature=1.0,
+                            seed=self._sample_seed + 7919 * self.global_step)
+        completion_ids = eng.roll.generate([prompt], G, sp, use_graph=self.args.use_decode_graph)
+
+        shuffled_rpf = None
+        if self.temporal and has_video:                                                      # T-GRPO (TR:442-481)
+            perm = torch.randperm(video_inputs[0].size(0))
+            sproc = self.processing_class(text=copy.deepcopy(prompts_text), images=image_inputs,
+                                          videos=[video_inputs[0][perm]], **call)
+            sprompt = self._prompt_input(sproc)
+            ssp = SamplingParams(**{**sp.__dict__, "seed": sp.seed + 1})
+            shuffled_ids = eng.roll.generate([sprompt], self.shuffled_num_generations, ssp, use_graph=self.args.use_decode_graph)
+            shuffled_rpf = self._run_rewards(inputs, prompts, shuffled_ids, self.shuffled_num_generations)
+
+        rewards_per_func = self._run_rewards(inputs, prompts, completion_ids, G, video_path=video_path)
+        rewards, temporal_reward = temporal_bonus(rewards_per_func, shuffled_rpf, self.temporal, has_video)
+        eos = getattr(self.processing_class, "eos_token_id", self.cfg.eos_token_id)
+        is_eos = (completion_ids == eos).cpu()
+        lengths = torch.where(is_eos.any(1), is_eos.int().argmax(1) + 1, torch.full((G,), completion_ids.shape[1]))
+        rewards = length_bonus(rewards, rewards_per_func, lengths, self.len_control)
+        adv, std = group_advantages(rewards, G)
+        res = eng.score_and_backward(prompt, completion_ids, adv.to(self.device), grad_scale=grad_scale)
+
+        packed = pack_metrics(lengths, rewards_per_func, rewards, temporal_reward, std, float(res["kl"]))
+        if self.pg is not None:
+            src = packed.to(self.device) if torch.distributed.get_backend(self.pg) == "nccl" else packed
+            buf = [torch.zeros_like(src) for _ in range(self.world)]
+            torch.distributed.all_gather(buf, src, group=self.pg)       # ONE collective (reference: nine, TR:650-683)
+            stacked = torch.stack(buf).cpu()
+        else:
+            stacked = packed.unsqueeze(0)
+        names = [getattr(f, "__name__", str(f)) for f in self.reward_funcs]
+        for k, v in reduce_metrics(stacked, names, self.temporal).items():
+            self._metrics[k].append(v)
+        return res["loss"]
+
+    # ------------------------------------------------------------------ loop / logging / checkpoints
+    def log(self, logs: Dict[str, float], start_time: Optional[float] = None) -> None:
+        metrics = {k: sum(v) / len(v) for k, v in self._metrics.items()}                    # TR:689
+        logs = {**logs, **metrics}
+        self._metrics.clear()
+        if self.rank == 0:
+            os.makedirs(self.args.output_dir, exist_ok=True)
+            with open(os.path.join(self.args.output_dir, "trainer_log.jsonl"), "a") as f:
+                f.write(json.dumps(logs) + "\n")
+            print(json.dumps(logs), flush=True)
+
+    def train(self, resume_from_checkpoint: Optional[str] = None):
+        a = self.args
+        if resume_from_checkpoint:
+            self._load_checkpoint(resume_from_checkpoint)
+        n_rows = len(self.train_dataset)
+        acc = max(1, a.gradient_accumulation_steps * a.per_device_train_batch_size)
+        epoch, t_last = 0, time.time()
+        while self.global_step < self.total_steps:
+            idx = shard_indices(n_rows, self.rank, self.world, a.data_seed if a.data_seed is not None else a.seed, epoch)
+            for s in range(0, len(idx) - acc + 1, acc):
+                if self.global_step >= self.total_steps:
+                    break
+                loss = 0.0
+                for j in range(acc):
+                    loss += float(self.compute_loss(None, [self.train_dataset[idx[s + j]]], grad_scale=1.0 / acc)) / acc
+                self.engine.reduce_gradients()
+                lr = self.engine.optimizer_step(self.world)
+                self.global_step += 1
+                if self.global_step % a.logging_steps == 0:
+                    self.log({"loss": loss, "learning_rate": lr, "grad_norm": self.engine.grad_norm(self.world),
+                              "step": self.global_step, "step_time": time.time() - t_last})
+                    t_last = time.time()
+                if a.save_steps and self.global_step % a.save_steps == 0:
+                    self.save_model(os.path.join(a.output_dir, f"checkpoint-{self.global_step}"))
+            epoch += 1
+        return {"global_step": self.global_step}
+
+    def save_model(self, output_dir: Optional[str] = None, _internal_call: bool = False) -> None:
+        """Weights in the original Qwen2-VL checkpoint names (bf16 safetensors) + the step counter."""
+        if self.rank != 0:
+            return
+        output_dir = output_dir or self.args.output_dir
+        os.makedirs(output_dir, exist_ok=True)
+        sd = {k: v.detach().cpu().contiguous() for k, v in export_state_dict(self.engine.policy).items()}
+        try:
+            from safetensors.torch import save_file
+            save_file(sd, os.path.join(output_dir, "model.safetensors"))
+        except ImportError:
+            torch.save(sd, os.path.join(output_dir, "pytorch_model.bin"))
+        with open(os.path.join(output_dir, "trainer_state.json"), "w") as f:
+            json.dump({"global_step": self.global_step, "model_id": self.model_id, "notes": self._log_lines}, f)
+
+    def _load_checkpoint(self, path: str) -> None:
+        load_state_dict(self.engine.policy, _read_checkpoint(path))
+        self.engine.master.flat.copy_(self.engine.policy.flat.float())
+        st = os.path.join(path, "trainer_state.json")
+        if os.path.exists(st):
+            with open(st) as f:
+                self.global_step = int(json.load(f).get("global_step", 0))
+            self.engine.step_count = self.global_step
+
+
+def _read_checkpoint(path: str) -> Dict[str, torch.Tensor]:
+    """A directory (or file) of safetensors / .bin shards in the original Qwen2-VL names."""
+    files = [path] if os.path.isfile(path) else sorted(os.path.join(path, f) for f in os.listdir(path)
+                                                       if f.endswith(".safetensors") or f.endswith(".bin"))
+    if not files:
+        raise FileNotFoundError(f"no checkpoint shards under {path}")
+    sd: Dict[str, torch.Tensor] = {}
+    for f in files:
+        if f.endswith(".safetensors"):
+            from safetensors.torch import load_file
+            part = load_file(f)
+        else:
+            part = torch.load(f, map_location="cpu")
+        for k, v in part.items():
+            k = k.replace("model.language_model.", "model.").replace("model.visual.", "visual.")   # transformers 5.x names
+            sd[k] = v
+    return sd

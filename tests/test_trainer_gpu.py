@@ -1,0 +1,66 @@
+"""GPU: SGRLVRTrainer end to end on the tiny model with a fake processor: two optimizer steps with T-GRPO on,
+reward plugin API, metric keys, checkpoint round trip."""
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from fake_processor import FakeProcessor                                  # noqa: E402
+from golden_util import load_tiny                                         # noqa: E402
+from spacer_amd.open_r1.config import GRPOConfig, GRPOScriptArguments     # noqa: E402
+from spacer_amd.open_r1.rewards import format_reward                      # noqa: E402
+from spacer_amd.open_r1.trainer import SGRLVRTrainer                      # noqa: E402
+from spacer_amd.qwen2vl.config import TINY                                # noqa: E402
+from spacer_amd.qwen2vl.weights import FlatParams, load_state_dict        # noqa: E402
+
+SEEN = []
+
+
+def accuracy_reward(prompts, completions, video_path=None, **kw):
+    """Plugin-API probe: checks what the trainer passes (TR:587-592) and returns content-dependent rewards."""
+    SEEN.append(dict(n=len(completions), keys=sorted(kw), video_path=video_path is not None))
+    assert len(prompts) == len(completions) == len(kw["problem_type"]) == len(kw["solution"])
+    assert all(isinstance(c, list) and c[0]["role"] == "assistant" for c in completions)
+    return [float(len(c[0]["content"]) % 3) for c in completions]
+
+
+def test_trainer_two_steps(dev, tmp_path):
+    g = load_tiny()
+    params = FlatParams.empty(TINY, dev)
+    load_state_dict(params, g["w"])
+    before = params.flat.clone()
+    rows = []
+    for i in range(2):
+        frames = torch.randint(0, 256, (6, 3, 56, 84), generator=torch.Generator().manual_seed(i), dtype=torch.uint8)
+        rows.append(dict(prompt=[{"role": "user", "content": [{"type": "video"}, {"type": "text", "text": f"what is in clip {i} ?"}]}],
+                         path=frames, data_type="video", problem_type="multiple choice", solution="<answer>A</answer>",
+                         problem_id=i, options=["A. x", "B. y"], data_source="other"))
+    args = GRPOConfig(output_dir=str(tmp_path), max_completion_length=8, num_generations=4, learning_rate=1e-4, max_steps=2,
+                      logging_steps=1, save_steps=2, seed=3)
+    trainer = SGRLVRTrainer(model=params, reward_funcs=[accuracy_reward, format_reward], args=args,
+                            script_args=GRPOScriptArguments(temporal=True, len_control=True), train_dataset=rows,
+                            processing_class=FakeProcessor(TINY), device=dev)
+    with pytest.raises(ValueError):
+        trainer.compute_loss(None, [rows[0]], return_outputs=True)
+    out = trainer.train()
+    assert out["global_step"] == 2
+    assert not torch.equal(before, trainer.engine.policy.flat)                     # weights moved
+    assert torch.equal(trainer.engine.ref.flat, before)                            # reference model frozen
+    # reward plugin saw K rollouts with video_path and K/2 shuffled rollouts without it (TR:571 vs :592)
+    assert {(s["n"], s["video_path"]) for s in SEEN} == {(4, True), (2, False)}
+    assert set(SEEN[0]["keys"]) >= {"path", "problem_type", "solution", "problem_id", "data_type"}
+    logs = [json.loads(line) for line in open(os.path.join(str(tmp_path), "trainer_log.jsonl"))]
+    assert len(logs) == 2
+    for key in ("completion_length", "rewards/accuracy_reward", "rewards/format_reward", "all_wrong", "all_correct",
+                "temporal_rewards", "reward", "reward_std", "kl", "loss", "learning_rate"):
+        assert key in logs[0], key
+    assert logs[0]["completion_length"] <= 8 and logs[0]["kl"] >= 0
+    # checkpoint round trip in the original checkpoint names
+    ck = os.path.join(str(tmp_path), "checkpoint-2")
+    assert os.path.exists(os.path.join(ck, "model.safetensors"))
+    t2 = SGRLVRTrainer(model=ck, reward_funcs=[format_reward], args=GRPOConfig(output_dir=str(tmp_path), max_steps=1),
+                       train_dataset=rows, processing_class=FakeProcessor(TINY), device=dev, model_config=TINY)
+    assert torch.equal(t2.engine.policy.flat, trainer.engine.policy.flat)

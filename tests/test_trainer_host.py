@@ -1,0 +1,157 @@
+"""CPU: the host side of the drop-in surface -- C-ABI symbols, flag parsing, prompt construction, reward plumbing,
+reward shaping, metric aggregation and the data-parallel exchange (world_size 2 over gloo)."""
+import hashlib
+import os
+import re
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import grpo_ref as GR
+from spacer_amd import _lib
+from spacer_amd.grpo import GRPOHyper, allreduce_flat_, group_advantages, length_bonus, lr_at, temporal_bonus
+from spacer_amd.open_r1 import SG_RLVR as ENTRY
+from spacer_amd.open_r1.config import parse_args
+from spacer_amd.open_r1.trainer import SG_RLVR_trainer as T
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ----------------------------------------------------------------------------------------------- C-ABI
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "spacer_hip.h")).read()
+    declared = set(re.findall(r"\b(spacer_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) > 30
+    lib = _lib.load()                                  # fails loudly if the .so is not built
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/spacer_hip.h but not exported"
+    assert declared == set(_lib.SIGNATURES) | set(_lib.OTHER_SYMBOLS), declared ^ (set(_lib.SIGNATURES) | set(_lib.OTHER_SYMBOLS))
+    assert lib.spacer_version() >= 100
+    # argument validation runs before any launch, so it can be exercised without a GPU
+    rc = lib.spacer_gemm_bf16_nt(None, 0, None, 0, None, 0, 1, 1, 64, None, None)
+    assert rc == -1 and b"null operand" in lib.spacer_last_error()
+
+
+def test_kernels_refuse_cpu_tensors():
+    from spacer_amd import kernels as K
+    with pytest.raises(K.SpacerError):
+        K.gemm_nt(torch.zeros(64, 64, dtype=torch.bfloat16), torch.zeros(64, 64, dtype=torch.bfloat16))
+
+
+# ----------------------------------------------------------------------------------------------- flags / prompts
+def test_launch_script_flags_parse():
+    sh = open(os.path.join(ROOT, "scripts", "run_SpaceR_SG_RLVR.sh")).read()
+    body = sh[sh.index("-m spacer_amd.open_r1.SG_RLVR") + len("-m spacer_amd.open_r1.SG_RLVR"):]
+    argv = [t for t in re.sub(r"\\\n", " ", body).replace('"', "").split() if t]
+    argv = [a.replace("${MODEL:-Qwen/Qwen2-VL-7B-Instruct}", "Qwen/Qwen2-VL-7B-Instruct").replace("${DATASET:-SpaceR-151k.jsonl}", "d.jsonl") for a in argv]
+    script, train, model = parse_args(argv)
+    assert script.temporal is True and script.len_control is True and script.max_pixels == 401408
+    assert train.num_generations == 8 and train.beta == 0.04 and train.max_grad_norm == 5 and train.learning_rate == 1e-6
+    assert train.max_completion_length == 1024 and train.lr_scheduler_type == "cosine" and train.bf16 is True
+    assert train.deepspeed == "local_scripts/zero3.json" and model.attn_implementation == "flash_attention_2"
+
+
+def test_prompt_templates_are_the_reference_strings():
+    h = lambda s: hashlib.sha256(s.encode()).hexdigest()  # noqa: E731
+    # sha256 of the reference's literals (open_r1/SG-RLVR.py:293-318), computed in the authoring container
+    assert h(ENTRY.QUESTION_TEMPLATE) == "c2cea5bded10a50275c9487557d94f48a4aa80bc5ef708765678e252f072bfcd"
+    assert h(ENTRY.COGMAP_TEMPLATE) == "fd1bb11ef399edabbf3e3c03c29a89446dea31d72d231fec84e3f7556ca836f9"
+    assert h(repr(sorted(ENTRY.TYPE_TEMPLATE.items()))) == "a9a4eacd16a748d72b47514bdf573c9afb5e82a3b71575ff2339edd4514f46c4"
+    ENTRY.R.MAP_DATA["v1"] = {"cognitive_map": {"chair": [[1, 1]], "tv": [[2, 2]]}, "object_list": ["chair", "tv"]}
+    row = dict(problem="How many chairs?", problem_type="multiple choice", options=["A. 1", "B. 2"], data_source="SR_dataset",
+               path="/x/v1.mp4", data_type="video")
+    msg = ENTRY.make_conversation_image_and_video_map(row)["prompt"]
+    assert msg[0]["content"][0] == {"type": "video"} and "['chair', 'tv']" in msg[0]["content"][1]["text"]
+    assert msg[0]["content"][1]["text"].startswith("Question: How many chairs?Options:\nA. 1\nB. 2\n\n")
+    txt = T.qwen2vl_chat_template(msg)
+    assert txt.startswith("<|im_start|>system\nYou are a helpful assistant.<|im_end|>\n<|im_start|>user\n<|vision_start|><|video_pad|><|vision_end|>Question:")
+    assert txt.endswith("<|im_end|>\n<|im_start|>assistant\n")
+
+
+def test_reward_kwargs_and_none_stripping():
+    inputs = [dict(prompt=[{"role": "user", "content": [{"type": "video", "text": None}, {"type": "text", "text": "q", "video": None}]}],
+                   path="/v.mp4", problem_type="numerical", solution="<answer>3</answer>", problem_id=7, data_type="video")]
+    kw = T.repeat_columns(inputs, 3)
+    assert set(kw) == {"path", "problem_type", "solution", "problem_id", "data_type"} and kw["problem_id"] == [7, 7, 7]
+    cleaned = T.remove_none_from_data([dict(m, content=[dict(p) for p in m["content"]]) for m in inputs[0]["prompt"]])
+    assert cleaned[0]["content"] == [{"type": "video"}, {"type": "text", "text": "q"}]
+    assert T.is_conversational(inputs[0]) and not T.is_conversational({"prompt": "plain"})
+
+
+# ----------------------------------------------------------------------------------------------- reward shaping
+def test_reward_shaping_matches_oracle_restatement():
+    g = torch.Generator().manual_seed(0)
+    for trial in range(50):
+        G = 8
+        rpf = torch.stack([torch.rand(G, generator=g) * 2 * (torch.rand(G, generator=g) > 0.4), (torch.rand(G, generator=g) > 0.5).float()], 1)
+        sh = torch.stack([torch.rand(G // 2, generator=g) * 2, torch.ones(G // 2)], 1)
+        lens = torch.randint(200, 700, (G,), generator=g)
+        mask = (torch.arange(700)[None, :] < lens[:, None]).int()
+        for temporal in (True, False):
+            r1, t1 = temporal_bonus(rpf, sh, temporal, True)
+            r2, t2 = GR.temporal_bonus(rpf, sh, temporal, True)
+            assert torch.equal(r1, r2) and t1 == t2
+            a1 = length_bonus(r1, rpf, lens, True)
+            a2 = GR.length_bonus(r2, rpf, mask, True)
+            assert torch.equal(a1, a2)
+            adv1, s1 = group_advantages(a1, G)
+            adv2, s2 = GR.group_advantages(a2, G)
+            assert torch.allclose(adv1, adv2, atol=0, rtol=0) and torch.equal(s1, s2)
+
+
+def test_lr_schedule():
+    h = GRPOHyper(learning_rate=1e-6, total_steps=100, lr_scheduler_type="cosine")
+    assert lr_at(0, h) == 1e-6 and abs(lr_at(50, h) - 0.5e-6) < 1e-12 and lr_at(100, h) < 1e-12
+    h2 = GRPOHyper(learning_rate=1.0, total_steps=10, warmup_steps=2, lr_scheduler_type="linear")
+    assert lr_at(0, h2) == 0.5 and lr_at(1, h2) == 1.0 and lr_at(2, h2) == 1.0 and abs(lr_at(6, h2) - 0.5) < 1e-12
+
+
+def test_shard_indices_cover_dataset():
+    parts = [T.shard_indices(103, r, 4, seed=1, epoch=0) for r in range(4)]
+    assert all(len(p) == 26 for p in parts) and set(sum(parts, [])) == set(range(103))
+    assert T.shard_indices(103, 0, 4, seed=1, epoch=0) != T.shard_indices(103, 0, 4, seed=1, epoch=1)
+
+
+# ----------------------------------------------------------------------------------------------- world_size 2 (gloo)
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _dp_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pg = dist.group.WORLD
+    # gradient exchange: bucketed flat all-reduce == plain sum
+    g = torch.Generator().manual_seed(100 + rank)
+    flat = torch.randn(10_000, generator=g)
+    mine = flat.clone()
+    allreduce_flat_(flat, pg, bucket_elems=3000)
+    others = [torch.randn(10_000, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
+    ok_grad = torch.allclose(flat, sum(others)) and not torch.equal(flat, mine)
+    # packed metrics: rank 0 group all wrong, rank 1 group all correct
+    rpf = torch.tensor([[0.0, 1.0]] * 4) if rank == 0 else torch.tensor([[1.9, 1.0]] * 4)
+    rewards = rpf.sum(1)
+    packed = T.pack_metrics(torch.tensor([10, 20, 30, 40]) + rank, rpf, rewards, float(rank), torch.zeros(4), 0.25 * (rank + 1))
+    buf = [torch.zeros_like(packed) for _ in range(world)]
+    dist.all_gather(buf, packed, group=pg)
+    m = T.reduce_metrics(torch.stack(buf), ["accuracy_reward", "format_reward"], temporal=True)
+    ret[rank] = (ok_grad, m)
+    dist.destroy_process_group()
+
+
+def test_data_parallel_exchange_world2():
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_dp_worker, args=(2, port, ret), nprocs=2, join=True)
+    for r in range(2):
+        ok, m = ret[r]
+        assert ok
+        assert m["all_wrong"] == 0.5 and m["all_correct"] == 0.5          # fraction of ranks (TR:663-672)
+        assert abs(m["completion_length"] - 25.5) < 1e-6 and abs(m["kl"] - 0.375) < 1e-6
+        assert abs(m["rewards/accuracy_reward"] - 0.95) < 1e-6 and m["rewards/format_reward"] == 1.0
+        assert m["temporal_rewards"] == 0.5 and abs(m["reward"] - (1.0 + 2.9) / 2) < 1e-6
