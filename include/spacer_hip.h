@@ -61,6 +61,12 @@ int spacer_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, void* 
 int spacer_gemm_skinny_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
                             const spacer_gemm_epilogue* epi, spacer_stream_t stream);
 
+/* Fragment-major weight copy for the decode loop: out = [N/16][K/32][64 lanes][8 bf16] so that every wave load of
+ * the skinny GEMM is 1 KiB contiguous (N % 16 == 0, K % 32 == 0); rebuilt once per optimizer step. */
+int spacer_pack_weight_frag(const void* W, long ld, void* out, int N, int K, spacer_stream_t stream);
+int spacer_gemm_skinny_packed_bf16(const void* A, long lda, const void* Bpacked, void* C, long ldc, int M, int N, int K,
+                                   spacer_stream_t stream);
+
 /* out[C, Rpad] = in[R, C]^T, zero-filling columns R..Rpad-1 (bf16).  Feeds the NT GEMM in backward. */
 int spacer_transpose_bf16(const void* in, long ld_in, void* out, long ld_out, int R, int C, int Rpad,
                           spacer_stream_t stream);

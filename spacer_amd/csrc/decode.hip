@@ -3,66 +3,139 @@
 // from fp32 accumulators, and single-query attention over [shared prompt KV | per-rollout tail KV].
 // All step-dependent scalars (tail length, step index) are read from device memory so one decode step can
 // be captured once in a hipGraph and replayed.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
 
 // =============================================================================== skinny GEMM (M <= 64)
-// C32[M,N] += A[M,K] . B[N,K]^T.  Workgroup = 64 columns (wave = 16) x one K slice of KS; the A slice
-// (<= 64 x KS bf16) is staged once in LDS (swizzled) and shared by the 4 waves; B (the weights) is streamed
-// HBM -> VGPR with 16-byte fragment loads, 8 k-steps in flight per lane; fp32 atomics reduce across K slices.
-template <int KS>
+// C32[M,N] += A[M,K] . B[N,K]^T, weights streamed exactly once from HBM.
+// Workgroup = 64 columns (wave = 16) x a contiguous RANGE of 256-wide K slices.  Per slice the A slice (<= 64 x 256
+// bf16) goes global -> registers -> LDS (double-buffered, one barrier per slice, next slice's loads in flight
+// under the MFMAs); B is streamed HBM -> VGPR with non-temporal 16-byte fragment loads through two 8-deep register
+// sets that stay in flight across the barriers.  The sums live in registers over the whole K range and are flushed
+// ONCE: a plain read-add-write when the workgroup covers all of K, fp32 atomics when K is split (small N only --
+// the L2 atomic units, not HBM, bound the kernel when every 64x64 tile is flushed per slice).
+// PACKED = B stored fragment-major (spacer_pack_weight_frag): [N/16][K/32][64 lanes][8 bf16], so every wave load is
+// 1 KiB of contiguous memory; row-major B gives 16 x 64-byte segments per instruction, ~30 % slower.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+template <bool PACKED>
 __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __restrict__ A, long lda,
                                                              const bf16_t* __restrict__ B, long ldb,
-                                                             float* __restrict__ C, long ldc, int M, int N, int K) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [64][KS] bf16, chunk ^= row & 15
-    constexpr int ROWB = KS * 2, CHUNKS = KS / 8;
+                                                             float* __restrict__ C, long ldc, int M, int N, int K,
+                                                             int slices_per_range, int mflush) {
+    constexpr int KS = 256, ROWB = KS * 2;                 // 512-byte LDS rows, 16-byte chunk index ^= row & 15
+    __shared__ __attribute__((aligned(16))) char smem[2][64 * ROWB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n0 = blockIdx.x * 64 + wave * 16, k0 = blockIdx.y * KS;
     const int l15 = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 64 + wave * 16;
+    const int total_slices = K / KS;
+    const int s_begin = blockIdx.y * slices_per_range, s_end = min(total_slices, s_begin + slices_per_range);
+    if (s_begin >= s_end) return;
 
-    // stage A slice (zero rows >= M)
-    for (int idx = tid; idx < 64 * CHUNKS; idx += 256) {
-        const int row = idx / CHUNKS, ch = idx % CHUNKS;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (row < M) v = *(const uint4*)(A + (long)row * lda + k0 + ch * 8);
-        *(uint4*)(smem + row * ROWB + ((ch ^ (row & 15)) * 16)) = v;
-    }
-    const int nrow = min(n0 + l15, N - 1);
-    const bf16_t* bp = B + (long)nrow * ldb + k0 + g * 8;
+    // ---- staging map: instruction j of a thread covers row (tid >> 5) + 8 j, 16-byte chunk tid & 31
+    // (a wave reads 2 rows x 512 contiguous bytes per load instruction)
+    const int ar0 = tid >> 5, ach = tid & 31;
+    uint4 areg[8];
+    auto load_a = [&](int slice) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = ar0 + 8 * j;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (row < M) v = *(const uint4*)(A + (long)row * lda + slice * KS + ach * 8);
+            areg[j] = v;
+        }
+    };
+    auto store_a = [&](char* buf) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = ar0 + 8 * j;
+            *(uint4*)(buf + row * ROWB + ((ach ^ (row & 15)) * 16)) = areg[j];
+        }
+    };
+    const bf16_t* bbase;
+    if (PACKED) bbase = B + ((long)min(n0 >> 4, (N >> 4) - 1) * (K >> 5)) * 512 + lane * 8;
+    else bbase = B + (long)min(n0 + l15, N - 1) * ldb + g * 8;
+    auto load_w = [&](u32x4 (&w)[8], int slice) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bf16_t* p = PACKED ? bbase + ((long)slice * 8 + u) * 512 : bbase + slice * KS + u * 32;
+            w[u] = __builtin_nontemporal_load((const u32x4*)p);
+        }
+    };
     f32x4 acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
-
-    constexpr int STEPS = KS / 32, UN = 8;
-#pragma unroll 1
-    for (int s0 = 0; s0 < STEPS; s0 += UN) {
-        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-        u32x4 w[UN];
-#pragma unroll
-        for (int u = 0; u < UN; ++u) w[u] = __builtin_nontemporal_load((const u32x4*)(bp + (s0 + u) * 32));
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int ch = (s0 + u) * 4 + g;
-            const bf16x8 wf = __builtin_bit_cast(bf16x8, w[u]);
+    auto compute = [&](const u32x4 (&w)[8], const char* buf) {
+        // A fragments double-buffered by hand and the scheduler fenced per k-step (left alone hipcc hoists all 32
+        // fragment reads of the slice and spills)
+        bf16x8 af[2][4];
+        auto read_a = [&](bf16x8 (&dst)[4], int u) {
+            const int ch = u * 4 + g;
 #pragma unroll
             for (int mf = 0; mf < 4; ++mf) {
                 const int row = mf * 16 + l15;
-                const bf16x8 af = *(const bf16x8*)(smem + row * ROWB + ((ch ^ (row & 15)) * 16));
-                acc[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, wf, acc[mf], 0, 0, 0);   // D[m][n]
+                dst[mf] = *(const bf16x8*)(buf + row * ROWB + ((ch ^ (row & 15)) * 16));
             }
+        };
+        read_a(af[0], 0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (u + 1 < 8) read_a(af[(u + 1) & 1], u + 1);
+            const bf16x8 wf = __builtin_bit_cast(bf16x8, w[u]);
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf)
+                acc[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][mf], wf, acc[mf], 0, 0, 0);   // D[m][n]
+            __builtin_amdgcn_sched_barrier(0);
         }
+    };
+
+    u32x4 wa[8], wb[8];
+    load_a(s_begin);
+    load_w(wa, s_begin);
+    int s = s_begin;
+    while (true) {
+        store_a(smem[0]);
+        __syncthreads();
+        if (s + 1 < s_end) { load_a(s + 1); load_w(wb, s + 1); }
+        compute(wa, smem[0]);
+        if (++s >= s_end) break;
+        store_a(smem[1]);
+        __syncthreads();
+        if (s + 1 < s_end) { load_a(s + 1); load_w(wa, s + 1); }
+        compute(wb, smem[1]);
+        if (++s >= s_end) break;
     }
     // lane holds C[m = mf*16 + g*4 + r][n = n0 + l15]
-    if (n0 + l15 < N) {
+    const int n = n0 + l15;
+    const bool whole_k = (s_begin == 0 && s_end == total_slices);
+    if (n < N) {
 #pragma unroll
         for (int mf = 0; mf < 4; ++mf)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = mf * 16 + g * 4 + r;
-                if (m < M) atomicAdd(C + (long)m * ldc + n0 + l15, acc[mf][r]);
+                if (m < mflush) {
+                    float* c = C + (long)m * ldc + n;
+                    if (whole_k) *c += acc[mf][r];
+                    else atomicAdd(c, acc[mf][r]);
+                }
             }
+    }
+}
+
+// W [N, K] row-major -> fragment-major copy for the decode loop (rebuilt once per optimizer step)
+__global__ __launch_bounds__(256) void pack_frag_kernel(const bf16_t* __restrict__ W, long ld, bf16_t* __restrict__ out, int N, int K) {
+    const long total = (long)(N >> 4) * (K >> 5) * 64;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int lane = (int)(i & 63);
+        const long frag = i >> 6;
+        const int kb = (int)(frag % (K >> 5));
+        const long nb = frag / (K >> 5);
+        const uint4 v = *(const uint4*)(W + (nb * 16 + (lane & 15)) * ld + kb * 32 + (lane >> 4) * 8);
+        *(uint4*)(out + i * 8) = v;
     }
 }
 
@@ -214,24 +287,47 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
 
 }  // namespace
 
-extern "C" int spacer_gemm_skinny_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N,
-                                       int K, const spacer_gemm_epilogue* epi, spacer_stream_t stream) {
+static int launch_skinny(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
+                         const spacer_gemm_epilogue* epi, bool packed, hipStream_t s) {
     SP_REQUIRE(A && B && C, SPACER_EINVAL, "gemm_skinny: null operand");
     SP_REQUIRE(M > 0 && M <= 64, SPACER_EINVAL, "gemm_skinny: M=%d must be in 1..64", M);
     SP_REQUIRE(K % 256 == 0, SPACER_EINVAL, "gemm_skinny: K=%d must be a multiple of 256", K);
-    SP_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, SPACER_EINVAL, "gemm_skinny: lda/ldb must be multiples of 8");
+    SP_REQUIRE(lda % 8 == 0 && (packed || ldb % 8 == 0), SPACER_EINVAL, "gemm_skinny: lda/ldb must be multiples of 8");
+    SP_REQUIRE(!packed || N % 16 == 0, SPACER_EINVAL, "gemm_skinny: packed weights need N %% 16 == 0");
     SP_REQUIRE(!epi || (epi->out_f32 && !epi->bias && epi->act == 0 && (!epi->residual || epi->residual == C)),
                SPACER_EINVAL, "gemm_skinny: only fp32 accumulate-into-C is supported (C32 += A.B^T)");
-    hipStream_t s = (hipStream_t)stream;
-    if (K % 512 == 0 && (long)cdiv(N, 64) * (K / 512) >= 384) {
-        static const int once = hipFuncSetAttribute((const void*)gemm_skinny_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 512 * 2);
-        (void)once;
-        hipLaunchKernelGGL(gemm_skinny_kernel<512>, dim3(cdiv(N, 64), K / 512), dim3(256), 64 * 512 * 2, s, (const bf16_t*)A, lda,
-                           (const bf16_t*)B, ldb, (float*)C, ldc, M, N, K);
-    } else {
-        hipLaunchKernelGGL(gemm_skinny_kernel<256>, dim3(cdiv(N, 64), K / 256), dim3(256), 64 * 256 * 2, s, (const bf16_t*)A, lda,
-                           (const bf16_t*)B, ldb, (float*)C, ldc, M, N, K);
-    }
+    // K ranges: 1 (no atomics) when the column groups alone fill the chip, else just enough ranges for ~2 workgroups / CU
+    const int col_groups = cdiv(N, 64), slices = K / 256;
+    int ranges = 1;
+    if (col_groups < 448) ranges = min(slices, cdiv(512, col_groups));
+    const int spr = cdiv(slices, ranges);
+    ranges = cdiv(slices, spr);
+    const int mflush = getenv("SPACER_PROBE_NOFLUSH") ? 0 : M;
+    if (packed)
+        hipLaunchKernelGGL(gemm_skinny_kernel<true>, dim3(col_groups, ranges), dim3(256), 0, s, (const bf16_t*)A, lda,
+                           (const bf16_t*)B, ldb, (float*)C, ldc, M, N, K, spr, mflush);
+    else
+        hipLaunchKernelGGL(gemm_skinny_kernel<false>, dim3(col_groups, ranges), dim3(256), 0, s, (const bf16_t*)A, lda,
+                           (const bf16_t*)B, ldb, (float*)C, ldc, M, N, K, spr, mflush);
+    SP_CHECK_LAUNCH();
+    return SPACER_OK;
+}
+
+extern "C" int spacer_gemm_skinny_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N,
+                                       int K, const spacer_gemm_epilogue* epi, spacer_stream_t stream) {
+    return launch_skinny(A, lda, B, ldb, C, ldc, M, N, K, epi, false, (hipStream_t)stream);
+}
+
+extern "C" int spacer_gemm_skinny_packed_bf16(const void* A, long lda, const void* Bpacked, void* C, long ldc, int M, int N,
+                                              int K, spacer_stream_t stream) {
+    return launch_skinny(A, lda, Bpacked, 0, C, ldc, M, N, K, nullptr, true, (hipStream_t)stream);
+}
+
+extern "C" int spacer_pack_weight_frag(const void* W, long ld, void* out, int N, int K, spacer_stream_t stream) {
+    SP_REQUIRE(N % 16 == 0 && K % 32 == 0 && ld % 8 == 0, SPACER_EINVAL, "pack_weight_frag: need N %% 16 == 0, K %% 32 == 0");
+    const long total = (long)(N / 16) * (K / 32) * 64;
+    hipLaunchKernelGGL(pack_frag_kernel, dim3((int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192)), dim3(256), 0,
+                       (hipStream_t)stream, (const bf16_t*)W, ld, (bf16_t*)out, N, K);
     SP_CHECK_LAUNCH();
     return SPACER_OK;
 }

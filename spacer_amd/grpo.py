@@ -158,6 +158,7 @@ class GRPOEngine:
                       sumsq=self._sumsq, max_norm=h.max_grad_norm, grad_scale=gscale)
         self.G.flat.zero_()
         self.engine.invalidate_cache()
+        self.roll.invalidate()
         return lr
 
     def grad_norm(self, world_size: int = 1) -> float:

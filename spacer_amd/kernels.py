@@ -111,6 +111,24 @@ def gemm_skinny_acc(a: torch.Tensor, b: torch.Tensor, c32: torch.Tensor) -> torc
     return c32
 
 
+def pack_weight_frag(w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[N, K] row-major bf16 -> fragment-major flat copy for gemm_skinny_packed_acc."""
+    N, K = w.shape
+    if out is None:
+        out = torch.empty(N * K, device=w.device, dtype=BF16)
+    check(_lib.load().spacer_pack_weight_frag(_ptr(w), _rowmajor(w), _ptr(out), N, K, _stream()), "pack_weight_frag")
+    return out
+
+
+def gemm_skinny_packed_acc(a: torch.Tensor, bp: torch.Tensor, c32: torch.Tensor, N: int) -> torch.Tensor:
+    """c32[M,N] (fp32) += a[M,K] @ W[N,K]^T with W given in packed (fragment-major) form."""
+    M, K = a.shape
+    assert bp.numel() == N * K and c32.dtype == torch.float32
+    check(_lib.load().spacer_gemm_skinny_packed_bf16(_ptr(a), _rowmajor(a), _ptr(bp), _ptr(c32), _rowmajor(c32), M, N, K,
+                                                     _stream()), "gemm_skinny_packed_bf16")
+    return c32
+
+
 def transpose_pad(x: torch.Tensor, rpad: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x[R,C] bf16 -> out[C, Rpad] with zero fill (Rpad defaults to R rounded up to 64)."""
     R, Cc = x.shape

@@ -49,8 +49,21 @@ class RolloutEngine:
         self.e = engine
         self.cfg = engine.cfg
         self.dev = engine.dev
-        self._graph = None
-        self._graph_key = None
+        self._packed = None          # fragment-major copies of the LLM matmul weights for the skinny GEMMs
+
+    # ------------------------------------------------------------------ decode-layout weights
+    def invalidate(self) -> None:
+        """Call after the optimizer rewrote the bf16 weights."""
+        self._packed = None
+
+    def _pack(self) -> dict:
+        """Fragment-major (spacer_pack_weight_frag) copies of qkv/o/gate-up/down per layer + lm_head: every skinny-GEMM
+        load instruction then reads 1 KiB of contiguous HBM.  Rebuilt once per optimizer step (~14 GB at 7B, ~10 ms)."""
+        if self._packed is None:
+            W, cfg = self.e.W, self.cfg
+            names = [f"llm.{i}.{n}" for i in range(cfg.layers) for n in ("qkv_w", "o_w", "gu_w", "down_w")] + ["llm.lm_head"]
+            self._packed = {n: K.pack_weight_frag(W[n]) for n in names}
+        return self._packed
 
     # ------------------------------------------------------------------ prefill
     def _prefill(self, prompts: List[PromptInput], era_rule: bool):
@@ -83,7 +96,7 @@ class RolloutEngine:
 
     # ------------------------------------------------------------------ one decode step (graph-capturable)
     def _decode_step(self, st: dict, sp: SamplingParams) -> None:
-        cfg, W = self.cfg, self.e.W
+        cfg, W, PW = self.cfg, self.e.W, st["packed"]
         Hq, Hkv, D, I = cfg.heads, cfg.kv_heads, cfg.head_dim, cfg.intermediate
         B = st["B"]
         x = K.embed_fwd(st["cur_tok"], W["llm.embed"], None, None, out=st["x"])
@@ -92,19 +105,19 @@ class RolloutEngine:
         for i in range(cfg.layers):
             p = f"llm.{i}."
             h = K.rmsnorm_fwd(x, W[p + "ln1_w"], cfg.rms_eps, out=st["h"])
-            K.gemm_skinny_acc(h, W[p + "qkv_w"], st["acc_qkv"])
+            K.gemm_skinny_packed_acc(h, PW[p + "qkv_w"], st["acc_qkv"], cfg.qkv_dim)
             K.decode_qkv_finish(st["acc_qkv"], W[p + "qkv_b"], st["cos"], st["sin"], st["q"], st["tk"][i], st["tv"][i],
                                 st["tail_len"], Hq, Hkv, D)
             o = K.attn_decode(st["q"], st["pk"][i], st["pv"][i], st["plen"], st["prompt_of"], st["tk"][i], st["tv"][i],
                               st["tail_len"], Hq, Hkv, D, scale, out=st["o"])
-            K.gemm_skinny_acc(o, W[p + "o_w"], x)
+            K.gemm_skinny_packed_acc(o, PW[p + "o_w"], x, cfg.hidden)
             h2 = K.rmsnorm_fwd(x, W[p + "ln2_w"], cfg.rms_eps, out=st["h"])
-            K.gemm_skinny_acc(h2, W[p + "gu_w"], st["acc_gu"])
+            K.gemm_skinny_packed_acc(h2, PW[p + "gu_w"], st["acc_gu"], 2 * I)
             a = K.swiglu_f32_fwd(st["acc_gu"], st["a"])
-            K.gemm_skinny_acc(a, W[p + "down_w"], x)
+            K.gemm_skinny_packed_acc(a, PW[p + "down_w"], x, cfg.hidden)
         hn = K.rmsnorm_fwd(x, W["llm.norm_w"], cfg.rms_eps, out=st["h"])
         st["logits"].zero_()
-        K.gemm_skinny_acc(hn, W["llm.lm_head"], st["logits"])
+        K.gemm_skinny_packed_acc(hn, PW["llm.lm_head"], st["logits"], cfg.vocab)
         st["step"].add_(1)
         st["tail_len"].add_(1)
         K.sample_top_p(st["logits"], st["step"], top_k=sp.top_k, top_p=sp.top_p, temperature=sp.temperature, seed=sp.seed,
@@ -130,7 +143,7 @@ class RolloutEngine:
         pk, pv, first_logits, plen, pos_base = self._prefill(prompts, sp.era_rule)
         L, Hkv, D, H = cfg.layers, cfg.kv_heads, cfg.head_dim, cfg.hidden
         st = dict(
-            B=B, pk=pk, pv=pv,
+            B=B, pk=pk, pv=pv, packed=self._pack(),
             plen=torch.tensor(plen, dtype=torch.int32, device=dev),
             prompt_of=torch.arange(B, dtype=torch.int32, device=dev) // Kn,
             pos_base=torch.tensor(pos_base, dtype=torch.int32, device=dev).repeat_interleave(Kn).contiguous(),

@@ -74,7 +74,7 @@ def test_gemm_rejects_bad_k(dev):
         K.gemm_nt(a, b)
 
 
-@pytest.mark.parametrize("M,N,K", [(64, 3584, 3584), (8, 4608, 3584), (64, 2048, 1536), (33, 1000, 256), (64, 512, 18944)])
+@pytest.mark.parametrize("M,N,K", [(64, 3584, 3584), (8, 4608, 3584), (64, 2048, 1536), (33, 1000, 256), (33, 1008, 256), (64, 512, 18944)])
 def test_gemm_skinny(dev, M, N, K):
     a, b = rnd((M, K), dev, 1, 0.5), rnd((N, K), dev, 2, 0.05)
     c0 = rnd((M, N), dev, 3, dtype=torch.float32)
@@ -82,6 +82,10 @@ def test_gemm_skinny(dev, M, N, K):
     K_mod = __import__("spacer_amd.kernels", fromlist=["x"])
     K_mod.gemm_skinny_acc(a, b, c)
     assert_close(c, c0 + a.float() @ b.float().t(), 5e-3, 2e-3, "skinny")
+    if N % 16 == 0:
+        c2 = c0.clone()
+        K_mod.gemm_skinny_packed_acc(a, K_mod.pack_weight_frag(b), c2, N)
+        assert_close(c2, c0 + a.float() @ b.float().t(), 5e-3, 2e-3, "skinny packed")
 
 
 def test_transpose_pad(dev):
