@@ -5,7 +5,7 @@
 // be captured once in a hipGraph and replayed.
 #include <stdlib.h>
 
-#include "common.h"
+#include "attn_common.h"
 
 namespace {
 
@@ -198,7 +198,147 @@ __global__ __launch_bounds__(256) void swiglu_f32_kernel(float* __restrict__ acc
 
 // x32 += 0 helper not needed; residual adds land in the fp32 stream through the skinny GEMM atomics.
 
-// =============================================================================== decode attention
+// =============================================================================== decode attention (MFMA)
+// Workgroup = (sequence b, kv head); the REP q-heads of the GQA group are the MFMA's 16-wide N dimension (zero
+// padded), so every K/V byte is read once per workgroup and scored against all heads by the matrix cores:
+//   S^T = K . Q^T   (A = K fragment loaded straight from global memory, row-per-lane 16 B; B = Q in registers)
+//   O^T += V^T . P^T (V tile transposed through a wave-private LDS region, same slot permutation as the forward kernel)
+// The 4 waves stride over 64-key tiles of [shared prompt KV | per-rollout tail KV] and are merged through LDS.
+template <int REP>
+__global__ __launch_bounds__(256, 2) void attn_decode_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ pk,
+                                                                  const bf16_t* __restrict__ pv, const int* __restrict__ plen,
+                                                                  const int* __restrict__ prompt_of, const bf16_t* __restrict__ tk,
+                                                                  const bf16_t* __restrict__ tv, const int* __restrict__ tail_len,
+                                                                  bf16_t* __restrict__ o, int Pmax, int Cmax, int Hq, int Hkv,
+                                                                  float scale) {
+    constexpr int D = 128, DC = 4, DF = 8;
+    __shared__ __attribute__((aligned(16))) char smem[4 * AT_T_BYTES(D)];      // 4 x 16 KiB: V^T per wave, then the merge
+    const int b = blockIdx.x, hk = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int pr = prompt_of[b], P = plen[pr], total = P + *tail_len + 1;
+    char* vt = smem + wave * AT_T_BYTES(D);
+
+    bf16x8 qf[DC];
+    {
+        const bf16_t* qp = q + ((long)b * Hq + hk * REP + min(l15, REP - 1)) * D;
+#pragma unroll
+        for (int dc = 0; dc < DC; ++dc) {
+            uint4 t = make_uint4(0, 0, 0, 0);
+            if (l15 < REP) t = *(const uint4*)(qp + dc * 32 + g * 8);
+            qf[dc] = __builtin_bit_cast(bf16x8, t);
+        }
+    }
+    auto key_ptr = [&](const bf16_t* pre, const bf16_t* tail, int key) -> const bf16_t* {
+        key = min(key, total - 1);
+        return key < P ? pre + (((long)pr * Pmax + key) * Hkv + hk) * D : tail + (((long)b * Cmax + (key - P)) * Hkv + hk) * D;
+    };
+    f32x4 oacc[DF];
+#pragma unroll
+    for (int d = 0; d < DF; ++d) oacc[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    for (int k0 = wave * 64; k0 < total; k0 += 256) {
+        // ---- V tile -> registers (4 passes: d-chunk c = lane & 15, row quad rq = (lane >> 4) + 4 i), issued first
+        uint4 vreg[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int key = k0 + (g + 4 * i) * 4 + j;
+                vreg[i][j] = *(const uint4*)(key_ptr(pv, tv, key) + l15 * 8);
+            }
+        // ---- S^T = K . Q^T : st[kf] = keys k0 + kf*16 + g*4 + r for head q = l15
+        f32x4 st[4];
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf) {
+            st[kf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const bf16_t* kp = key_ptr(pk, tk, k0 + kf * 16 + l15) + g * 8;
+#pragma unroll
+            for (int dc = 0; dc < DC; ++dc) {
+                const bf16x8 kfr = __builtin_bit_cast(bf16x8, *(const uint4*)(kp + dc * 32));
+                st[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[dc], st[kf], 0, 0, 0);
+            }
+        }
+        float p[4][4], mx = -INFINITY;
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sv = (k0 + kf * 16 + g * 4 + r < total) ? st[kf][r] * scale : -INFINITY;
+                p[kf][r] = sv;
+                mx = fmaxf(mx, sv);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);           // finite: every tile a wave visits has >= 1 valid key
+        const float alpha = __expf(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { p[kf][r] = __expf(p[kf][r] - m_new); psum += p[kf][r]; }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < DF; ++d) oacc[d] *= alpha;
+        const bf16x8 pf0 = pack_slots(p[0], p[1]), pf1 = pack_slots(p[2], p[3]);
+        // ---- V^T through the wave-private LDS image
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rq = g + 4 * i;
+            const uint32_t w[4][4] = {{vreg[i][0].x, vreg[i][0].y, vreg[i][0].z, vreg[i][0].w}, {vreg[i][1].x, vreg[i][1].y, vreg[i][1].z, vreg[i][1].w},
+                                      {vreg[i][2].x, vreg[i][2].y, vreg[i][2].z, vreg[i][2].w}, {vreg[i][3].x, vreg[i][3].y, vreg[i][3].z, vreg[i][3].w}};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int d = l15 * 8 + e, wi = e >> 1, hi = e & 1;
+                uint32_t x[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[j] = hi ? (w[j][wi] >> 16) : (w[j][wi] & 0xffffu);
+                *(uint2*)(vt + d * AT_T_ROW_BYTES + ((rq ^ vswz(d)) * 8)) = make_uint2(x[0] | (x[1] << 16), x[2] | (x[3] << 16));
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // image complete before any lane reads fragments from it
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int df = 0; df < DF; ++df) {
+            oacc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t(vt, df, 0, lane), pf0, oacc[df], 0, 0, 0);
+            oacc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t(vt, df, 1, lane), pf1, oacc[df], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragments read before the next tile overwrites the image
+        __builtin_amdgcn_wave_barrier();
+    }
+    // ---- merge the 4 waves: per wave m[q], l[q], O^T[d][q] (q = l15 < REP)
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    __syncthreads();                                   // every wave is done with its V^T image
+    float* mo = (float*)smem;                          // [4][D][16] O^T, then [4][16] m, [4][16] l
+    float* mm = mo + 4 * D * 16;
+    float* ml = mm + 64;
+#pragma unroll
+    for (int df = 0; df < DF; ++df)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mo[(wave * D + df * 16 + g * 4 + r) * 16 + l15] = oacc[df][r];
+    if (g == 0) { mm[wave * 16 + l15] = m_run; ml[wave * 16 + l15] = l_run; }
+    __syncthreads();
+    for (int i = tid; i < REP * D; i += 256) {
+        const int qh = i / D, d = i % D;
+        float M = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) M = fmaxf(M, mm[w * 16 + qh]);
+        float L = 0.f, O = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float mw = mm[w * 16 + qh];
+            const float f = (mw == -INFINITY) ? 0.f : __expf(mw - M);
+            L += ml[w * 16 + qh] * f;
+            O += mo[(w * D + d) * 16 + qh] * f;
+        }
+        o[((long)b * Hq + hk * REP + qh) * D + d] = f2bf(O / L);
+    }
+}
+
+// =============================================================================== decode attention (VALU reference form)
 // Workgroup = (sequence b, kv head).  16 lanes x 8 dims cover one key; a wave scores 4 keys per step, the
 // 4 waves stride over keys; all `REP` q heads of the GQA group are scored against each loaded key/value.
 template <int D, int REP>
@@ -370,10 +510,16 @@ extern "C" int spacer_attn_decode(const void* q, const void* prefix_k, const voi
     if (B <= 0) return SPACER_OK;
     const int rep = Hq / Hkv;
     hipStream_t s = (hipStream_t)stream;
+    const bool valu = getenv("SPACER_DECODE_ATTN_VALU") != nullptr;     // reference form kept for A/B runs
 #define LAUNCH(R)                                                                                                      \
-    hipLaunchKernelGGL((attn_decode_kernel<128, R>), dim3(B, Hkv), dim3(256), 0, s, (const bf16_t*)q, (const bf16_t*)prefix_k, \
-                       (const bf16_t*)prefix_v, prefix_len, prompt_of, (const bf16_t*)tail_k, (const bf16_t*)tail_v,      \
-                       tail_len_dev, (bf16_t*)o, Pmax, Cmax, Hq, Hkv, scale)
+    if (valu)                                                                                                          \
+        hipLaunchKernelGGL((attn_decode_kernel<128, R>), dim3(B, Hkv), dim3(256), 0, s, (const bf16_t*)q,              \
+                           (const bf16_t*)prefix_k, (const bf16_t*)prefix_v, prefix_len, prompt_of, (const bf16_t*)tail_k, \
+                           (const bf16_t*)tail_v, tail_len_dev, (bf16_t*)o, Pmax, Cmax, Hq, Hkv, scale);              \
+    else                                                                                                               \
+        hipLaunchKernelGGL((attn_decode_mfma_kernel<R>), dim3(B, Hkv), dim3(256), 0, s, (const bf16_t*)q,              \
+                           (const bf16_t*)prefix_k, (const bf16_t*)prefix_v, prefix_len, prompt_of, (const bf16_t*)tail_k, \
+                           (const bf16_t*)tail_v, tail_len_dev, (bf16_t*)o, Pmax, Cmax, Hq, Hkv, scale)
     switch (rep) {
         case 1: LAUNCH(1); break;
         case 2: LAUNCH(2); break;

@@ -63,61 +63,96 @@ __global__ __launch_bounds__(SNT) void sample_kernel(const float* __restrict__ l
         return;
     }
     const float* row = logits + (long)b * ld;
-    auto val = [&](int i) -> float {
-        const float x = row[i] * inv_temp;
-        return (suppress_eos && i == eos) ? -INFINITY : x;
+    auto fix = [&](float raw, int i) -> float { return (suppress_eos && i == eos) ? -INFINITY : raw * inv_temp; };
+    auto val = [&](int i) -> float { return fix(row[i], i); };
+    const bool vec_ok = (ld % 4 == 0) && (((uintptr_t)logits & 15) == 0);
+
+    // exact k-th largest key of `count` values produced by load(i): 4-pass radix select, wave-aggregated LDS atomics
+    auto kth_key = [&](auto&& load, int count, int k) -> uint32_t {
+        uint32_t prefix = 0;
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            for (int i = tid; i < 256; i += SNT) hist[i] = 0;
+            __syncthreads();
+            for (int i0 = 0; i0 < count; i0 += SNT) {
+                const int i = i0 + tid;
+                bool live = i < count;
+                const uint32_t key = live ? okey(load(i)) : 0u;
+                if (pass > 0) live = live && ((key >> (shift + 8)) == prefix);
+                const int bin = (key >> shift) & 255;
+                unsigned long long act = __ballot(live);
+                while (act) {
+                    const int leader = __ffsll((long long)act) - 1;
+                    const int lb = __shfl(bin, leader, 64);
+                    const unsigned long long same = __ballot(live && bin == lb);
+                    if (lane == leader) atomicAdd(&hist[lb], __popcll(same));
+                    act &= ~same;
+                }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int cum = 0, bsel = 0;
+                for (int bb = 255; bb >= 0; --bb) {
+                    if (cum + hist[bb] >= k) { bsel = bb; break; }
+                    cum += hist[bb];
+                }
+                sel_bin = bsel; sel_k = k - cum;
+            }
+            __syncthreads();
+            prefix = (prefix << 8) | (uint32_t)sel_bin;
+            k = sel_k;
+            __syncthreads();
+        }
+        return prefix;
+    };
+    auto gather = [&](uint32_t thr) {
+        if (tid == 0) ncand = 0;
+        __syncthreads();
+        auto consider = [&](float x, int i) {
+            if (okey(x) >= thr) {
+                const int slot = atomicAdd(&ncand, 1);
+                if (slot < CAP) { cval[slot] = x; cidx[slot] = i; }
+            }
+        };
+        if (vec_ok) {
+            for (int i4 = tid; i4 < (vocab >> 2); i4 += SNT) {
+                const float4 v = *(const float4*)(row + i4 * 4);
+                consider(fix(v.x, i4 * 4), i4 * 4); consider(fix(v.y, i4 * 4 + 1), i4 * 4 + 1);
+                consider(fix(v.z, i4 * 4 + 2), i4 * 4 + 2); consider(fix(v.w, i4 * 4 + 3), i4 * 4 + 3);
+            }
+            for (int i = (vocab & ~3) + tid; i < vocab; i += SNT) consider(val(i), i);
+        } else {
+            for (int i = tid; i < vocab; i += SNT) consider(val(i), i);
+        }
+        __syncthreads();
     };
 
-    // ---- 1. radix select of the k-th largest key
-    uint32_t prefix = 0;
-    int k = top_k;
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
-        for (int i = tid; i < 256; i += SNT) hist[i] = 0;
-        __syncthreads();
-        for (int i0 = 0; i0 < vocab; i0 += SNT) {
-            const int i = i0 + tid;
-            bool live = i < vocab;
-            uint32_t key = live ? okey(val(i)) : 0u;
-            if (pass > 0) live = live && ((key >> (shift + 8)) == prefix);
-            const int bin = (key >> shift) & 255;
-            unsigned long long act = __ballot(live);
-            while (act) {                                   // wave-aggregated histogram update
-                const int leader = __ffsll((long long)act) - 1;
-                const int lb = __shfl(bin, leader, 64);
-                const unsigned long long same = __ballot(live && bin == lb);
-                if (lane == leader) atomicAdd(&hist[lb], __popcll(same));
-                act &= ~same;
-            }
+    // ---- 1. candidates.  Fast path (2 passes over the row): the top_k-th largest of the 1024 per-thread maxima is a
+    // lower bound of the top_k-th largest logit, so "logit >= bound" keeps a superset of the top-k (typically ~2k
+    // values) that is then trimmed exactly after the sort.  Pathological rows (mass ties) overflow CAP and take the
+    // exact 4-pass radix select over the whole row.
+    float lmax = -INFINITY;
+    if (vec_ok) {
+        for (int i4 = tid; i4 < (vocab >> 2); i4 += SNT) {
+            const float4 v = *(const float4*)(row + i4 * 4);
+            lmax = fmaxf(fmaxf(lmax, fmaxf(fix(v.x, i4 * 4), fix(v.y, i4 * 4 + 1))), fmaxf(fix(v.z, i4 * 4 + 2), fix(v.w, i4 * 4 + 3)));
         }
-        __syncthreads();
-        if (tid == 0) {
-            int cum = 0, bsel = 0;
-            for (int bb = 255; bb >= 0; --bb) {
-                if (cum + hist[bb] >= k) { bsel = bb; break; }
-                cum += hist[bb];
-            }
-            sel_bin = bsel; sel_k = k - cum;
-        }
-        __syncthreads();
-        prefix = (prefix << 8) | (uint32_t)sel_bin;
-        k = sel_k;
-        __syncthreads();
+        for (int i = (vocab & ~3) + tid; i < vocab; i += SNT) lmax = fmaxf(lmax, val(i));
+    } else {
+        for (int i = tid; i < vocab; i += SNT) lmax = fmaxf(lmax, val(i));
     }
-    const uint32_t kth = prefix;
-
-    // ---- 2. gather candidates
-    if (tid == 0) ncand = 0;
+    cval[tid] = lmax;
     __syncthreads();
-    for (int i = tid; i < vocab; i += SNT) {
-        const float x = val(i);
-        if (okey(x) >= kth) {
-            const int slot = atomicAdd(&ncand, 1);
-            if (slot < CAP) { cval[slot] = x; cidx[slot] = i; }
-        }
+    const uint32_t bound = kth_key([&](int i) { return cval[i]; }, SNT, top_k);
+    __syncthreads();
+    gather(bound);
+    bool trimmed_exactly = false;
+    if (ncand > CAP) {
+        const uint32_t kth = kth_key(val, vocab, top_k);
+        gather(kth);
+        trimmed_exactly = true;
     }
-    __syncthreads();
-    const int n = min(ncand, CAP);
+    const int n = min(ncand, CAP);   // (ties beyond CAP are dropped)
     int np2 = 1;
     while (np2 < n) np2 <<= 1;
     for (int i = n + tid; i < np2; i += SNT) { cval[i] = -INFINITY; cidx[i] = 0x7fffffff; }
@@ -138,12 +173,23 @@ __global__ __launch_bounds__(SNT) void sample_kernel(const float* __restrict__ l
             __syncthreads();
         }
 
+    // exact top-k with ties (HF keeps every logit >= the k-th largest): candidates are sorted descending
+    int n_keep = n;
+    if (!trimmed_exactly) {
+        const float kval = cval[min(top_k, n) - 1];
+        __shared__ int cut;
+        if (tid == 0) cut = 0;
+        __syncthreads();
+        if (tid < n && cval[tid] >= kval) atomicMax(&cut, tid + 1);
+        __syncthreads();
+        n_keep = cut;
+    }
     // ---- 3. nucleus over the sorted candidates (n <= CAP <= SNT: one candidate per thread)
     const float vmax = cval[0];
-    const float p = (tid < n) ? __expf(cval[tid] - vmax) : 0.f;
+    const float p = (tid < n_keep) ? __expf(cval[tid] - vmax) : 0.f;
     float Z;
     const float excl = block_excl_scan(p, wsum, Z);
-    const bool keep = (tid < n) && (tid == 0 || excl < top_p * Z);
+    const bool keep = (tid < n_keep) && (tid == 0 || excl < top_p * Z);
     const float pk = keep ? p : 0.f;
     float Zk;
     const float exk = block_excl_scan(pk, wsum, Zk);
