@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--phase-times", action="store_true", help="print per-phase wall times (adds synchronisations)")
+    ap.add_argument("--gemm-shapes", action="store_true", help="also print the GEMM time broken down by (M,N,K) to stderr")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -143,6 +144,7 @@ def main():
         step(i)
     phase.clear()
     K.PROFILER.reset(enabled=True)
+    K.PROFILER.by_shape = args.gemm_shapes
     barrier()
     t_start = time.perf_counter()
     for i in range(args.steps):
@@ -156,6 +158,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     prof = K.PROFILER.summary()
+    if args.gemm_shapes and rank == 0:
+        shapes = sorted(((v["seconds"], k, v) for k, v in prof.items() if k.startswith("gemm[")), reverse=True)
+        for sec, k, v in shapes[:24]:
+            print(f"  {k:32s} {v['launches']:5d} x  {1e6 * sec / v['launches']:9.1f} us  {v['tflops']:7.1f} TF/s  total {sec:6.3f} s",
+                  file=sys.stderr)
+        prof = {k: v for k, v in prof.items() if not k.startswith("gemm[")}
 
     if rank == 0:
         samples = groups * Kgen * world * args.steps

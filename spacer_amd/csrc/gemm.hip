@@ -4,21 +4,24 @@
 // reference trainer drives is y = x W^T with W stored [out,in]); backward GEMMs reuse it through the
 // transpose kernel (dX = dY . (W^T)^T, dW = dY^T . (X^T)^T).
 //
-// Design (MI355X_MICROARCH / cdna_hip_programming "step-3" structure + T1/T2/T3):
-//   * 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each wave 64x64 = 4x4 MFMA 16x16x32 frags)
-//   * BK = 64; A/B tiles go HBM -> LDS directly with global_load_lds_dwordx4 (1 KiB per wave-instruction),
-//     double-buffered: loads of tile t+1 are issued before the MFMAs of tile t, one barrier per tile
+// Design (MI355X_MICROARCH / cdna_hip_programming T1/T2/T3):
+//   * one kernel template, two tile shapes picked by problem size:
+//       128x128x64  : 4 waves as 2x2, wave = 64x64  (4x4 MFMA 16x16x32 frags), 64 KiB LDS, 2 workgroups / CU
+//       256x256x64  : 8 waves as 2x4, wave = 128x64 (8x4 frags),               128 KiB LDS, 1 workgroup / CU
+//   * A/B tiles go HBM -> LDS directly with global_load_lds_dwordx4 (1 KiB per wave-instruction), double-buffered:
+//     loads of tile t+1 are issued before the MFMAs of tile t, one barrier per tile
 //   * LDS image is lane-linear (DMA constraint); the bank-conflict XOR swizzle is applied on the per-lane
 //     SOURCE address and again on the ds_read_b128 address (16-byte chunk ^= (row>>1)&7)
 //   * MFMA is issued with swapped operands (D^T = B.A^T) so each lane owns 4 consecutive N of one row:
 //     8-byte bf16 / 16-byte fp32 epilogue stores
 //   * XCD-aware bijective block remap + grouped tile order so neighbouring tiles share L2
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per stage
+constexpr int BK = 64;
 
 struct GemmArgs {
     const bf16_t* A; const bf16_t* B; void* C;
@@ -42,14 +45,16 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     }
 }
 
-// Issue the global->LDS DMA of one 128x64 bf16 tile (rows r0.., cols k0..k0+63) into `lds` (16 KiB).
-// 16 wave-instructions of 1 KiB cover the tile; wave w issues instructions w*4 .. w*4+3.
+// Issue the global->LDS DMA of one ROWS x 64 bf16 tile (rows r0.., cols k0..k0+63) into `lds` (ROWS*128 B).
+// ROWS/8 wave-instructions of 1 KiB cover the tile; wave w issues instructions w*PER .. w*PER+PER-1.
+template <int ROWS, int NWAVES>
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, long ld, int r0, int rmax, int k0,
                                            char* lds, int wave, int lane) {
+    constexpr int PER = ROWS / 8 / NWAVES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int inst = wave * 4 + i;
-        const int row = inst * 8 + (lane >> 3);          // tile row 0..127
+    for (int i = 0; i < PER; ++i) {
+        const int inst = wave * PER + i;
+        const int row = inst * 8 + (lane >> 3);          // tile row
         const int pchunk = lane & 7;                     // physical 16-B chunk in the LDS row
         const int chunk = pchunk ^ ((row >> 1) & 7);     // logical chunk this lane must fetch
         int gr = r0 + row;
@@ -65,8 +70,54 @@ __device__ __forceinline__ bf16x8 lds_frag(const char* lds, int row, int chunk) 
     return *(const bf16x8*)(lds + row * 128 + p * 16);
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A 16K | B 16K]
+// One accumulator fragment -> memory with the fused epilogue.  Deliberately NOT inlined: the 256x256 tile has 32
+// fragments per lane and a fully inlined epilogue exceeds hipcc's unroll budget, which leaves the fragment index
+// dynamic and pushes the whole accumulator array to scratch (5x slower).
+struct EpiArgs {
+    void* C; const bf16_t* bias; const void* resid; long ldc, ldr; int M, N, out_f32, act; float alpha;
+};
+__device__ __noinline__ void store_frag(EpiArgs g, int m, int n, f32x4 a) {
+    if (m >= g.M || n >= g.N) return;
+    float v[4] = {a[0], a[1], a[2], a[3]};
+    const int nv = min(4, g.N - n);
+    const bool n_vec_ok = (g.N % 4) == 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v[e] *= g.alpha;
+        if (g.bias && e < nv) v[e] += bf2f(g.bias[n + e]);
+        v[e] = apply_act(v[e], g.act);
+    }
+    if (g.out_f32) {
+        float* c = (float*)g.C + (long)m * g.ldc + n;
+        const float* r = g.resid ? (const float*)g.resid + (long)m * g.ldr + n : nullptr;
+        if (nv == 4 && n_vec_ok && (g.ldc % 4) == 0 && (!r || (g.ldr % 4) == 0)) {
+            float4 o = make_float4(v[0], v[1], v[2], v[3]);
+            if (r) { const float4 rr = *(const float4*)r; o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w; }
+            *(float4*)c = o;
+        } else {
+            for (int e = 0; e < nv; ++e) c[e] = v[e] + (r ? r[e] : 0.f);
+        }
+    } else {
+        bf16_t* c = (bf16_t*)g.C + (long)m * g.ldc + n;
+        const bf16_t* r = g.resid ? (const bf16_t*)g.resid + (long)m * g.ldr + n : nullptr;
+        if (nv == 4 && n_vec_ok && (g.ldc % 4) == 0 && (!r || (g.ldr % 4) == 0)) {
+            if (r) {
+                const uint2 rr = *(const uint2*)r;
+                v[0] += bf_lo(rr.x); v[1] += bf_hi(rr.x); v[2] += bf_lo(rr.y); v[3] += bf_hi(rr.y);
+            }
+            *(uint2*)c = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+        } else {
+            for (int e = 0; e < nv; ++e) c[e] = f2bf(v[e] + (r ? bf2f(r[e]) : 0.f));
+        }
+    }
+}
+
+template <int WAVES_M, int WAVES_N, int FM, int FN>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N == 4) ? 2 : 1) void gemm_bf16_nt_kernel(GemmArgs g) {
+    constexpr int NWAVES = WAVES_M * WAVES_N;
+    constexpr int BM = WAVES_M * FM * 16, BN = WAVES_N * FN * 16;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A | B]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -77,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmArgs g) {
         const int b = blockIdx.x, x = b & 7, q = nwg >> 3, r = nwg & 7;
         pid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
     }
-    constexpr int GM = 8;
+    constexpr int GM = (BM == 128) ? 8 : 4;
     const int per_group = GM * g.tiles_n;
     const int group = pid / per_group, first_m = group * GM;
     const int gsz = min(g.tiles_m - first_m, GM);
@@ -85,88 +136,181 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmArgs g) {
     const int tn = (pid % per_group) / gsz;
     const int m0 = tm * BM, n0 = tn * BN;
 
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;  // wave's 64x64 sub-tile
-    f32x4 acc[4][4];
+    const int wm = (wave / WAVES_N) * (FM * 16), wn = (wave % WAVES_N) * (FN * 16);  // wave's sub-tile origin
+    f32x4 acc[FM][FN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nt = g.K / BK;
-    stage_tile(g.A, g.lda, m0, g.M, 0, smem, wave, lane);
-    stage_tile(g.B, g.ldb, n0, g.N, 0, smem + TILE_BYTES, wave, lane);
+    stage_tile<BM, NWAVES>(g.A, g.lda, m0, g.M, 0, smem, wave, lane);
+    stage_tile<BN, NWAVES>(g.B, g.ldb, n0, g.N, 0, smem + A_BYTES, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     for (int t = 0; t < nt; ++t) {
-        const char* cur = smem + (t & 1) * (2 * TILE_BYTES);
-        char* nxt = smem + ((t + 1) & 1) * (2 * TILE_BYTES);
+        const char* cur = smem + (t & 1) * STAGE;
+        char* nxt = smem + ((t + 1) & 1) * STAGE;
         if (t + 1 < nt) {
-            stage_tile(g.A, g.lda, m0, g.M, (t + 1) * BK, nxt, wave, lane);
-            stage_tile(g.B, g.ldb, n0, g.N, (t + 1) * BK, nxt + TILE_BYTES, wave, lane);
+            stage_tile<BM, NWAVES>(g.A, g.lda, m0, g.M, (t + 1) * BK, nxt, wave, lane);
+            stage_tile<BN, NWAVES>(g.B, g.ldb, n0, g.N, (t + 1) * BK, nxt + A_BYTES, wave, lane);
         }
+        // The wave tile is walked in (k-step, 4-row-fragment group) passes of 4 x FN MFMAs; the scheduler is fenced
+        // between passes of the big tile, otherwise hipcc hoists every fragment read of the K tile and spills.
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 a[4], b[4];
+            bf16x8 b[FN];
             const int chunk = kk * 4 + (lane >> 4);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = lds_frag(cur, wm + i * 16 + (lane & 15), chunk);
+            for (int j = 0; j < FN; ++j) b[j] = lds_frag(cur + A_BYTES, wn + j * 16 + (lane & 15), chunk);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = lds_frag(cur + TILE_BYTES, wn + j * 16 + (lane & 15), chunk);
+            for (int ih = 0; ih < FM; ih += 4) {
+                bf16x8 a[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i) a[i] = lds_frag(cur, wm + (ih + i) * 16 + (lane & 15), chunk);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    // swapped operands: D'[n][m] -> lane holds n = (lane>>4)*4 + r, m = lane&15
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        // swapped operands: D'[n][m] -> lane holds n = (lane>>4)*4 + r, m = lane&15
+                        acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[ih + i][j], 0, 0, 0);
+                if (NWAVES == 8) __builtin_amdgcn_sched_barrier(0);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
     // ---- epilogue: lane owns C[m][n..n+3], m = m0+wm+i*16+(lane&15), n = n0+wn+j*16+(lane>>4)*4 ----
-    const bool n_vec_ok = (g.N % 4) == 0;
+    const EpiArgs e = {g.C, g.bias, g.resid, g.ldc, g.ldr, g.M, g.N, g.out_f32, g.act, g.alpha};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm + i * 16 + (lane & 15);
-        if (m >= g.M) continue;
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn + j * 16 + (lane >> 4) * 4;
-            if (n >= g.N) continue;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            const int nv = min(4, g.N - n);
+        for (int j = 0; j < FN; ++j)
+            store_frag(e, m0 + wm + i * 16 + (lane & 15), n0 + wn + j * 16 + (lane >> 4) * 4, acc[i][j]);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// 256x256x64, 8 waves (2x4, wave = 128x64), PHASED schedule (cdna_hip_programming T3/T4/T5 adapted):
+//   * each K tile is consumed in 4 phases of 16 MFMAs (one 64x32 quadrant of the wave tile x both k-steps); a phase
+//     is a LOAD segment (ds_read the quadrant's fragments + issue a share of the next tile's global->LDS DMA) and a
+//     COMPUTE segment (the MFMAs), separated by raw s_barriers
+//   * the two wave rows (wr = 0 / 1) run ONE SEGMENT APART: the two waves that share a SIMD alternate roles, so the
+//     matrix pipe is fed by one while the other waits on LDS / issues DMA (s_setprio favours the computing wave)
+//   * the next tile's DMA is issued in phases 0-2 (3+3+2 instructions per wave) and waited for at the end of phase 3's
+//     load segment: every DMA has >= 2 segments to land, and its LDS slot was released a full tile earlier
+template <int DUMMY>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256p_kernel(GemmArgs g) {
+    constexpr int BM = 256, BN = 256;
+    constexpr bool STAGGER = (DUMMY & 1) == 0, PRIO = (DUMMY & 2) == 0;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A | B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int nwg = g.tiles_m * g.tiles_n;
+    int pid;
+    {
+        const int b = blockIdx.x, x = b & 7, q = nwg >> 3, r = nwg & 7;
+        pid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+    }
+    constexpr int GM = 4;
+    const int per_group = GM * g.tiles_n;
+    const int group = pid / per_group, first_m = group * GM;
+    const int gsz = min(g.tiles_m - first_m, GM);
+    const int tm = first_m + (pid % per_group) % gsz;
+    const int tn = (pid % per_group) / gsz;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int wm = wr * 128, wn = wc * 64;
+
+    f32x4 acc[8][4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[e] *= g.alpha;
-                if (g.bias && e < nv) v[e] += bf2f(g.bias[n + e]);
-                v[e] = apply_act(v[e], g.act);
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // DMA share of this wave: instructions q = wave*8 + i of the combined [A (32 x 1 KiB) | B (32 x 1 KiB)] tile image
+    auto dma = [&](char* slot, int k0, int i) {
+        const int q = wave * 8 + i;
+        const bool isA = q < 32;
+        const int inst = isA ? q : q - 32;
+        const int row = inst * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        int gr = (isA ? m0 : n0) + row;
+        const int rmax = isA ? g.M : g.N;
+        gr = gr < rmax ? gr : rmax - 1;
+        const bf16_t* src = (isA ? g.A + (long)gr * g.lda : g.B + (long)gr * g.ldb) + k0 + chunk * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(slot + (isA ? 0 : A_BYTES) + inst * 1024), 16, 0, 0);
+    };
+
+    const int nt = g.K / BK;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dma(smem, 0, i);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (STAGGER && wr == 1) __builtin_amdgcn_s_barrier();          // stagger: wave row 1 runs one segment behind wave row 0
+
+    bf16x8 a[4][2], b[2][2];
+    for (int t = 0; t < nt; ++t) {
+        const char* cur = smem + (t & 1) * STAGE;
+        char* nxt = smem + ((t + 1) & 1) * STAGE;
+        const bool more = t + 1 < nt;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int mq = p >> 1, nq = (p == 1 || p == 2) ? 1 : 0;       // quadrants (0,0) (0,1) (1,1) (1,0)
+            // ---------------- load segment
+            if (p == 0 || p == 2) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        a[i][kk] = lds_frag(cur, wm + (mq * 4 + i) * 16 + (lane & 15), kk * 4 + (lane >> 4));
             }
-            if (g.out_f32) {
-                float* c = (float*)g.C + (long)m * g.ldc + n;
-                const float* r = g.resid ? (const float*)g.resid + (long)m * g.ldr + n : nullptr;
-                if (nv == 4 && n_vec_ok && (g.ldc % 4) == 0 && (!r || (g.ldr % 4) == 0)) {
-                    float4 o = make_float4(v[0], v[1], v[2], v[3]);
-                    if (r) { const float4 rr = *(const float4*)r; o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w; }
-                    *(float4*)c = o;
-                } else {
-                    for (int e = 0; e < nv; ++e) c[e] = v[e] + (r ? r[e] : 0.f);
-                }
-            } else {
-                bf16_t* c = (bf16_t*)g.C + (long)m * g.ldc + n;
-                const bf16_t* r = g.resid ? (const bf16_t*)g.resid + (long)m * g.ldr + n : nullptr;
-                if (nv == 4 && n_vec_ok && (g.ldc % 4) == 0 && (!r || (g.ldr % 4) == 0)) {
-                    if (r) {
-                        const uint2 rr = *(const uint2*)r;
-                        v[0] += bf_lo(rr.x); v[1] += bf_hi(rr.x); v[2] += bf_lo(rr.y); v[3] += bf_hi(rr.y);
-                    }
-                    *(uint2*)c = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-                } else {
-                    for (int e = 0; e < nv; ++e) c[e] = f2bf(v[e] + (r ? bf2f(r[e]) : 0.f));
-                }
+            if (p != 2) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        b[j][kk] = lds_frag(cur + A_BYTES, wn + (nq * 2 + j) * 16 + (lane & 15), kk * 4 + (lane >> 4));
             }
+            if (more) {
+                if (p == 0) { dma(nxt, (t + 1) * BK, 0); dma(nxt, (t + 1) * BK, 1); dma(nxt, (t + 1) * BK, 2); }
+                if (p == 1) { dma(nxt, (t + 1) * BK, 3); dma(nxt, (t + 1) * BK, 4); dma(nxt, (t + 1) * BK, 5); }
+                if (p == 2) { dma(nxt, (t + 1) * BK, 6); dma(nxt, (t + 1) * BK, 7); }
+            }
+            if (p == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---------------- compute segment
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[mq * 4 + i][nq * 2 + j] =
+                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][kk], a[i][kk], acc[mq * 4 + i][nq * 2 + j], 0, 0, 0);
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
+    if (STAGGER && wr == 0) __builtin_amdgcn_s_barrier();
+
+    const EpiArgs e = {g.C, g.bias, g.resid, g.ldc, g.ldr, g.M, g.N, g.out_f32, g.act, g.alpha};
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            store_frag(e, m0 + wm + i * 16 + (lane & 15), n0 + wn + j * 16 + (lane >> 4) * 4, acc[i][j]);
 }
 
 }  // namespace
@@ -190,9 +334,42 @@ extern "C" int spacer_gemm_bf16_nt(const void* A, long lda, const void* B, long 
     if (epi && epi->alpha == 0.f) g.alpha = 1.f;
     const int esz = g.out_f32 ? 4 : 2;
     SP_REQUIRE(((uintptr_t)C % (4 * esz)) == 0, SPACER_EINVAL, "gemm: C misaligned");
-    g.tiles_m = cdiv(M, BM); g.tiles_n = cdiv(N, BN);
-    const int grid = g.tiles_m * g.tiles_n;
-    hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3(grid), dim3(256), 4 * TILE_BYTES, (hipStream_t)stream, g);
+    // tile choice: the 256x256 tile needs enough tiles to fill 256 CUs at one workgroup per CU
+    static const char* force = getenv("SPACER_GEMM_TILE");
+    const long tiles256 = (long)cdiv(M, 256) * cdiv(N, 256);
+    // wave-quantisation aware choice: the 256 tile is ~15 % faster per tile-FLOP but runs one workgroup per CU
+    // (256 slots) against two for the 128 tile (512 slots); pick the better (efficiency x speed) product
+    const long tiles128 = (long)cdiv(M, 128) * cdiv(N, 128);
+    const double eff256 = (double)tiles256 / (double)(cdiv(tiles256, 256) * 256L);
+    const double eff128 = (double)tiles128 / (double)(cdiv(tiles128, 512) * 512L);
+    bool big = 1.15 * eff256 > eff128;
+    if (force) big = atoi(force) == 256;
+    hipStream_t s = (hipStream_t)stream;
+    if (force && atoi(force) >= 257 && atoi(force) <= 260) {
+        constexpr int LDS = 2 * (256 * BK * 2 + 256 * BK * 2);
+        g.tiles_m = cdiv(M, 256); g.tiles_n = cdiv(N, 256);
+        const int var = atoi(force) - 257;
+#define LAUNCH_P(V)                                                                                                     \
+        do {                                                                                                            \
+            static const int o = hipFuncSetAttribute((const void*)gemm_bf16_nt_256p_kernel<V>,                          \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS);                  \
+            (void)o;                                                                                                    \
+            hipLaunchKernelGGL((gemm_bf16_nt_256p_kernel<V>), dim3(g.tiles_m * g.tiles_n), dim3(512), LDS, s, g);        \
+        } while (0)
+        if (var == 0) LAUNCH_P(0); else if (var == 1) LAUNCH_P(1); else if (var == 2) LAUNCH_P(2); else LAUNCH_P(3);
+#undef LAUNCH_P
+    } else if (big) {
+        constexpr int LDS = 2 * (256 * BK * 2 + 256 * BK * 2);
+        static const int once = hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<2, 4, 8, 4>,
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)once;
+        g.tiles_m = cdiv(M, 256); g.tiles_n = cdiv(N, 256);
+        hipLaunchKernelGGL((gemm_bf16_nt_kernel<2, 4, 8, 4>), dim3(g.tiles_m * g.tiles_n), dim3(512), LDS, s, g);
+    } else {
+        constexpr int LDS = 2 * (128 * BK * 2 + 128 * BK * 2);
+        g.tiles_m = cdiv(M, 128); g.tiles_n = cdiv(N, 128);
+        hipLaunchKernelGGL((gemm_bf16_nt_kernel<2, 2, 4, 4>), dim3(g.tiles_m * g.tiles_n), dim3(256), LDS, s, g);
+    }
     SP_CHECK_LAUNCH();
     return SPACER_OK;
 }

@@ -41,6 +41,7 @@ class _Profiler:
 
     def __init__(self):
         self.enabled = False
+        self.by_shape = False
         self.records = []
 
     def reset(self, enabled: bool = False):
@@ -98,6 +99,9 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = N
                                           M, N, K, C.byref(epi), _stream()), "gemm_bf16_nt")
     ka = algo_k or K       # algorithmic contraction length (dW GEMMs run on a zero-padded token dim)
     PROFILER.end("gemm_bf16_nt_kernel", t0, 2.0 * M * N * ka, 2.0 * (M * ka + N * ka) + out.element_size() * M * N)
+    if PROFILER.by_shape and t0 is not None:
+        s0, e0 = PROFILER.records[-1][1], PROFILER.records[-1][2]
+        PROFILER.records.append((f"gemm[{M}x{N}x{K}]", s0, e0, 2.0 * M * N * ka, 0.0))
     return out
 
 
