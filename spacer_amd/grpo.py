@@ -103,12 +103,13 @@ class GRPOEngine:
     """Owns policy + frozen reference weights, fp32 master / Adam state / gradients, and runs the step phases."""
 
     def __init__(self, cfg: Qwen2VLConfig, policy: FlatParams, hyper: GRPOHyper, *, ref: Optional[FlatParams] = None,
-                 process_group=None):
+                 process_group=None, cache_wT: bool = True):
         self.cfg, self.h = cfg, hyper
         self.dev = policy.flat.device
         self.policy = policy
         self.ref = ref if ref is not None else FlatParams(cfg, policy.flat.clone(), policy.specs)   # create_reference_model
-        self.engine = Qwen2VLEngine(cfg, self.policy)
+        # W^T copies for the dX GEMMs are kept for the whole optimizer step (all prompt groups reuse them): +1x weights
+        self.engine = Qwen2VLEngine(cfg, self.policy, cache_wT=cache_wT)
         self.ref_engine = Qwen2VLEngine(cfg, self.ref)
         self.roll = RolloutEngine(self.engine)
         self.master = FlatParams(cfg, policy.flat.float(), policy.specs)
