@@ -67,6 +67,17 @@ def cpu_baseline(cfg, seconds_budget: float = 12.0):
     return rate, threads, f"{n} fp32 forwards of one {cfg.hidden}-wide decoder layer over {T} tokens ({dt:.1f} s)"
 
 
+def pmc_traffic(workload: str):
+    """L2-miss (fabric/HBM side) bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_gemm_pmc.json: FETCH_SIZE doubled + WRITE_SIZE, KiB -> bytes, weighted by the cfg3 launch mix).
+    PMC collection is a separate run by construction; null for workloads it was not collected on."""
+    path = os.path.join(ROOT, "profiles", "r01_gemm_pmc.json")
+    if workload not in ("cfg3", "cfg4") or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return round(json.load(f)["hbm_bytes_per_launch"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -183,7 +194,8 @@ def main():
                        "global_batch": groups * Kgen * world, "parallelism": f"dp{world}", "decode_graph": not args.no_graph},
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_kernel", "achieved": round(gemm["tflops"], 2),
                          "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gemm["tflops"] / MFMA_PEAK_TFLOPS, 4),
-                         "traffic": None, "launches": gemm["launches"],
+                         "traffic": pmc_traffic(args.workload), "launches": gemm["launches"],
+                         "algorithmic_bytes_per_launch": round(gemm["bytes"] / max(1, gemm["launches"])),
                          "avg_launch_us": round(1e6 * gemm["seconds"] / max(1, gemm["launches"]), 2),
                          "share_of_step": round(gemm["seconds"] / elapsed, 3)},
             "kernels": {k: {"tflops": round(v["tflops"], 2), "launches": v["launches"], "seconds": round(v["seconds"], 4)}

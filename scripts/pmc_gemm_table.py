@@ -1,0 +1,37 @@
+"""Combine the FETCH_SIZE / WRITE_SIZE passes over scripts/gemm_step_shapes.py into profiles/<name>.json:
+per-shape HBM bytes per launch (FETCH_SIZE doubled, both in KiB -> bytes: MI355X_MICROARCH.md HBM section) and the
+launch-weighted average over one cfg3 step.   usage: pmc_gemm_table.py fetch.db write.db out.json"""
+import json
+import os
+import sqlite3
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from gemm_step_shapes import SHAPES  # noqa: E402
+
+
+def per_dispatch(db, counter):
+    cur = sqlite3.connect(db).cursor()
+    rows = list(cur.execute("select dispatch_id, value from counters_collection where counter_name = ? and kernel_name like "
+                            "'%gemm_bf16_nt_kernel%' order by dispatch_id", (counter,)))
+    return [v for _, v in rows]
+
+
+fetch, write = per_dispatch(sys.argv[1], "FETCH_SIZE"), per_dispatch(sys.argv[2], "WRITE_SIZE")
+reps = len(fetch) // len(SHAPES)
+assert len(fetch) == len(write) == reps * len(SHAPES), (len(fetch), len(write), len(SHAPES))
+table, tot_bytes, tot_launch, tot_algo = [], 0.0, 0, 0.0
+for i, (M, N, K, launches, f32) in enumerate(SHAPES):
+    f = sum(fetch[i * reps:(i + 1) * reps]) / reps
+    w = sum(write[i * reps:(i + 1) * reps]) / reps
+    hbm = (2.0 * f + w) * 1024.0
+    algo = 2.0 * (M * K + N * K) + (4 if f32 else 2) * M * N
+    table.append(dict(M=M, N=N, K=K, launches_per_step=launches, fetch_kib=f, write_kib=w, hbm_bytes=hbm, algorithmic_bytes=algo,
+                      ratio=hbm / algo))
+    tot_bytes += hbm * launches; tot_launch += launches; tot_algo += algo * launches
+out = dict(kernel="gemm_bf16_nt_kernel", method="rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over "
+           "scripts/gemm_step_shapes.py; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts half of wide reads)",
+           hbm_bytes_per_launch=tot_bytes / tot_launch, algorithmic_bytes_per_launch=tot_algo / tot_launch,
+           launches_per_step=tot_launch, shapes=table)
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print(json.dumps({k: v for k, v in out.items() if k != "shapes"}))

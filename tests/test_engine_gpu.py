@@ -51,6 +51,15 @@ def test_logps_match_oracle(setup):
     want = O.completion_logps(s["wb"], g["cfg"], g["prompt"], g["completions"], s["rows"], [s["grid"]])
     err = (lp.cpu() - want).abs().max()
     assert err < 8e-3, f"log-prob max abs err {err}"   # bf16 activations; see DESIGN.md "numerics"
+    # the reference's own bf16 eager numerics (every op output rounded to bf16, bf16 residual stream and logits),
+    # emulated on the CPU: this engine must be at least as close to the fp32 truth as the reference path is
+    from oracle import qwen2vl_bf16_emul as E
+    ref_bf16 = E.completion_logps(s["wb"], g["cfg"], g["prompt"], g["completions"], s["rows"], [s["grid"]])
+    err_ref = (ref_bf16 - want).abs().max()
+    err_pair = (lp.cpu() - ref_bf16).abs().max()
+    print(f"max |logp - fp32 oracle|: engine {float(err):.2e}, reference-style bf16 eager {float(err_ref):.2e}; "
+          f"engine vs bf16 eager {float(err_pair):.2e}")
+    assert err <= err_ref + 1e-3
     # text-only prompt (no video) goes through the same path
     lp2 = s["eng"].score_group(g["prompt"][-9:].to(dev), g["completions"].to(dev), None, None)
     want2 = O.completion_logps(s["wb"], g["cfg"], g["prompt"][-9:], g["completions"], None, None)
