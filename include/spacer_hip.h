@@ -127,6 +127,15 @@ int spacer_attn_bwd(const void* q, const void* k, const void* v, const void* o, 
 int spacer_attn_decode(const void* q, const void* prefix_k, const void* prefix_v, const int* prefix_len,
                        const int* prompt_of, const void* tail_k, const void* tail_v, const int* tail_len_dev, void* o,
                        int B, int Pmax, int Cmax, int Hq, int Hkv, int D, float scale, spacer_stream_t stream);
+/* Same result, but the prompt keys are scored ONCE per (prompt, kv head) for all Kn rollouts of the prompt (rows
+ * b = prompt * Kn + k must be contiguous per prompt; Kn * Hq/Hkv <= 64) and merged with each rollout's tail keys:
+ * decode attention is bound by per-CU load bandwidth, so not re-reading the prompt per rollout is ~3x faster.
+ * workspace: spacer_attn_decode_workspace_bytes(n_prompts, Hkv) bytes of device memory. */
+long spacer_attn_decode_workspace_bytes(int n_prompts, int Hkv);
+int spacer_attn_decode_shared(const void* q, const void* prefix_k, const void* prefix_v, const int* prefix_len,
+                              const int* prompt_of, const void* tail_k, const void* tail_v, const int* tail_len_dev, void* o,
+                              void* workspace, int B, int Kn, int Pmax, int Cmax, int Hq, int Hkv, int D, float scale,
+                              spacer_stream_t stream);
 
 /* Decode-step helpers (all read the step / tail length from device memory so that one decode step can be
  * captured in a hipGraph and replayed):

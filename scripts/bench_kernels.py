@@ -72,7 +72,8 @@ def bench_decode_attn():
         o = torch.empty(B, Hq * D, device=dev, dtype=BF)
         t = timeit(lambda: K.attn_decode(q, pk, pv, plen, pof, tk, tv, tld, Hq, Hkv, D, D ** -0.5, out=o))
         kv = (nP * P + B * (tl + 1)) * Hkv * D * 2 * 2
-        print(f"  tail {tl:4d}: {t * 1e6:8.1f} us   unique KV {kv / 1e6:7.1f} MB -> {kv / t / 1e12:5.2f} TB/s")
+        t2 = timeit(lambda: K.attn_decode_shared(q, pk, pv, plen, pof, tk, tv, tld, 8, Hq, Hkv, D, D ** -0.5, out=o))
+        print(f"  tail {tl:4d}: per-seq {t * 1e6:7.1f} us | shared-prefix {t2 * 1e6:7.1f} us   unique KV {kv / 1e6:7.1f} MB -> {kv / t2 / 1e12:5.2f} TB/s")
 
 
 def bench_sampler():

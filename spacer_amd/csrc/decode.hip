@@ -198,25 +198,132 @@ __global__ __launch_bounds__(256) void swiglu_f32_kernel(float* __restrict__ acc
 
 // x32 += 0 helper not needed; residual adds land in the fp32 stream through the skinny GEMM atomics.
 
+// =============================================================================== decode attention: shared prompt keys
+// The K rollouts of one prompt all attend the same prompt keys.  Workgroup = (prompt, kv head, key split): the query
+// COLUMNS are the (rollout, q-head) pairs of the prompt (Kn * REP <= 64, one 16-column block per wave), the prompt's
+// K / V tiles are staged once in LDS (row-major K image + transposed V image, as in the prefill kernel) and scored
+// against all columns by MFMA.  Per-column partial (O, m, l) go to a small fp32 workspace; the tail kernel merges them.
+// Each prompt key is read once per kv head instead of once per rollout (per-CU load bandwidth is what bounds decode
+// attention: ~24 GB/s per CU, so re-reading the prompt in all 8 rollouts' workgroups costs 8x the time).
+constexpr int PRE_SPLITS = 8;
+
+template <int REP>
+__global__ __launch_bounds__(256, 2) void attn_decode_prefix_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ pk,
+                                                                    const bf16_t* __restrict__ pv, const int* __restrict__ plen,
+                                                                    float* __restrict__ pre, int Kn, int Pmax, int Hq, int Hkv,
+                                                                    float scale) {
+    constexpr int D = 128, DC = 4, DF = 8;
+    __shared__ __attribute__((aligned(16))) char smem[AT_RM_BYTES + AT_T_BYTES(D)];
+    char* k_lds = smem;
+    char* vt_lds = smem + AT_RM_BYTES;
+    const int pr = blockIdx.x, hk = blockIdx.y, sp = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int P = plen[pr];
+    const int tiles = (P + 63) >> 6, tps = (tiles + PRE_SPLITS - 1) / PRE_SPLITS;
+    const int t0 = sp * tps, t1 = min(tiles, t0 + tps);
+    const int col = wave * 16 + l15;                       // (rollout, head) column of this lane
+    const bool col_ok = col < Kn * REP;
+    bf16x8 qf[DC];
+    {
+        const int kr = col_ok ? col / REP : 0, hr = col_ok ? col % REP : 0;
+        const bf16_t* qp = q + ((long)(pr * Kn + kr) * Hq + hk * REP + hr) * D;
+#pragma unroll
+        for (int dc = 0; dc < DC; ++dc) {
+            uint4 t = make_uint4(0, 0, 0, 0);
+            if (col_ok) t = *(const uint4*)(qp + dc * 32 + g * 8);
+            qf[dc] = __builtin_bit_cast(bf16x8, t);
+        }
+    }
+    f32x4 oacc[DF];
+#pragma unroll
+    for (int d = 0; d < DF; ++d) oacc[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    const long row_stride = (long)Hkv * D;
+    uint4 kreg[4], vreg[4];
+    if (t0 < t1) {
+        const long off = (((long)pr * Pmax + t0 * 64) * Hkv + hk) * D;
+        tile_load<D>(kreg, pk + off, row_stride, P - t0 * 64, tid);
+        tile_load<D>(vreg, pv + off, row_stride, P - t0 * 64, tid);
+    }
+    for (int t = t0; t < t1; ++t) {
+        __syncthreads();
+        tile_store<D, true, false>(kreg, k_lds, nullptr, tid);
+        tile_store<D, false, true>(vreg, nullptr, vt_lds, tid);
+        __syncthreads();
+        if (t + 1 < t1) {
+            const long off = (((long)pr * Pmax + (t + 1) * 64) * Hkv + hk) * D;
+            tile_load<D>(kreg, pk + off, row_stride, P - (t + 1) * 64, tid);
+            tile_load<D>(vreg, pv + off, row_stride, P - (t + 1) * 64, tid);
+        }
+        f32x4 st[4];
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf) {
+            st[kf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dc = 0; dc < DC; ++dc)
+                st[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rm(k_lds, kf, dc, lane), qf[dc], st[kf], 0, 0, 0);
+        }
+        float p[4][4], mx = -INFINITY;
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sv = (t * 64 + kf * 16 + g * 4 + r < P) ? st[kf][r] * scale : -INFINITY;
+                p[kf][r] = sv;
+                mx = fmaxf(mx, sv);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);           // finite: a visited tile has >= 1 valid key
+        const float alpha = __expf(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { p[kf][r] = __expf(p[kf][r] - m_new); psum += p[kf][r]; }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < DF; ++d) oacc[d] *= alpha;
+        const bf16x8 pf0 = pack_slots(p[0], p[1]), pf1 = pack_slots(p[2], p[3]);
+#pragma unroll
+        for (int df = 0; df < DF; ++df) {
+            oacc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t(vt_lds, df, 0, lane), pf0, oacc[df], 0, 0, 0);
+            oacc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t(vt_lds, df, 1, lane), pf1, oacc[df], 0, 0, 0);
+        }
+    }
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    // lane holds O^T[d = df*16 + g*4 + r][col]; partial record = [D floats O | m | l]
+    float* rec = pre + (((long)(pr * Hkv + hk) * PRE_SPLITS + sp) * 64 + col) * (D + 2);
+#pragma unroll
+    for (int df = 0; df < DF; ++df)
+        *(float4*)(rec + df * 16 + g * 4) = make_float4(oacc[df][0], oacc[df][1], oacc[df][2], oacc[df][3]);
+    if (g == 0) { rec[D] = m_run; rec[D + 1] = l_run; }
+}
+
 // =============================================================================== decode attention (MFMA)
 // Workgroup = (sequence b, kv head); the REP q-heads of the GQA group are the MFMA's 16-wide N dimension (zero
 // padded), so every K/V byte is read once per workgroup and scored against all heads by the matrix cores:
 //   S^T = K . Q^T   (A = K fragment loaded straight from global memory, row-per-lane 16 B; B = Q in registers)
 //   O^T += V^T . P^T (V tile transposed through a wave-private LDS region, same slot permutation as the forward kernel)
 // The 4 waves stride over 64-key tiles of [shared prompt KV | per-rollout tail KV] and are merged through LDS.
-template <int REP>
-__global__ __launch_bounds__(256, 2) void attn_decode_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ pk,
+template <int REP, int NW>
+__global__ __launch_bounds__(NW * 64, (NW == 4) ? 2 : 1) void attn_decode_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ pk,
                                                                   const bf16_t* __restrict__ pv, const int* __restrict__ plen,
                                                                   const int* __restrict__ prompt_of, const bf16_t* __restrict__ tk,
                                                                   const bf16_t* __restrict__ tv, const int* __restrict__ tail_len,
                                                                   bf16_t* __restrict__ o, int Pmax, int Cmax, int Hq, int Hkv,
-                                                                  float scale) {
+                                                                  float scale, const float* __restrict__ pre, int Kn) {
+    // pre != nullptr: the prompt keys were already scored for all rollouts of the prompt by attn_decode_prefix_kernel;
+    // this launch covers the tail keys only and folds the PRE_SPLITS prefix partials into its merge.
     constexpr int D = 128, DC = 4, DF = 8;
-    __shared__ __attribute__((aligned(16))) char smem[4 * AT_T_BYTES(D)];      // 4 x 16 KiB: V^T per wave, then the merge
+    extern __shared__ __attribute__((aligned(16))) char smem[];               // NW x 16 KiB: V^T per wave, then the merge
     const int b = blockIdx.x, hk = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int pr = prompt_of[b], P = plen[pr], total = P + *tail_len + 1;
+    const int pr = prompt_of[b], P = pre ? 0 : plen[pr], total = P + *tail_len + 1;
     char* vt = smem + wave * AT_T_BYTES(D);
 
     bf16x8 qf[DC];
@@ -238,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void attn_decode_mfma_kernel(const bf16_t* 
     for (int d = 0; d < DF; ++d) oacc[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
 
-    for (int k0 = wave * 64; k0 < total; k0 += 256) {
+    for (int k0 = wave * 64; k0 < total; k0 += NW * 64) {
         // ---- V tile -> registers (4 passes: d-chunk c = lane & 15, row quad rq = (lane >> 4) + 4 i), issued first
         uint4 vreg[4][4];
 #pragma unroll
@@ -312,27 +419,44 @@ __global__ __launch_bounds__(256, 2) void attn_decode_mfma_kernel(const bf16_t* 
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
     __syncthreads();                                   // every wave is done with its V^T image
-    float* mo = (float*)smem;                          // [4][D][16] O^T, then [4][16] m, [4][16] l
-    float* mm = mo + 4 * D * 16;
-    float* ml = mm + 64;
+    float* mo = (float*)smem;                          // [NW][D][16] O^T, then [NW][16] m, [NW][16] l
+    float* mm = mo + NW * D * 16;
+    float* ml = mm + NW * 16;
 #pragma unroll
     for (int df = 0; df < DF; ++df)
 #pragma unroll
         for (int r = 0; r < 4; ++r) mo[(wave * D + df * 16 + g * 4 + r) * 16 + l15] = oacc[df][r];
     if (g == 0) { mm[wave * 16 + l15] = m_run; ml[wave * 16 + l15] = l_run; }
     __syncthreads();
-    for (int i = tid; i < REP * D; i += 256) {
+    for (int i = tid; i < REP * D; i += NW * 64) {
         const int qh = i / D, d = i % D;
         float M = -INFINITY;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) M = fmaxf(M, mm[w * 16 + qh]);
+        for (int w = 0; w < NW; ++w) M = fmaxf(M, mm[w * 16 + qh]);
         float L = 0.f, O = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < NW; ++w) {
             const float mw = mm[w * 16 + qh];
             const float f = (mw == -INFINITY) ? 0.f : __expf(mw - M);
             L += ml[w * 16 + qh] * f;
             O += mo[(w * D + d) * 16 + qh] * f;
+        }
+        if (pre) {      // prefix partials of column (rollout within prompt, head): [prompt][hk][split][64 cols][D + 2]
+            const int col = (b - pr * Kn) * REP + qh;
+            const float* pp = pre + ((long)(pr * Hkv + hk) * PRE_SPLITS * 64 + col) * (D + 2);
+            float M2 = M;
+#pragma unroll
+            for (int sp = 0; sp < PRE_SPLITS; ++sp) M2 = fmaxf(M2, pp[(long)sp * 64 * (D + 2) + D]);
+            const float f0 = (M == -INFINITY) ? 0.f : __expf(M - M2);
+            L *= f0; O *= f0;
+#pragma unroll
+            for (int sp = 0; sp < PRE_SPLITS; ++sp) {
+                const float* q1 = pp + (long)sp * 64 * (D + 2);
+                const float ms = q1[D];
+                const float f = (ms == -INFINITY) ? 0.f : __expf(ms - M2);
+                L += q1[D + 1] * f;
+                O += q1[d] * f;
+            }
         }
         o[((long)b * Hq + hk * REP + qh) * D + d] = f2bf(O / L);
     }
@@ -439,7 +563,8 @@ static int launch_skinny(const void* A, long lda, const void* B, long ldb, void*
     // K ranges: 1 (no atomics) when the column groups alone fill the chip, else just enough ranges for ~2 workgroups / CU
     const int col_groups = cdiv(N, 64), slices = K / 256;
     int ranges = 1;
-    if (col_groups < 448) ranges = min(slices, cdiv(512, col_groups));
+    static const int target_blocks = getenv("SPACER_SKINNY_BLOCKS") ? atoi(getenv("SPACER_SKINNY_BLOCKS")) : 512;
+    if (col_groups < 448) ranges = min(slices, cdiv(target_blocks, col_groups));
     const int spr = cdiv(slices, ranges);
     ranges = cdiv(slices, spr);
     const int mflush = getenv("SPACER_PROBE_NOFLUSH") ? 0 : M;
@@ -501,10 +626,10 @@ extern "C" int spacer_swiglu_f32_fwd(float* acc32, void* y, int B, int inter, sp
     return SPACER_OK;
 }
 
-extern "C" int spacer_attn_decode(const void* q, const void* prefix_k, const void* prefix_v, const int* prefix_len,
-                                  const int* prompt_of, const void* tail_k, const void* tail_v, const int* tail_len_dev,
-                                  void* o, int B, int Pmax, int Cmax, int Hq, int Hkv, int D, float scale,
-                                  spacer_stream_t stream) {
+static int launch_attn_decode(const void* q, const void* prefix_k, const void* prefix_v, const int* prefix_len,
+                              const int* prompt_of, const void* tail_k, const void* tail_v, const int* tail_len_dev,
+                              void* o, float* pre_ws, int Kn, int B, int Pmax, int Cmax, int Hq, int Hkv, int D, float scale,
+                              spacer_stream_t stream) {
     SP_REQUIRE(D == 128, SPACER_EINVAL, "attn_decode: head_dim %d unsupported (128)", D);
     SP_REQUIRE(Hkv > 0 && Hq % Hkv == 0, SPACER_EINVAL, "attn_decode: bad head counts");
     if (B <= 0) return SPACER_OK;
@@ -517,9 +642,26 @@ extern "C" int spacer_attn_decode(const void* q, const void* prefix_k, const voi
                            (const bf16_t*)prefix_k, (const bf16_t*)prefix_v, prefix_len, prompt_of, (const bf16_t*)tail_k, \
                            (const bf16_t*)tail_v, tail_len_dev, (bf16_t*)o, Pmax, Cmax, Hq, Hkv, scale);              \
     else                                                                                                               \
-        hipLaunchKernelGGL((attn_decode_mfma_kernel<R>), dim3(B, Hkv), dim3(256), 0, s, (const bf16_t*)q,              \
+    {                                                                                                              \
+        static const int once = hipFuncSetAttribute((const void*)attn_decode_mfma_kernel<R, 8>,                        \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 8 * AT_T_BYTES(128));  \
+        (void)once;                                                                                                    \
+        hipLaunchKernelGGL((attn_decode_mfma_kernel<R, 8>), dim3(B, Hkv), dim3(512), 8 * AT_T_BYTES(128), s, (const bf16_t*)q, \
                            (const bf16_t*)prefix_k, (const bf16_t*)prefix_v, prefix_len, prompt_of, (const bf16_t*)tail_k, \
-                           (const bf16_t*)tail_v, tail_len_dev, (bf16_t*)o, Pmax, Cmax, Hq, Hkv, scale)
+                           (const bf16_t*)tail_v, tail_len_dev, (bf16_t*)o, Pmax, Cmax, Hq, Hkv, scale, pre_ws, Kn); \
+    }
+    if (pre_ws) {
+        SP_REQUIRE(Kn > 0 && Kn * rep <= 64 && B % Kn == 0, SPACER_EINVAL, "attn_decode_shared: Kn*rep=%d must be <= 64", Kn * rep);
+#define LAUNCH_PRE(R)                                                                                                   \
+        hipLaunchKernelGGL((attn_decode_prefix_kernel<R>), dim3(B / Kn, Hkv, PRE_SPLITS), dim3(256), 0, s, (const bf16_t*)q, \
+                           (const bf16_t*)prefix_k, (const bf16_t*)prefix_v, prefix_len, pre_ws, Kn, Pmax, Hq, Hkv, scale)
+        switch (rep) {
+            case 1: LAUNCH_PRE(1); break; case 2: LAUNCH_PRE(2); break; case 3: LAUNCH_PRE(3); break; case 4: LAUNCH_PRE(4); break;
+            case 5: LAUNCH_PRE(5); break; case 6: LAUNCH_PRE(6); break; case 7: LAUNCH_PRE(7); break; case 8: LAUNCH_PRE(8); break;
+            default: SP_REQUIRE(false, SPACER_EINVAL, "attn_decode: GQA ratio %d not instantiated", rep);
+        }
+#undef LAUNCH_PRE
+    }
     switch (rep) {
         case 1: LAUNCH(1); break;
         case 2: LAUNCH(2); break;
@@ -534,4 +676,25 @@ extern "C" int spacer_attn_decode(const void* q, const void* prefix_k, const voi
 #undef LAUNCH
     SP_CHECK_LAUNCH();
     return SPACER_OK;
+}
+
+extern "C" int spacer_attn_decode(const void* q, const void* prefix_k, const void* prefix_v, const int* prefix_len,
+                                  const int* prompt_of, const void* tail_k, const void* tail_v, const int* tail_len_dev,
+                                  void* o, int B, int Pmax, int Cmax, int Hq, int Hkv, int D, float scale,
+                                  spacer_stream_t stream) {
+    return launch_attn_decode(q, prefix_k, prefix_v, prefix_len, prompt_of, tail_k, tail_v, tail_len_dev, o, nullptr, 0, B, Pmax,
+                              Cmax, Hq, Hkv, D, scale, stream);
+}
+
+extern "C" long spacer_attn_decode_workspace_bytes(int n_prompts, int Hkv) {
+    return (long)n_prompts * Hkv * PRE_SPLITS * 64 * (128 + 2) * (long)sizeof(float);
+}
+
+extern "C" int spacer_attn_decode_shared(const void* q, const void* prefix_k, const void* prefix_v, const int* prefix_len,
+                                         const int* prompt_of, const void* tail_k, const void* tail_v,
+                                         const int* tail_len_dev, void* o, void* workspace, int B, int Kn, int Pmax, int Cmax,
+                                         int Hq, int Hkv, int D, float scale, spacer_stream_t stream) {
+    SP_REQUIRE(workspace != nullptr, SPACER_EINVAL, "attn_decode_shared: workspace required");
+    return launch_attn_decode(q, prefix_k, prefix_v, prefix_len, prompt_of, tail_k, tail_v, tail_len_dev, o, (float*)workspace, Kn,
+                              B, Pmax, Cmax, Hq, Hkv, D, scale, stream);
 }

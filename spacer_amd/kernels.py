@@ -234,6 +234,22 @@ def attn_decode(q, prefix_k, prefix_v, prefix_len, prompt_of, tail_k, tail_v, ta
     return out
 
 
+def attn_decode_shared(q, prefix_k, prefix_v, prefix_len, prompt_of, tail_k, tail_v, tail_len_dev, Kn, Hq, Hkv, D, scale, *,
+                       out=None, workspace=None):
+    """attn_decode with the prompt keys scored once per prompt for its Kn rollouts (rows b = prompt*Kn + k)."""
+    B = q.shape[0]
+    if out is None:
+        out = torch.empty(B, Hq * D, device=q.device, dtype=BF16)
+    if workspace is None:
+        workspace = torch.empty(_lib.load().spacer_attn_decode_workspace_bytes(prefix_k.shape[0], Hkv) // 4, device=q.device,
+                                dtype=torch.float32)
+    check(_lib.load().spacer_attn_decode_shared(_ptr(q), _ptr(prefix_k), _ptr(prefix_v), _ptr(prefix_len), _ptr(prompt_of),
+                                                _ptr(tail_k), _ptr(tail_v), _ptr(tail_len_dev), _ptr(out), _ptr(workspace), B, Kn,
+                                                prefix_k.shape[1], tail_k.shape[1], Hq, Hkv, D, scale, _stream()),
+          "attn_decode_shared")
+    return out
+
+
 # ----------------------------------------------------------------------------------------- element-wise
 def swiglu_fwd(gu, *, out=None):
     rows, two_i = gu.shape

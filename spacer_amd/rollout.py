@@ -108,8 +108,12 @@ class RolloutEngine:
             K.gemm_skinny_packed_acc(h, PW[p + "qkv_w"], st["acc_qkv"], cfg.qkv_dim)
             K.decode_qkv_finish(st["acc_qkv"], W[p + "qkv_b"], st["cos"], st["sin"], st["q"], st["tk"][i], st["tv"][i],
                                 st["tail_len"], Hq, Hkv, D)
-            o = K.attn_decode(st["q"], st["pk"][i], st["pv"][i], st["plen"], st["prompt_of"], st["tk"][i], st["tv"][i],
-                              st["tail_len"], Hq, Hkv, D, scale, out=st["o"])
+            if st["shared_prefix"]:      # prompt keys scored once per prompt for its K rollouts
+                o = K.attn_decode_shared(st["q"], st["pk"][i], st["pv"][i], st["plen"], st["prompt_of"], st["tk"][i], st["tv"][i],
+                                         st["tail_len"], st["Kn"], Hq, Hkv, D, scale, out=st["o"], workspace=st["attn_ws"])
+            else:
+                o = K.attn_decode(st["q"], st["pk"][i], st["pv"][i], st["plen"], st["prompt_of"], st["tk"][i], st["tv"][i],
+                                  st["tail_len"], Hq, Hkv, D, scale, out=st["o"])
             K.gemm_skinny_packed_acc(o, PW[p + "o_w"], x, cfg.hidden)
             h2 = K.rmsnorm_fwd(x, W[p + "ln2_w"], cfg.rms_eps, out=st["h"])
             K.gemm_skinny_packed_acc(h2, PW[p + "gu_w"], st["acc_gu"], 2 * I)
@@ -143,7 +147,8 @@ class RolloutEngine:
         pk, pv, first_logits, plen, pos_base = self._prefill(prompts, sp.era_rule)
         L, Hkv, D, H = cfg.layers, cfg.kv_heads, cfg.head_dim, cfg.hidden
         st = dict(
-            B=B, pk=pk, pv=pv, packed=self._pack(),
+            B=B, pk=pk, pv=pv, packed=self._pack(), Kn=Kn, shared_prefix=Kn * (cfg.heads // cfg.kv_heads) <= 64 and Kn > 1,
+            attn_ws=torch.empty(nP * cfg.kv_heads * 8 * 64 * (cfg.head_dim + 2), device=dev, dtype=F32),
             plen=torch.tensor(plen, dtype=torch.int32, device=dev),
             prompt_of=torch.arange(B, dtype=torch.int32, device=dev) // Kn,
             pos_base=torch.tensor(pos_base, dtype=torch.int32, device=dev).repeat_interleave(Kn).contiguous(),

@@ -250,6 +250,27 @@ def test_attention_decode(dev):
             assert_close(o[b], want, 2e-2, 2e-2, f"decode attn b={b} tl={tl}")
 
 
+def test_attention_decode_shared_prefix(dev):
+    """Prompt keys scored once per prompt for its Kn rollouts + per-rollout tail == the per-sequence kernel."""
+    D, Hq, Hkv, Kn, nP, Pmax, Cmax = 128, 14, 2, 4, 3, 150, 24
+    B = nP * Kn
+    q = rnd((B, Hq * D), dev, 1, 0.7)
+    pk, pv = rnd((nP, Pmax, Hkv, D), dev, 2, 0.7), rnd((nP, Pmax, Hkv, D), dev, 3, 0.7)
+    tk, tv = rnd((B, Cmax, Hkv, D), dev, 4, 0.7), rnd((B, Cmax, Hkv, D), dev, 5, 0.7)
+    plen = torch.tensor([150, 64, 7], dtype=torch.int32, device=dev)
+    pof = (torch.arange(B, device=dev) // Kn).int()
+    for tl in (0, 5, 23):
+        tld = torch.tensor([tl], dtype=torch.int32, device=dev)
+        o = K.attn_decode_shared(q, pk, pv, plen, pof, tk, tv, tld, Kn, Hq, Hkv, D, D ** -0.5)
+        for b in range(B):
+            P = int(plen[pof[b]])
+            kk = torch.cat([pk[pof[b], :P], tk[b, :tl + 1]]).float().repeat_interleave(Hq // Hkv, 1)
+            vv = torch.cat([pv[pof[b], :P], tv[b, :tl + 1]]).float().repeat_interleave(Hq // Hkv, 1)
+            s = torch.einsum("hd,lhd->hl", q[b].float().view(Hq, D), kk) * D ** -0.5
+            want = torch.einsum("hl,lhd->hd", torch.softmax(s, -1), vv).reshape(-1)
+            assert_close(o[b], want, 2e-2, 2e-2, f"shared decode attn b={b} tl={tl}")
+
+
 # ----------------------------------------------------------------------------------------------- element-wise
 def test_swiglu_act_bias_cast(dev):
     rows, I = 50, 512
