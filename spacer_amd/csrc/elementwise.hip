@@ -260,20 +260,56 @@ __global__ __launch_bounds__(NT) void scatter_add_rows_kernel(const bf16_t* __re
 }
 
 // ------------------------------------------------------------------ transpose with zero padding
-// out[c, r] = in[r, c] for r < R, 0 for R <= r < Rpad.   64x64 tiles through LDS.
+// out[c, r] = in[r, c] for r < R, 0 for R <= r < Rpad.  64x64 tiles: 16-byte global loads, 2-byte transposed LDS
+// writes, 16-byte LDS reads and 16-byte coalesced global stores (rows of 8 source rows per store).
 __global__ __launch_bounds__(NT) void transpose_kernel(const bf16_t* __restrict__ in, long ld_in,
                                                        bf16_t* __restrict__ out, long ld_out, int R, int C, int Rpad) {
-    __shared__ bf16_t tile[64][66];
+    constexpr int ROW = 64 + 8;                          // bf16 per LDS row (144 B: keeps 16-byte alignment, skews banks)
+    __shared__ __attribute__((aligned(16))) bf16_t tile[64 * ROW];   // tile[c][r]
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
-    for (int j = ty; j < 64; j += 4) {
-        const int r = r0 + j, c = c0 + tx;
-        tile[j][tx] = (r < R && c < C) ? in[(long)r * ld_in + c] : (bf16_t)0;
-    }
-    __syncthreads();
-    for (int j = ty; j < 64; j += 4) {
-        const int c = c0 + j, r = r0 + tx;
-        if (c < C && r < Rpad) out[(long)c * ld_out + r] = tile[tx][j];
+    const int t = threadIdx.x;
+    const bool fast = (ld_in % 8 == 0) && (ld_out % 8 == 0) && (((uintptr_t)in | (uintptr_t)out) % 16 == 0);
+    if (fast) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = (t >> 3) + 32 * j, cc = (t & 7) * 8;       // 8 lanes cover one 128-byte source row segment
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (r0 + r < R) {
+                if (c0 + cc + 8 <= C) v = *(const uint4*)(in + (long)(r0 + r) * ld_in + c0 + cc);
+                else {
+                    bf16_t tmp[8];
+                    for (int e = 0; e < 8; ++e) tmp[e] = (c0 + cc + e < C) ? in[(long)(r0 + r) * ld_in + c0 + cc + e] : (bf16_t)0;
+                    v = *(const uint4*)tmp;
+                }
+            }
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) tile[(cc + e) * ROW + r] = (bf16_t)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = (t >> 3) + 32 * j, rr = (t & 7) * 8;
+            if (c0 + c < C && r0 + rr < Rpad) {
+                const uint4 v = *(const uint4*)(tile + c * ROW + rr);
+                if (r0 + rr + 8 <= Rpad) *(uint4*)(out + (long)(c0 + c) * ld_out + r0 + rr) = v;
+                else {
+                    const bf16_t* pv = (const bf16_t*)&v;
+                    for (int e = 0; e < 8 && r0 + rr + e < Rpad; ++e) out[(long)(c0 + c) * ld_out + r0 + rr + e] = pv[e];
+                }
+            }
+        }
+    } else {
+        const int tx = t & 63, ty = t >> 6;
+        for (int j = ty; j < 64; j += 4) {
+            const int r = r0 + j, c = c0 + tx;
+            tile[tx * ROW + j] = (r < R && c < C) ? in[(long)r * ld_in + c] : (bf16_t)0;
+        }
+        __syncthreads();
+        for (int j = ty; j < 64; j += 4) {
+            const int c = c0 + j, r = r0 + tx;
+            if (c < C && r < Rpad) out[(long)c * ld_out + r] = tile[j * ROW + tx];
+        }
     }
 }
 
