@@ -11,7 +11,7 @@ scoring -> GRPO loss -> backward through lm_head / LLM / ViT -> gradient all-red
 Nothing is skipped or cached inside the timed region.  Weak scaling: every rank runs the same number of groups.
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task statement) with two extra objects:
-  roofline      bf16 MFMA roofline of the dominant kernel (gemm_bf16_nt_kernel), measured live with HIP events on
+  roofline      bf16 MFMA roofline of the dominant kernel (gemm_bf16_nt_256h_kernel), measured live with HIP events on
                 the launch stream over the timed region: sum(2*M*N*K) / sum(duration)
   cpu_baseline  the fp32 oracle (oracle/qwen2vl_fp32.py, kind "port") timed on the host cores on a bounded sample
 """
@@ -181,7 +181,7 @@ def main():
     if rank == 0:
         samples = groups * Kgen * world * args.steps
         value = samples / elapsed
-        gemm = prof.get("gemm_bf16_nt_kernel", dict(tflops=0.0, launches=0, seconds=0.0, flops=0.0))
+        gemm = prof.get("gemm_bf16_nt_256h_kernel", dict(tflops=0.0, launches=0, seconds=0.0, flops=0.0, bytes=0.0))
         out = {
             "metric": "GRPO samples/sec (K=8 rollouts) Qwen2-VL-7B 16-frame" if args.workload in ("cfg3", "cfg4")
             else f"GRPO samples/sec ({args.workload})",
@@ -192,7 +192,7 @@ def main():
                                    f"K={Kgen}, C={C} (EOS suppressed), {groups} prompt groups/GPU, full step "
                                    f"(rollout+ref/policy scoring+backward+AdamW)",
                        "global_batch": groups * Kgen * world, "parallelism": f"dp{world}", "decode_graph": not args.no_graph},
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_kernel", "achieved": round(gemm["tflops"], 2),
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_256h_kernel", "achieved": round(gemm["tflops"], 2),
                          "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gemm["tflops"] / MFMA_PEAK_TFLOPS, 4),
                          "traffic": pmc_traffic(args.workload), "launches": gemm["launches"],
                          "algorithmic_bytes_per_launch": round(gemm["bytes"] / max(1, gemm["launches"])),

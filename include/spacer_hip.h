@@ -54,6 +54,10 @@ typedef struct spacer_gemm_epilogue {
 int spacer_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
                         const spacer_gemm_epilogue* epi, spacer_stream_t stream);
 
+/* Which tile spacer_gemm_bf16_nt runs an [M,N] problem on: 256 (gemm_bf16_nt_256h_kernel) or 128 (gemm_bf16_nt_kernel).
+ * Pure host function; profilers use it to attribute a launch to the kernel rocprof will name. */
+int spacer_gemm_tile(int M, int N);
+
 /* Skinny GEMM for the decode loop (M <= 64 rows, weights streamed once from HBM, split-K):
  * C32[M,N] += A[M,K] . B[N,K]^T  (fp32 atomics; C may be the fp32 residual stream itself).  K % 256 == 0.
  * epi must be NULL or {out_f32 = 1, residual = C}.  Replaces the per-token projections inside HF

@@ -13,7 +13,7 @@ from gemm_step_shapes import SHAPES  # noqa: E402
 def per_dispatch(db, counter):
     cur = sqlite3.connect(db).cursor()
     rows = list(cur.execute("select dispatch_id, value from counters_collection where counter_name = ? and kernel_name like "
-                            "'%gemm_bf16_nt_kernel%' order by dispatch_id", (counter,)))
+                            "'%gemm_bf16_nt_%' order by dispatch_id", (counter,)))
     return [v for _, v in rows]
 
 

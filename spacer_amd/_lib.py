@@ -70,7 +70,7 @@ SIGNATURES = {
     "spacer_sumsq_f32": [_p, _l, _p, _p],
     "spacer_adamw_step": [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _f, _p, _f, _f, _p],
 }
-OTHER_SYMBOLS = ["spacer_last_error", "spacer_version", "spacer_sample_workspace_bytes", "spacer_attn_decode_workspace_bytes"]
+OTHER_SYMBOLS = ["spacer_last_error", "spacer_version", "spacer_sample_workspace_bytes", "spacer_attn_decode_workspace_bytes", "spacer_gemm_tile"]
 
 _lib = None
 
@@ -93,6 +93,8 @@ def load() -> C.CDLL:
     lib.spacer_version.restype = C.c_int
     lib.spacer_sample_workspace_bytes.argtypes = [_i, _i]
     lib.spacer_sample_workspace_bytes.restype = C.c_long
+    lib.spacer_gemm_tile.argtypes = [_i, _i]
+    lib.spacer_gemm_tile.restype = _i
     lib.spacer_attn_decode_workspace_bytes.argtypes = [_i, _i]
     lib.spacer_attn_decode_workspace_bytes.restype = C.c_long
     _lib = lib

@@ -5,11 +5,12 @@
 // transpose kernel (dX = dY . (W^T)^T, dW = dY^T . (X^T)^T).
 //
 // Design (MI355X_MICROARCH / cdna_hip_programming T1/T2/T3):
-//   * one kernel template, two tile shapes picked by problem size:
-//       128x128x64  : 4 waves as 2x2, wave = 64x64  (4x4 MFMA 16x16x32 frags), 64 KiB LDS, 2 workgroups / CU
-//       256x256x64  : 8 waves as 2x4, wave = 128x64 (8x4 frags),               128 KiB LDS, 1 workgroup / CU
-//   * A/B tiles go HBM -> LDS directly with global_load_lds_dwordx4 (1 KiB per wave-instruction), double-buffered:
-//     loads of tile t+1 are issued before the MFMAs of tile t, one barrier per tile
+//   * two kernels picked by problem size (spacer_gemm_tile):
+//       gemm_bf16_nt_kernel       128x128x64, 4 waves as 2x2, wave = 64x64 (4x4 MFMA 16x16x32 frags), 64 KiB LDS,
+//                                 2 workgroups / CU; double-buffered K tiles, one barrier per tile
+//       gemm_bf16_nt_256h_kernel  256x256x64, 8 waves as 2x4, wave = 128x64 (8x4 frags), 128 KiB LDS, 1 workgroup / CU;
+//                                 half-tile DMA pipeline that never drains (gemm_halftile.h)
+//   * A/B tiles go HBM -> LDS directly with global_load_lds_dwordx4 (1 KiB per wave-instruction)
 //   * LDS image is lane-linear (DMA constraint); the bank-conflict XOR swizzle is applied on the per-lane
 //     SOURCE address and again on the ds_read_b128 address (16-byte chunk ^= (row>>1)&7)
 //   * MFMA is issued with swapped operands (D^T = B.A^T) so each lane owns 4 consecutive N of one row:
@@ -191,129 +192,22 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N == 4) ? 2
             store_frag(e, m0 + wm + i * 16 + (lane & 15), n0 + wn + j * 16 + (lane >> 4) * 4, acc[i][j]);
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// 256x256x64, 8 waves (2x4, wave = 128x64), PHASED schedule (cdna_hip_programming T3/T4/T5 adapted):
-//   * each K tile is consumed in 4 phases of 16 MFMAs (one 64x32 quadrant of the wave tile x both k-steps); a phase
-//     is a LOAD segment (ds_read the quadrant's fragments + issue a share of the next tile's global->LDS DMA) and a
-//     COMPUTE segment (the MFMAs), separated by raw s_barriers
-//   * the two wave rows (wr = 0 / 1) run ONE SEGMENT APART: the two waves that share a SIMD alternate roles, so the
-//     matrix pipe is fed by one while the other waits on LDS / issues DMA (s_setprio favours the computing wave)
-//   * the next tile's DMA is issued in phases 0-2 (3+3+2 instructions per wave) and waited for at the end of phase 3's
-//     load segment: every DMA has >= 2 segments to land, and its LDS slot was released a full tile earlier
-template <int DUMMY>
-__global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256p_kernel(GemmArgs g) {
-    constexpr int BM = 256, BN = 256;
-    constexpr bool STAGGER = (DUMMY & 1) == 0, PRIO = (DUMMY & 2) == 0;
-    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A | B]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-
-    const int nwg = g.tiles_m * g.tiles_n;
-    int pid;
-    {
-        const int b = blockIdx.x, x = b & 7, q = nwg >> 3, r = nwg & 7;
-        pid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
-    }
-    constexpr int GM = 4;
-    const int per_group = GM * g.tiles_n;
-    const int group = pid / per_group, first_m = group * GM;
-    const int gsz = min(g.tiles_m - first_m, GM);
-    const int tm = first_m + (pid % per_group) % gsz;
-    const int tn = (pid % per_group) / gsz;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int wm = wr * 128, wn = wc * 64;
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // DMA share of this wave: instructions q = wave*8 + i of the combined [A (32 x 1 KiB) | B (32 x 1 KiB)] tile image
-    auto dma = [&](char* slot, int k0, int i) {
-        const int q = wave * 8 + i;
-        const bool isA = q < 32;
-        const int inst = isA ? q : q - 32;
-        const int row = inst * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        int gr = (isA ? m0 : n0) + row;
-        const int rmax = isA ? g.M : g.N;
-        gr = gr < rmax ? gr : rmax - 1;
-        const bf16_t* src = (isA ? g.A + (long)gr * g.lda : g.B + (long)gr * g.ldb) + k0 + chunk * 8;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(slot + (isA ? 0 : A_BYTES) + inst * 1024), 16, 0, 0);
-    };
-
-    const int nt = g.K / BK;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) dma(smem, 0, i);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (STAGGER && wr == 1) __builtin_amdgcn_s_barrier();          // stagger: wave row 1 runs one segment behind wave row 0
-
-    bf16x8 a[4][2], b[2][2];
-    for (int t = 0; t < nt; ++t) {
-        const char* cur = smem + (t & 1) * STAGE;
-        char* nxt = smem + ((t + 1) & 1) * STAGE;
-        const bool more = t + 1 < nt;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int mq = p >> 1, nq = (p == 1 || p == 2) ? 1 : 0;       // quadrants (0,0) (0,1) (1,1) (1,0)
-            // ---------------- load segment
-            if (p == 0 || p == 2) {
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        a[i][kk] = lds_frag(cur, wm + (mq * 4 + i) * 16 + (lane & 15), kk * 4 + (lane >> 4));
-            }
-            if (p != 2) {
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        b[j][kk] = lds_frag(cur + A_BYTES, wn + (nq * 2 + j) * 16 + (lane & 15), kk * 4 + (lane >> 4));
-            }
-            if (more) {
-                if (p == 0) { dma(nxt, (t + 1) * BK, 0); dma(nxt, (t + 1) * BK, 1); dma(nxt, (t + 1) * BK, 2); }
-                if (p == 1) { dma(nxt, (t + 1) * BK, 3); dma(nxt, (t + 1) * BK, 4); dma(nxt, (t + 1) * BK, 5); }
-                if (p == 2) { dma(nxt, (t + 1) * BK, 6); dma(nxt, (t + 1) * BK, 7); }
-            }
-            if (p == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            // ---------------- compute segment
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            if (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[mq * 4 + i][nq * 2 + j] =
-                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][kk], a[i][kk], acc[mq * 4 + i][nq * 2 + j], 0, 0, 0);
-            if (PRIO) __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    if (STAGGER && wr == 0) __builtin_amdgcn_s_barrier();
-
-    const EpiArgs e = {g.C, g.bias, g.resid, g.ldc, g.ldr, g.M, g.N, g.out_f32, g.act, g.alpha};
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            store_frag(e, m0 + wm + i * 16 + (lane & 15), n0 + wn + j * 16 + (lane >> 4) * 4, acc[i][j]);
-}
+#include "gemm_halftile.h"
 
 }  // namespace
+
+// Tile choice, wave-quantisation aware: the 256x256 half-tile pipeline is ~25 % faster per tile-FLOP but runs one
+// workgroup per CU (256 slots) against two for the 128x128 tile (512 slots); pick the better efficiency x speed.
+// SPACER_GEMM_TILE=128|256 forces one of them (tests run every shape through both).
+extern "C" int spacer_gemm_tile(int M, int N) {
+    static const char* force = getenv("SPACER_GEMM_TILE");
+    if (force) return atoi(force) >= 256 ? 256 : 128;
+    const long tiles256 = (long)cdiv(M, 256) * cdiv(N, 256);
+    const long tiles128 = (long)cdiv(M, 128) * cdiv(N, 128);
+    const double eff256 = (double)tiles256 / (double)(cdiv(tiles256, 256) * 256L);
+    const double eff128 = (double)tiles128 / (double)(cdiv(tiles128, 512) * 512L);
+    return 1.25 * eff256 > eff128 ? 256 : 128;
+}
 
 extern "C" int spacer_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M,
                                    int N, int K, const spacer_gemm_epilogue* epi, spacer_stream_t stream) {
@@ -334,37 +228,15 @@ extern "C" int spacer_gemm_bf16_nt(const void* A, long lda, const void* B, long 
     if (epi && epi->alpha == 0.f) g.alpha = 1.f;
     const int esz = g.out_f32 ? 4 : 2;
     SP_REQUIRE(((uintptr_t)C % (4 * esz)) == 0, SPACER_EINVAL, "gemm: C misaligned");
-    // tile choice: the 256x256 tile needs enough tiles to fill 256 CUs at one workgroup per CU
-    static const char* force = getenv("SPACER_GEMM_TILE");
-    const long tiles256 = (long)cdiv(M, 256) * cdiv(N, 256);
-    // wave-quantisation aware choice: the 256 tile is ~15 % faster per tile-FLOP but runs one workgroup per CU
-    // (256 slots) against two for the 128 tile (512 slots); pick the better (efficiency x speed) product
-    const long tiles128 = (long)cdiv(M, 128) * cdiv(N, 128);
-    const double eff256 = (double)tiles256 / (double)(cdiv(tiles256, 256) * 256L);
-    const double eff128 = (double)tiles128 / (double)(cdiv(tiles128, 512) * 512L);
-    bool big = 1.15 * eff256 > eff128;
-    if (force) big = atoi(force) == 256;
+    const bool big = spacer_gemm_tile(M, N) == 256;
     hipStream_t s = (hipStream_t)stream;
-    if (force && atoi(force) >= 257 && atoi(force) <= 260) {
-        constexpr int LDS = 2 * (256 * BK * 2 + 256 * BK * 2);
-        g.tiles_m = cdiv(M, 256); g.tiles_n = cdiv(N, 256);
-        const int var = atoi(force) - 257;
-#define LAUNCH_P(V)                                                                                                     \
-        do {                                                                                                            \
-            static const int o = hipFuncSetAttribute((const void*)gemm_bf16_nt_256p_kernel<V>,                          \
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS);                  \
-            (void)o;                                                                                                    \
-            hipLaunchKernelGGL((gemm_bf16_nt_256p_kernel<V>), dim3(g.tiles_m * g.tiles_n), dim3(512), LDS, s, g);        \
-        } while (0)
-        if (var == 0) LAUNCH_P(0); else if (var == 1) LAUNCH_P(1); else if (var == 2) LAUNCH_P(2); else LAUNCH_P(3);
-#undef LAUNCH_P
-    } else if (big) {
-        constexpr int LDS = 2 * (256 * BK * 2 + 256 * BK * 2);
-        static const int once = hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<2, 4, 8, 4>,
+    if (big) {
+        constexpr int LDS = 8 * 128 * BK * 2;
+        static const int once = hipFuncSetAttribute((const void*)gemm_bf16_nt_256h_kernel<true>,
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         (void)once;
         g.tiles_m = cdiv(M, 256); g.tiles_n = cdiv(N, 256);
-        hipLaunchKernelGGL((gemm_bf16_nt_kernel<2, 4, 8, 4>), dim3(g.tiles_m * g.tiles_n), dim3(512), LDS, s, g);
+        hipLaunchKernelGGL((gemm_bf16_nt_256h_kernel<true>), dim3(g.tiles_m * g.tiles_n), dim3(512), LDS, s, g);
     } else {
         constexpr int LDS = 2 * (128 * BK * 2 + 128 * BK * 2);
         g.tiles_m = cdiv(M, 128); g.tiles_n = cdiv(N, 128);

@@ -1,0 +1,187 @@
+// 256x256x64 bf16 NT GEMM tile, 8 waves (2x4, wave = 128x64), HALF-TILE PIPELINE.
+// Included by gemm.hip inside its anonymous namespace (uses GemmArgs / EpiArgs / store_frag / BK).
+//
+// Why a second schedule: the simple tile loop (gemm_bf16_nt_kernel) drains its global->LDS DMA queue (vmcnt(0)) at the
+// barrier that ends every K tile, so each tile pays the tail of its own prefetch.  Here the DMA queue never drains:
+//
+//   * LDS holds 2 parities x 4 half-tile images {A-lo, A-hi, B-lo, B-hi} of 16 KiB (128 rows x 64 k).  "A half h" is
+//     the 64-row quadrant h of BOTH wave rows, "B half h" the 32-column quadrant h of all four wave columns, so one
+//     C quadrant (mq, nq) of every wave needs exactly A[mq] and B[nq].
+//   * a K tile is consumed in 4 phases = the 4 C quadrants in the order (0,0) (0,1) (1,1) (1,0); the A fragments stay in
+//     registers for two phases, the B-lo fragments for the whole tile, so the images are read at phases
+//         A-lo: 0    B-lo: 0    B-hi: 1    A-hi: 2    (phase 3 reads nothing)
+//   * every phase stages ONE half-tile (2 x 1 KiB DMA per wave) of a later tile into an image last read >= 2 phases ago:
+//         phase 0: B-hi(t+1)   phase 1: A-hi(t+1)   phase 2: A-lo(t+2)   phase 3: B-lo(t+2)
+//     and then waits with a COUNTED vmcnt(8): 4 half-tiles (64 KiB per CU) stay in flight, each has 4 phases
+//     (~2000 cycles) to land, and the half-tile a phase waits for is read one phase later (the barrier between
+//     publishes it to the other waves).
+//   * a phase is [ds_read fragments | issue DMA | vmcnt(8)] s_barrier [lgkmcnt(0) | 16 MFMA] s_barrier.  The two wave
+//     rows run one barrier apart (row 1 takes one extra barrier up front, row 0 one at the end): the two waves sharing a
+//     SIMD alternate between the LDS segment and the MFMA segment, so the matrix pipe always has a wave feeding it.
+//   * K tiles past the end are staged from the last real tile (redundant, never read) so the in-flight count is the
+//     same in every phase; the queue is drained once, before the epilogue.
+#include <type_traits>
+
+template <bool BALANCED>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
+    constexpr int BM = 256, BN = 256;
+    constexpr int HALF = 128 * BK * 2;                 // one half-tile image
+    enum { A_LO = 0, A_HI = 1, B_LO = 2, B_HI = 3 };
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [parity][A_LO, A_HI, B_LO, B_HI][HALF]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int nwg = g.tiles_m * g.tiles_n;
+    int pid;
+    {
+        const int b = blockIdx.x, x = b & 7, q = nwg >> 3, r = nwg & 7;
+        pid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+    }
+    constexpr int GM = 4;
+    const int per_group = GM * g.tiles_n;
+    const int group = pid / per_group, first_m = group * GM;
+    const int gsz = min(g.tiles_m - first_m, GM);
+    const int tm = first_m + (pid % per_group) % gsz;
+    const int tn = (pid % per_group) / gsz;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- DMA sources: this wave owns pieces (wave*2 + i), i = 0..1, of every half-tile image (8 rows x 128 B each)
+    unsigned offA[2][2], offB[2][2];                   // [half][piece] element offsets of this lane's 16-byte chunk
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int hr = (wave * 2 + i) * 8 + (lane >> 3);                 // image row
+            const int chunk = (lane & 7) ^ ((hr >> 1) & 7);                  // logical 16-B chunk this lane fetches
+            int ra = m0 + (hr >> 6) * 128 + h * 64 + (hr & 63);
+            int rb = n0 + (hr >> 5) * 64 + h * 32 + (hr & 31);
+            ra = ra < g.M ? ra : g.M - 1;
+            rb = rb < g.N ? rb : g.N - 1;
+            offA[h][i] = (unsigned)((long)ra * g.lda + chunk * 8);
+            offB[h][i] = (unsigned)((long)rb * g.ldb + chunk * 8);
+        }
+    const int nt = g.K / BK;
+    auto stage = [&](int par, int which, int t) {
+        const int k0 = (t < nt ? t : nt - 1) * BK;
+        char* dst = smem + (par * 4 + which) * HALF + wave * 2048;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bf16_t* src = (which < 2) ? g.A + offA[which & 1][i] + k0 : g.B + offB[which & 1][i] + k0;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment read offsets: row (lane&15) of a 16-row fragment, chunk (kk*4 + lane>>4) ^ swizzle(row)
+    const int fsw = (lane & 15) >> 1;                                        // (row >> 1) & 7 for every fragment row
+    const int fo0 = (lane & 15) * 128 + (((lane >> 4) ^ fsw) << 4);          // kk = 0
+    const int fo1 = fo0 ^ 64;                                                // kk = 1: chunk + 4
+    const int aoff = wr * 64 * 128, boff = wc * 32 * 128;
+    auto fragA = [&](const char* img, int i, int kk) { return *(const bf16x8*)(img + aoff + i * 2048 + (kk ? fo1 : fo0)); };
+    auto fragB = [&](const char* img, int j, int kk) { return *(const bf16x8*)(img + boff + j * 2048 + (kk ? fo1 : fo0)); };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue: tile 0 complete + the first two halves of tile 1, in steady-state issue order
+    stage(0, A_LO, 0); stage(0, B_LO, 0); stage(0, B_HI, 0); stage(0, A_HI, 0);
+    stage(1, A_LO, 1); stage(1, B_LO, 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                         // A-lo(0), B-lo(0) landed
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    bf16x8 a[4][2], bhi[2][2], blo_even[2][2], blo_odd[2][2];
+    if (BALANCED) {                                                          // tile 0's B-lo fragments
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) blo_even[j][kk] = fragB(smem + B_LO * HALF, j, kk);
+    }
+    if (wr == 1) __builtin_amdgcn_s_barrier();                               // wave row 1 runs one barrier behind
+
+    auto tile = [&](auto PAR, const int t, bf16x8 (&blo)[2][2], bf16x8 (&blo_next)[2][2]) {
+        constexpr int par = decltype(PAR)::value;
+        const char* img = smem + par * 4 * HALF;
+        const char* img_next = smem + (par ^ 1) * 4 * HALF;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            // ------------------------------------------------ LDS segment
+            if (p == 0) {
+                if (!BALANCED) {
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) blo[j][kk] = fragB(img + B_LO * HALF, j, kk);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a[i][kk] = fragA(img + A_LO * HALF, i, kk);
+            } else if (p == 1) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) bhi[j][kk] = fragB(img + B_HI * HALF, j, kk);
+            } else if (p == 2) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a[i][kk] = fragA(img + A_HI * HALF, i, kk);
+            } else if (BALANCED) {                                           // next tile's B-lo (waited for in phase 2)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) blo_next[j][kk] = fragB(img_next + B_LO * HALF, j, kk);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (p == 0) stage(par ^ 1, B_HI, t + 1);
+            if (p == 1) stage(par ^ 1, A_HI, t + 1);
+            if (p == 2) stage(par, A_LO, t + 2);
+            if (p == 3) stage(par, B_LO, t + 2);
+            if (BALANCED) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ------------------------------------------------ MFMA segment: C quadrant (mq, nq)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            const int mq = p >> 1;
+            const bool hi = (p == 1 || p == 2);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        // swapped operands: D'[n][m] -> lane holds n = (lane>>4)*4 + r, m = lane&15
+                        acc[mq * 4 + i][(hi ? 2 : 0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            hi ? bhi[j][kk] : blo[j][kk], a[i][kk], acc[mq * 4 + i][(hi ? 2 : 0) + j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    for (int t0 = 0; t0 < nt; t0 += 2) {
+        tile(std::integral_constant<int, 0>{}, t0, blo_even, blo_odd);
+        if (t0 + 1 < nt) tile(std::integral_constant<int, 1>{}, t0 + 1, blo_odd, blo_even);
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // redundant tail DMAs must land before exit
+
+    // ---- epilogue: wave quadrant (mq, nq) fragment (i, j) sits at rows wr*128 + mq*64 + i*16, cols wc*64 + nq*32 + j*16
+    const EpiArgs e = {g.C, g.bias, g.resid, g.ldc, g.ldr, g.M, g.N, g.out_f32, g.act, g.alpha};
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            store_frag(e, m0 + wr * 128 + i * 16 + (lane & 15), n0 + wc * 64 + j * 16 + (lane >> 4) * 4, acc[i][j]);
+}

@@ -98,7 +98,9 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = N
     check(_lib.load().spacer_gemm_bf16_nt(_ptr(a), _rowmajor(a), _ptr(b), _rowmajor(b), _ptr(out), _rowmajor(out),
                                           M, N, K, C.byref(epi), _stream()), "gemm_bf16_nt")
     ka = algo_k or K       # algorithmic contraction length (dW GEMMs run on a zero-padded token dim)
-    PROFILER.end("gemm_bf16_nt_kernel", t0, 2.0 * M * N * ka, 2.0 * (M * ka + N * ka) + out.element_size() * M * N)
+    if t0 is not None:
+        name = "gemm_bf16_nt_256h_kernel" if _lib.load().spacer_gemm_tile(M, N) == 256 else "gemm_bf16_nt_kernel"
+        PROFILER.end(name, t0, 2.0 * M * N * ka, 2.0 * (M * ka + N * ka) + out.element_size() * M * N)
     if PROFILER.by_shape and t0 is not None:
         s0, e0 = PROFILER.records[-1][1], PROFILER.records[-1][2]
         PROFILER.records.append((f"gemm[{M}x{N}x{K}]", s0, e0, 2.0 * M * N * ka, 0.0))
