@@ -49,14 +49,22 @@ typedef struct spacer_gemm_epilogue {
     int out_f32;
     int act;     /* enum spacer_act */
     float alpha; /* 0 is read as 1 */
+    /* optional split-K workspace of spacer_gemm_workspace_bytes() bytes, 16-byte aligned, owned by the caller (scratch,
+     * no initialisation needed); launches sharing a workspace must be ordered on one stream.  With it, the tiles of
+     * the last partially filled round of CUs are cut along K and summed in a fixed order by a second small kernel.
+     * NULL: the tail of the launch is not split. */
+    void* workspace;
+    long workspace_bytes;
 } spacer_gemm_epilogue;
 
 int spacer_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
                         const spacer_gemm_epilogue* epi, spacer_stream_t stream);
 
-/* Which tile spacer_gemm_bf16_nt runs an [M,N] problem on: 256 (gemm_bf16_nt_256h_kernel) or 128 (gemm_bf16_nt_kernel).
+long spacer_gemm_workspace_bytes(void);
+
+/* Which tile spacer_gemm_bf16_nt runs an [M,N,K] problem on: 256 (gemm_bf16_nt_256h_kernel) or 128 (gemm_bf16_nt_kernel).
  * Pure host function; profilers use it to attribute a launch to the kernel rocprof will name. */
-int spacer_gemm_tile(int M, int N);
+int spacer_gemm_tile(int M, int N, int K, int have_workspace);
 
 /* Skinny GEMM for the decode loop (M <= 64 rows, weights streamed once from HBM, split-K):
  * C32[M,N] += A[M,K] . B[N,K]^T  (fp32 atomics; C may be the fp32 residual stream itself).  K % 256 == 0.

@@ -21,7 +21,7 @@ class SpacerError(RuntimeError):
 
 class GemmEpilogue(C.Structure):
     _fields_ = [("bias", C.c_void_p), ("residual", C.c_void_p), ("ldr", C.c_long), ("out_f32", C.c_int),
-                ("act", C.c_int), ("alpha", C.c_float)]
+                ("act", C.c_int), ("alpha", C.c_float), ("workspace", C.c_void_p), ("workspace_bytes", C.c_long)]
 
 
 class AttnSegment(C.Structure):
@@ -70,7 +70,7 @@ SIGNATURES = {
     "spacer_sumsq_f32": [_p, _l, _p, _p],
     "spacer_adamw_step": [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _f, _p, _f, _f, _p],
 }
-OTHER_SYMBOLS = ["spacer_last_error", "spacer_version", "spacer_sample_workspace_bytes", "spacer_attn_decode_workspace_bytes", "spacer_gemm_tile"]
+OTHER_SYMBOLS = ["spacer_last_error", "spacer_version", "spacer_sample_workspace_bytes", "spacer_attn_decode_workspace_bytes", "spacer_gemm_tile", "spacer_gemm_workspace_bytes"]
 
 _lib = None
 
@@ -93,8 +93,10 @@ def load() -> C.CDLL:
     lib.spacer_version.restype = C.c_int
     lib.spacer_sample_workspace_bytes.argtypes = [_i, _i]
     lib.spacer_sample_workspace_bytes.restype = C.c_long
-    lib.spacer_gemm_tile.argtypes = [_i, _i]
+    lib.spacer_gemm_tile.argtypes = [_i, _i, _i, _i]
     lib.spacer_gemm_tile.restype = _i
+    lib.spacer_gemm_workspace_bytes.argtypes = []
+    lib.spacer_gemm_workspace_bytes.restype = C.c_long
     lib.spacer_attn_decode_workspace_bytes.argtypes = [_i, _i]
     lib.spacer_attn_decode_workspace_bytes.restype = C.c_long
     _lib = lib

@@ -35,6 +35,8 @@ struct GemmArgs {
     int act;                // spacer_act
     float alpha;
     int tiles_m, tiles_n;
+    int full_tiles, splits;     // 256h kernel: tiles owned whole / K splits of each remaining (tail) tile
+    float* slabs;               // split-K workspace (caller's): [tail tile][split][256x256] fp32 partial tiles
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -196,18 +198,43 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N == 4) ? 2
 
 }  // namespace
 
-// Tile choice, wave-quantisation aware: the 256x256 half-tile pipeline is ~25 % faster per tile-FLOP but runs one
-// workgroup per CU (256 slots) against two for the 128x128 tile (512 slots); pick the better efficiency x speed.
+// ---- launch planning --------------------------------------------------------------------------------------------
+constexpr long WS_SLAB_BYTES = 256L * 256 * 4, WS_MAX_SLABS = 256;
+
+// Tail split of the 256-tile kernel: the tiles of the last, partially filled round of the 256 CUs are each cut into
+// `splits` K ranges (<= 256 blocks in total, >= 16 K tiles per range: below that the slab round trip costs more than
+// the idle CUs it recovers).
+static void tail_plan(long tiles, int nt, bool have_ws, int* full, int* splits) {
+    *full = (int)tiles; *splits = 1;
+    const int rem = (int)(tiles % 256);
+    if (!have_ws || rem == 0 || rem > 176) return;
+    int s = 256 / rem;
+    if (s > 8) s = 8;
+    while (s > 1 && nt / s < 16) --s;
+    if (s < 2) return;
+    *full = (int)tiles - rem; *splits = s;
+}
+
+// Tile choice, wave-quantisation aware.  Cost in units of one 256x256 tile on one CU: the 256 tile runs one workgroup
+// per CU (256 slots), the 128 tile two (512 slots) and is ~25 % slower per FLOP, i.e. 0.625 per round.
 // SPACER_GEMM_TILE=128|256 forces one of them (tests run every shape through both).
-extern "C" int spacer_gemm_tile(int M, int N) {
+static int choose_tile(int M, int N, int K, bool have_ws) {
     static const char* force = getenv("SPACER_GEMM_TILE");
     if (force) return atoi(force) >= 256 ? 256 : 128;
     const long tiles256 = (long)cdiv(M, 256) * cdiv(N, 256);
     const long tiles128 = (long)cdiv(M, 128) * cdiv(N, 128);
-    const double eff256 = (double)tiles256 / (double)(cdiv(tiles256, 256) * 256L);
-    const double eff128 = (double)tiles128 / (double)(cdiv(tiles128, 512) * 512L);
-    return 1.25 * eff256 > eff128 ? 256 : 128;
+    int full, splits;
+    tail_plan(tiles256, K / BK, have_ws, &full, &splits);
+    double cost256 = (double)(full / 256);
+    if (splits > 1) cost256 += 1.0 / splits + 20.0 / (0.0268 * K);       // + ~20 us of slab traffic, in tile times
+    else if (tiles256 % 256) cost256 += 1.0;
+    const double cost128 = 0.625 * (double)cdiv(tiles128, 512);
+    return cost256 <= cost128 ? 256 : 128;
 }
+
+extern "C" long spacer_gemm_workspace_bytes(void) { return WS_MAX_SLABS * WS_SLAB_BYTES; }
+
+extern "C" int spacer_gemm_tile(int M, int N, int K, int have_workspace) { return choose_tile(M, N, K, have_workspace != 0); }
 
 extern "C" int spacer_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M,
                                    int N, int K, const spacer_gemm_epilogue* epi, spacer_stream_t stream) {
@@ -228,7 +255,9 @@ extern "C" int spacer_gemm_bf16_nt(const void* A, long lda, const void* B, long 
     if (epi && epi->alpha == 0.f) g.alpha = 1.f;
     const int esz = g.out_f32 ? 4 : 2;
     SP_REQUIRE(((uintptr_t)C % (4 * esz)) == 0, SPACER_EINVAL, "gemm: C misaligned");
-    const bool big = spacer_gemm_tile(M, N) == 256;
+    const bool have_ws = epi && epi->workspace && epi->workspace_bytes >= spacer_gemm_workspace_bytes();
+    SP_REQUIRE(!(epi && epi->workspace) || ((uintptr_t)epi->workspace % 16) == 0, SPACER_EINVAL, "gemm: workspace misaligned");
+    const bool big = choose_tile(M, N, K, have_ws) == 256;
     hipStream_t s = (hipStream_t)stream;
     if (big) {
         constexpr int LDS = 8 * 128 * BK * 2;
@@ -236,7 +265,14 @@ extern "C" int spacer_gemm_bf16_nt(const void* A, long lda, const void* B, long 
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         (void)once;
         g.tiles_m = cdiv(M, 256); g.tiles_n = cdiv(N, 256);
-        hipLaunchKernelGGL((gemm_bf16_nt_256h_kernel<true>), dim3(g.tiles_m * g.tiles_n), dim3(512), LDS, s, g);
+        const long tiles = (long)g.tiles_m * g.tiles_n;
+        static const char* nosplit = getenv("SPACER_GEMM_NOSPLIT");
+        tail_plan(tiles, K / BK, have_ws && !nosplit, &g.full_tiles, &g.splits);
+        g.slabs = have_ws ? (float*)epi->workspace : nullptr;
+        const long tail_tiles = tiles - g.full_tiles;
+        hipLaunchKernelGGL((gemm_bf16_nt_256h_kernel<true>), dim3((unsigned)(g.full_tiles + tail_tiles * g.splits)), dim3(512),
+                           LDS, s, g);
+        if (g.splits > 1) hipLaunchKernelGGL(gemm_tail_reduce_kernel, dim3((unsigned)(tail_tiles * 32)), dim3(512), 0, s, g);
     } else {
         constexpr int LDS = 2 * (128 * BK * 2 + 128 * BK * 2);
         g.tiles_m = cdiv(M, 128); g.tiles_n = cdiv(N, 128);

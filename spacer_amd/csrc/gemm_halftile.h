@@ -22,6 +22,17 @@
 //     same in every phase; the queue is drained once, before the epilogue.
 #include <type_traits>
 
+// pid (position in the launch's tile order) -> tile coordinates: groups of 4 tile-rows walked column by column, so the
+// tiles that run together share A rows and B columns in L2.
+__device__ __forceinline__ void tile_of_256(int pid, const GemmArgs& g, int& tm, int& tn) {
+    constexpr int GM = 4;
+    const int per_group = GM * g.tiles_n;
+    const int group = pid / per_group, first_m = group * GM;
+    const int gsz = min(g.tiles_m - first_m, GM);
+    tm = first_m + (pid % per_group) % gsz;
+    tn = (pid % per_group) / gsz;
+}
+
 template <bool BALANCED>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
     constexpr int BM = 256, BN = 256;
@@ -32,18 +43,28 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
 
-    const int nwg = g.tiles_m * g.tiles_n;
-    int pid;
+    // ---- block -> (tile, K range).  Blocks [0, full_tiles) own whole tiles (bijective XCD remap); the remaining
+    // tiles (the last, partially filled round of the 256 CUs) are each cut into `splits` K ranges, so the tail of the
+    // launch also fills the chip.  splits == 1 -> full_tiles == all tiles and there is no tail.
+    int pid, split = 0, kt0 = 0, ntl = g.K / BK;
+    bool tail = false;
     {
-        const int b = blockIdx.x, x = b & 7, q = nwg >> 3, r = nwg & 7;
-        pid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+        const int b = blockIdx.x;
+        if (b < g.full_tiles) {
+            const int x = b & 7, q = g.full_tiles >> 3, r = g.full_tiles & 7;
+            pid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+        } else {
+            const int u = b - g.full_tiles;
+            pid = g.full_tiles + u / g.splits;
+            split = u % g.splits;
+            tail = true;
+            const int nt_all = g.K / BK;
+            kt0 = (int)((long)split * nt_all / g.splits);
+            ntl = (int)((long)(split + 1) * nt_all / g.splits) - kt0;
+        }
     }
-    constexpr int GM = 4;
-    const int per_group = GM * g.tiles_n;
-    const int group = pid / per_group, first_m = group * GM;
-    const int gsz = min(g.tiles_m - first_m, GM);
-    const int tm = first_m + (pid % per_group) % gsz;
-    const int tn = (pid % per_group) / gsz;
+    int tm, tn;
+    tile_of_256(pid, g, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- DMA sources: this wave owns pieces (wave*2 + i), i = 0..1, of every half-tile image (8 rows x 128 B each)
@@ -61,9 +82,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
             offA[h][i] = (unsigned)((long)ra * g.lda + chunk * 8);
             offB[h][i] = (unsigned)((long)rb * g.ldb + chunk * 8);
         }
-    const int nt = g.K / BK;
+    const int nt = ntl;                                 // K tiles of THIS block: global tiles kt0 .. kt0+nt-1
     auto stage = [&](int par, int which, int t) {
-        const int k0 = (t < nt ? t : nt - 1) * BK;
+        const int k0 = (kt0 + (t < nt ? t : nt - 1)) * BK;
         char* dst = smem + (par * 4 + which) * HALF + wave * 2048;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -177,6 +198,19 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
     if (wr == 0) __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // redundant tail DMAs must land before exit
 
+    // ---- split-K tail: leave this block's fp32 partial tile as a slab (fragment-major, 16 B per lane, coalesced);
+    // gemm_tail_reduce_kernel sums a tile's slabs in split order and runs the epilogue (launched right behind).
+    if (tail) {
+        constexpr int SLAB4 = BM * BN / 4;                                   // float4 per slab
+        float4* mine = (float4*)g.slabs + ((size_t)(pid - g.full_tiles) * g.splits + split) * SLAB4;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                mine[(i * 4 + j) * 512 + tid] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        return;
+    }
+
     // ---- epilogue: wave quadrant (mq, nq) fragment (i, j) sits at rows wr*128 + mq*64 + i*16, cols wc*64 + nq*32 + j*16
     const EpiArgs e = {g.C, g.bias, g.resid, g.ldc, g.ldr, g.M, g.N, g.out_f32, g.act, g.alpha};
 #pragma unroll
@@ -184,4 +218,23 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             store_frag(e, m0 + wr * 128 + i * 16 + (lane & 15), n0 + wc * 64 + j * 16 + (lane >> 4) * 4, acc[i][j]);
+}
+
+// Sums the K-split partial tiles of the tail (written by gemm_bf16_nt_256h_kernel) in split order -- deterministic --
+// and applies the epilogue.  One block per (tail tile, accumulator fragment index): the whole chip takes part, a
+// single CU could pull its tile's slabs only at ~25 GB/s.
+__global__ __launch_bounds__(512) void gemm_tail_reduce_kernel(GemmArgs g) {
+    constexpr int SLAB4 = 256 * 256 / 4;
+    const int lt = blockIdx.x >> 5, f = blockIdx.x & 31, i = f >> 2, j = f & 3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 2, wc = wave & 3;
+    int tm, tn;
+    tile_of_256(g.full_tiles + lt, g, tm, tn);
+    const float4* p = (const float4*)g.slabs + (size_t)lt * g.splits * SLAB4 + f * 512 + tid;
+    f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int sp = 0; sp < g.splits; ++sp) {
+        const float4 v = p[(size_t)sp * SLAB4];
+        sum[0] += v.x; sum[1] += v.y; sum[2] += v.z; sum[3] += v.w;
+    }
+    const EpiArgs e = {g.C, g.bias, g.resid, g.ldc, g.ldr, g.M, g.N, g.out_f32, g.act, g.alpha};
+    store_frag(e, tm * 256 + wr * 128 + i * 16 + (lane & 15), tn * 256 + wc * 64 + j * 16 + (lane >> 4) * 4, sum);
 }

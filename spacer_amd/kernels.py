@@ -81,8 +81,22 @@ PROFILER = _Profiler()
 
 
 # ----------------------------------------------------------------------------------------- GEMM
+_GEMM_WS = {}
+
+
+def _gemm_workspace(device) -> torch.Tensor:
+    """Split-K workspace of the GEMM (fp32 partial-tile slabs), one per device; all launches go through the current
+    stream, which is what the C-ABI asks of launches that share a workspace."""
+    ws = _GEMM_WS.get(device)
+    if ws is None:
+        ws = torch.empty(_lib.load().spacer_gemm_workspace_bytes() // 4, device=device, dtype=torch.float32)
+        _GEMM_WS[device] = ws
+    return ws
+
+
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = None, bias=None, residual=None,
-            act: int = SPACER_ACT_NONE, out_dtype=BF16, alpha: float = 1.0, algo_k: Optional[int] = None) -> torch.Tensor:
+            act: int = SPACER_ACT_NONE, out_dtype=BF16, alpha: float = 1.0, algo_k: Optional[int] = None,
+            split_k: bool = True) -> torch.Tensor:
     """out[M,N] = act(alpha * a[M,K] @ b[N,K]^T + bias) + residual.  a, b bf16; out bf16 or fp32."""
     M, K = a.shape
     N, K2 = b.shape
@@ -94,12 +108,15 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = N
         assert residual.dtype == out.dtype
     epi = GemmEpilogue(_ptr(bias), _ptr(residual), _rowmajor(residual) if residual is not None else 0,
                        1 if out.dtype == torch.float32 else 0, act, alpha)
+    if split_k:
+        ws = _gemm_workspace(a.device)
+        epi.workspace, epi.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     t0 = PROFILER.begin()
     check(_lib.load().spacer_gemm_bf16_nt(_ptr(a), _rowmajor(a), _ptr(b), _rowmajor(b), _ptr(out), _rowmajor(out),
                                           M, N, K, C.byref(epi), _stream()), "gemm_bf16_nt")
     ka = algo_k or K       # algorithmic contraction length (dW GEMMs run on a zero-padded token dim)
     if t0 is not None:
-        name = "gemm_bf16_nt_256h_kernel" if _lib.load().spacer_gemm_tile(M, N) == 256 else "gemm_bf16_nt_kernel"
+        name = "gemm_bf16_nt_256h_kernel" if _lib.load().spacer_gemm_tile(M, N, K, 1 if split_k else 0) == 256 else "gemm_bf16_nt_kernel"
         PROFILER.end(name, t0, 2.0 * M * N * ka, 2.0 * (M * ka + N * ka) + out.element_size() * M * N)
     if PROFILER.by_shape and t0 is not None:
         s0, e0 = PROFILER.records[-1][1], PROFILER.records[-1][2]

@@ -68,6 +68,29 @@ def test_gemm_nt_epilogues(dev):
     assert K.gemm_nt(a, b, alpha=0.5).float().sub(0.5 * base).abs().max() < 5e-2
 
 
+@pytest.mark.parametrize("M,N,Kd", [(1300, 1536, 8192), (700, 3584, 8192), (5498, 3584, 8192), (2100, 256, 16384)])
+def test_gemm_split_k_tail(dev, M, N, Kd):
+    """Shapes whose 256-tiles leave the last round of CUs mostly empty: the tail tiles are cut along K, partial tiles
+    meet in the caller's workspace and a second kernel sums them in split order and runs the epilogue.  Must equal the
+    unsplit launch up to fp32 summation order and be bit-reproducible."""
+    a, b = rnd((M, Kd), dev, 11, 0.5), rnd((N, Kd), dev, 12, 0.1)
+    b[:, 0] += 1.0
+    bias = rnd((N,), dev, 13)
+    res = rnd((M, N), dev, 14, dtype=torch.float32)
+    want = a.float() @ b.float().t()
+    lib = K._lib.load()
+    assert lib.spacer_gemm_tile(M, N, Kd, 1) == 256
+    for _ in range(3):
+        got = K.gemm_nt(a, b, bias=bias, act=K.SPACER_ACT_QUICK_GELU)
+        assert_close(got, O.quick_gelu(want + bias.float()), 3e-2, 1e-2, "split-K bias+quick_gelu")
+    g1 = K.gemm_nt(a, b, residual=res, out_dtype=torch.float32)
+    g2 = K.gemm_nt(a, b, residual=res, out_dtype=torch.float32)
+    assert torch.equal(g1, g2), "split-K reduction must be deterministic"
+    assert_close(g1, want + res, 3e-3 * math.sqrt(Kd / 256), 1e-3, "split-K f32 residual")
+    g0 = K.gemm_nt(a, b, residual=res, out_dtype=torch.float32, split_k=False)
+    assert_close(g1, g0, 1e-3, 1e-4, "split vs unsplit")
+
+
 def test_gemm_rejects_bad_k(dev):
     a, b = rnd((64, 96), dev, 1), rnd((64, 96), dev, 2)
     with pytest.raises(K.SpacerError):
