@@ -79,6 +79,14 @@ int spacer_pack_weight_frag(const void* W, long ld, void* out, int N, int K, spa
 int spacer_gemm_skinny_packed_bf16(const void* A, long lda, const void* Bpacked, void* C, long ldc, int M, int N, int K,
                                    spacer_stream_t stream);
 
+/* Decode-loop MLP front half in one launch:  Y[M, inter] (bf16) = silu(A . Wgate^T) * (A . Wup^T)   (HF Qwen2MLP's
+ * act_fn(gate_proj(x)) * up_proj(x) inside generate, TR:463).  W = [gate (inter rows) | up (inter rows)] x K is packed
+ * by spacer_pack_weight_frag_swiglu so each 16-column MFMA fragment holds 8 gate + 8 up columns of the same outputs;
+ * every block owns the whole K, so there is no fp32 partial buffer and no separate SwiGLU kernel.  M <= 64. */
+int spacer_pack_weight_frag_swiglu(const void* W, long ld, void* out, int inter, int K, spacer_stream_t stream);
+int spacer_gemm_skinny_swiglu_bf16(const void* A, long lda, const void* Bpacked, void* Y, long ldy, int M, int inter, int K,
+                                   spacer_stream_t stream);
+
 /* out[C, Rpad] = in[R, C]^T, zero-filling columns R..Rpad-1 (bf16).  Feeds the NT GEMM in backward. */
 int spacer_transpose_bf16(const void* in, long ld_in, void* out, long ld_out, int R, int C, int Rpad,
                           spacer_stream_t stream);

@@ -36,6 +36,8 @@ SIGNATURES = {
     "spacer_gemm_skinny_bf16": [_p, _l, _p, _l, _p, _l, _i, _i, _i, C.POINTER(GemmEpilogue), _p],
     "spacer_pack_weight_frag": [_p, _l, _p, _i, _i, _p],
     "spacer_gemm_skinny_packed_bf16": [_p, _l, _p, _p, _l, _i, _i, _i, _p],
+    "spacer_pack_weight_frag_swiglu": [_p, _l, _p, _i, _i, _p],
+    "spacer_gemm_skinny_swiglu_bf16": [_p, _l, _p, _p, _l, _i, _i, _i, _p],
     "spacer_transpose_bf16": [_p, _l, _p, _l, _i, _i, _i, _p],
     "spacer_rmsnorm_fwd": [_p, _i, _p, _p, _p, _i, _i, _f, _p],
     "spacer_rmsnorm_bwd": [_p, _i, _p, _p, _p, _p, _i, _p, _i, _i, _p],

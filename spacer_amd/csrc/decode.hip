@@ -21,7 +21,10 @@ namespace {
 // 1 KiB of contiguous memory; row-major B gives 16 x 64-byte segments per instruction, ~30 % slower.
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
-template <bool PACKED>
+// SWIGLU (packed weights only, whole K per block): the 16 columns of a wave are [8 gate | 8 up] columns of the same 8
+// outputs (spacer_pack_weight_frag_swiglu), so lanes l and l^8 hold gate and up of one element; the epilogue writes
+// y = silu(gate) * up as bf16 [M, N/2] and C is that bf16 buffer -- no fp32 round trip, no separate SwiGLU launch.
+template <bool PACKED, bool SWIGLU = false>
 __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __restrict__ A, long lda,
                                                              const bf16_t* __restrict__ B, long ldb,
                                                              float* __restrict__ C, long ldc, int M, int N, int K,
@@ -110,6 +113,22 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __res
     }
     // lane holds C[m = mf*16 + g*4 + r][n = n0 + l15]
     const int n = n0 + l15;
+    if (SWIGLU) {
+        bf16_t* Y = (bf16_t*)C;
+        const int col = (n0 >> 1) + (l15 & 7);                               // output column of this gate/up pair
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float other = __shfl_xor(acc[mf][r], 8);
+                const int m = mf * 16 + g * 4 + r;
+                if (l15 < 8 && m < mflush && n < N) {
+                    const float gv = acc[mf][r];
+                    Y[(long)m * ldc + col] = f2bf(gv / (1.f + __expf(-gv)) * other);
+                }
+            }
+        return;
+    }
     const bool whole_k = (s_begin == 0 && s_end == total_slices);
     if (n < N) {
 #pragma unroll
@@ -127,14 +146,19 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __res
 }
 
 // W [N, K] row-major -> fragment-major copy for the decode loop (rebuilt once per optimizer step)
-__global__ __launch_bounds__(256) void pack_frag_kernel(const bf16_t* __restrict__ W, long ld, bf16_t* __restrict__ out, int N, int K) {
+// half > 0 (N = 2*half, rows [0,half) gate, [half,N) up): column group nb takes gate rows 8nb..8nb+7 then up rows
+// half+8nb..half+8nb+7, the layout the SWIGLU epilogue of gemm_skinny_kernel expects.
+__global__ __launch_bounds__(256) void pack_frag_kernel(const bf16_t* __restrict__ W, long ld, bf16_t* __restrict__ out, int N, int K,
+                                                        int half) {
     const long total = (long)(N >> 4) * (K >> 5) * 64;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int lane = (int)(i & 63);
         const long frag = i >> 6;
         const int kb = (int)(frag % (K >> 5));
         const long nb = frag / (K >> 5);
-        const uint4 v = *(const uint4*)(W + (nb * 16 + (lane & 15)) * ld + kb * 32 + (lane >> 4) * 8);
+        const int p = lane & 15;
+        const long row = half > 0 ? (p < 8 ? nb * 8 + p : half + nb * 8 + (p - 8)) : nb * 16 + p;
+        const uint4 v = *(const uint4*)(W + row * ld + kb * 32 + (lane >> 4) * 8);
         *(uint4*)(out + i * 8) = v;
     }
 }
@@ -563,7 +587,10 @@ static int launch_skinny(const void* A, long lda, const void* B, long ldb, void*
     // K ranges: 1 (no atomics) when the column groups alone fill the chip, else just enough ranges for ~2 workgroups / CU
     const int col_groups = cdiv(N, 64), slices = K / 256;
     int ranges = 1;
-    static const int target_blocks = getenv("SPACER_SKINNY_BLOCKS") ? atoi(getenv("SPACER_SKINNY_BLOCKS")) : 512;
+    // SPACER_SKINNY_BLOCKS=1 forces one K range per column group (no atomics: bit-reproducible sums); read per call so
+    // a test can switch it
+    const char* tb = getenv("SPACER_SKINNY_BLOCKS");
+    const int target_blocks = tb ? atoi(tb) : 512;
     if (col_groups < 448) ranges = min(slices, cdiv(target_blocks, col_groups));
     const int spr = cdiv(slices, ranges);
     ranges = cdiv(slices, spr);
@@ -592,7 +619,30 @@ extern "C" int spacer_pack_weight_frag(const void* W, long ld, void* out, int N,
     SP_REQUIRE(N % 16 == 0 && K % 32 == 0 && ld % 8 == 0, SPACER_EINVAL, "pack_weight_frag: need N %% 16 == 0, K %% 32 == 0");
     const long total = (long)(N / 16) * (K / 32) * 64;
     hipLaunchKernelGGL(pack_frag_kernel, dim3((int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192)), dim3(256), 0,
-                       (hipStream_t)stream, (const bf16_t*)W, ld, (bf16_t*)out, N, K);
+                       (hipStream_t)stream, (const bf16_t*)W, ld, (bf16_t*)out, N, K, 0);
+    SP_CHECK_LAUNCH();
+    return SPACER_OK;
+}
+
+extern "C" int spacer_pack_weight_frag_swiglu(const void* W, long ld, void* out, int inter, int K, spacer_stream_t stream) {
+    SP_REQUIRE(inter % 32 == 0 && K % 32 == 0 && ld % 8 == 0, SPACER_EINVAL,
+               "pack_weight_frag_swiglu: need inter %% 32 == 0, K %% 32 == 0");
+    const long total = (long)(2 * inter / 16) * (K / 32) * 64;
+    hipLaunchKernelGGL(pack_frag_kernel, dim3((int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192)), dim3(256), 0,
+                       (hipStream_t)stream, (const bf16_t*)W, ld, (bf16_t*)out, 2 * inter, K, inter);
+    SP_CHECK_LAUNCH();
+    return SPACER_OK;
+}
+
+extern "C" int spacer_gemm_skinny_swiglu_bf16(const void* A, long lda, const void* Bpacked, void* Y, long ldy, int M, int inter,
+                                              int K, spacer_stream_t stream) {
+    SP_REQUIRE(A && Bpacked && Y, SPACER_EINVAL, "gemm_skinny_swiglu: null operand");
+    SP_REQUIRE(M > 0 && M <= 64, SPACER_EINVAL, "gemm_skinny_swiglu: M=%d must be in 1..64", M);
+    SP_REQUIRE(K % 256 == 0 && inter % 32 == 0 && lda % 8 == 0, SPACER_EINVAL,
+               "gemm_skinny_swiglu: need K %% 256 == 0, inter %% 32 == 0, lda %% 8 == 0");
+    const int N = 2 * inter;
+    hipLaunchKernelGGL((gemm_skinny_kernel<true, true>), dim3(cdiv(N, 64), 1), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)A, lda, (const bf16_t*)Bpacked, 0L, (float*)Y, ldy, M, N, K, K / 256, M);
     SP_CHECK_LAUNCH();
     return SPACER_OK;
 }

@@ -152,6 +152,26 @@ def gemm_skinny_packed_acc(a: torch.Tensor, bp: torch.Tensor, c32: torch.Tensor,
     return c32
 
 
+def pack_weight_frag_swiglu(w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[2*I, K] = [gate | up] rows -> fragment-major copy with 8 gate + 8 up columns per fragment (gemm_skinny_swiglu)."""
+    N, K = w.shape
+    if out is None:
+        out = torch.empty(N * K, device=w.device, dtype=BF16)
+    check(_lib.load().spacer_pack_weight_frag_swiglu(_ptr(w), _rowmajor(w), _ptr(out), N // 2, K, _stream()), "pack_weight_frag_swiglu")
+    return out
+
+
+def gemm_skinny_swiglu(a: torch.Tensor, bp: torch.Tensor, inter: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M, inter] (bf16) = silu(a @ Wgate^T) * (a @ Wup^T), weights from pack_weight_frag_swiglu."""
+    M, K = a.shape
+    assert bp.numel() == 2 * inter * K
+    if out is None:
+        out = torch.empty(M, inter, device=a.device, dtype=BF16)
+    check(_lib.load().spacer_gemm_skinny_swiglu_bf16(_ptr(a), _rowmajor(a), _ptr(bp), _ptr(out), _rowmajor(out), M, inter, K,
+                                                     _stream()), "gemm_skinny_swiglu_bf16")
+    return out
+
+
 def transpose_pad(x: torch.Tensor, rpad: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x[R,C] bf16 -> out[C, Rpad] with zero fill (Rpad defaults to R rounded up to 64)."""
     R, Cc = x.shape

@@ -62,7 +62,7 @@ class RolloutEngine:
         if self._packed is None:
             W, cfg = self.e.W, self.cfg
             names = [f"llm.{i}.{n}" for i in range(cfg.layers) for n in ("qkv_w", "o_w", "gu_w", "down_w")] + ["llm.lm_head"]
-            self._packed = {n: K.pack_weight_frag(W[n]) for n in names}
+            self._packed = {n: (K.pack_weight_frag_swiglu(W[n]) if n.endswith("gu_w") else K.pack_weight_frag(W[n])) for n in names}
         return self._packed
 
     # ------------------------------------------------------------------ prefill
@@ -116,8 +116,7 @@ class RolloutEngine:
                                   st["tail_len"], Hq, Hkv, D, scale, out=st["o"])
             K.gemm_skinny_packed_acc(o, PW[p + "o_w"], x, cfg.hidden)
             h2 = K.rmsnorm_fwd(x, W[p + "ln2_w"], cfg.rms_eps, out=st["h"])
-            K.gemm_skinny_packed_acc(h2, PW[p + "gu_w"], st["acc_gu"], 2 * I)
-            a = K.swiglu_f32_fwd(st["acc_gu"], st["a"])
+            a = K.gemm_skinny_swiglu(h2, PW[p + "gu_w"], I, out=st["a"])      # gate|up GEMM + SwiGLU in one launch
             K.gemm_skinny_packed_acc(a, PW[p + "down_w"], x, cfg.hidden)
         hn = K.rmsnorm_fwd(x, W["llm.norm_w"], cfg.rms_eps, out=st["h"])
         st["logits"].zero_()
@@ -159,7 +158,6 @@ class RolloutEngine:
             q=torch.empty(B, cfg.heads * D, device=dev, dtype=BF16), o=torch.empty(B, cfg.heads * D, device=dev, dtype=BF16),
             a=torch.empty(B, cfg.intermediate, device=dev, dtype=BF16),
             acc_qkv=torch.zeros(B, cfg.qkv_dim, device=dev, dtype=F32),
-            acc_gu=torch.zeros(B, 2 * cfg.intermediate, device=dev, dtype=F32),
             cos=torch.empty(B, D, device=dev, dtype=F32), sin=torch.empty(B, D, device=dev, dtype=F32),
             logits=torch.empty(B, cfg.vocab, device=dev, dtype=F32),
         )

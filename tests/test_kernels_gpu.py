@@ -111,6 +111,15 @@ def test_gemm_skinny(dev, M, N, K):
         assert_close(c2, c0 + a.float() @ b.float().t(), 5e-3, 2e-3, "skinny packed")
 
 
+@pytest.mark.parametrize("M,I,Kd", [(64, 18944, 3584), (8, 512, 256), (33, 96, 1536)])
+def test_gemm_skinny_swiglu(dev, M, I, Kd):
+    a, w = rnd((M, Kd), dev, 1, 0.5), rnd((2 * I, Kd), dev, 2, 0.05)
+    y = K.gemm_skinny_swiglu(a, K.pack_weight_frag_swiglu(w), I)
+    gu = a.float() @ w.float().t()
+    want = torch.nn.functional.silu(gu[:, :I]) * gu[:, I:]
+    assert_close(y, want, 2e-2, 1e-2, "skinny swiglu")
+
+
 def test_transpose_pad(dev):
     x = rnd((200, 136), dev, 1)
     t = K.transpose_pad(x, 256)
