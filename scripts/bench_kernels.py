@@ -76,6 +76,34 @@ def bench_decode_attn():
         print(f"  tail {tl:4d}: per-seq {t * 1e6:7.1f} us | shared-prefix {t2 * 1e6:7.1f} us   unique KV {kv / 1e6:7.1f} MB -> {kv / t2 / 1e12:5.2f} TB/s")
 
 
+def bench_attn():
+    print("== prefill/scoring attention, cfg3 group layout: prompt 1402 + 8 x 512 rollouts sharing the prompt keys")
+    P, C, Kn, Hq, Hkv, D = 1402, 512, 8, 28, 4, 128
+    T = P + Kn * C
+    qkv = rnd(T, (Hq + 2 * Hkv) * D)
+    q, k, v = qkv[:, :Hq * D], qkv[:, Hq * D:(Hq + Hkv) * D], qkv[:, (Hq + Hkv) * D:]
+    segs = K.make_segments([(0, P, 0, 0)] + [(P + i * C, C, 0, P) for i in range(Kn)], dev)
+    pairs = P * (P + 1) / 2 + Kn * (C * P + C * (C + 1) / 2)          # visible (q, k) pairs per head
+    flops = 4.0 * pairs * D * Hq
+    o, lse = K.attn_fwd(q, k, v, segs, P, Hq, Hkv, D, True, D ** -0.5)
+    t = timeit(lambda: K.attn_fwd(q, k, v, segs, P, Hq, Hkv, D, True, D ** -0.5, out=o, lse=lse), iters=20)
+    print(f"  fwd  D=128: {t * 1e6:8.1f} us  {flops / t / 1e12:7.1f} TF/s")
+    d_o = rnd(T, Hq * D)
+    dqkv = torch.empty_like(qkv)
+    dk32 = torch.zeros(T, Hkv * D, device=dev); dv32 = torch.zeros(T, Hkv * D, device=dev)
+    t = timeit(lambda: K.attn_bwd(q, k, v, o, d_o, lse, segs, P, Hq, Hkv, D, True, D ** -0.5, dq=dqkv[:, :Hq * D], dk32=dk32, dv32=dv32),
+               iters=10)
+    print(f"  bwd  D=128: {t * 1e6:8.1f} us  {2.5 * flops / t / 1e12:7.1f} TF/s (2.5x forward flops)")
+    # ViT: 8 temporal grids of 520 patches, 16 heads x 80, non-causal
+    Tv, Hv, Dv = 4160, 16, 80
+    qkv = rnd(Tv, 3 * Hv * Dv)
+    segs = K.make_segments([(i * 520, 520, 0, 0) for i in range(8)], dev)
+    fl = 4.0 * 8 * 520 * 520 * Dv * Hv
+    t = timeit(lambda: K.attn_fwd(qkv[:, :Hv * Dv], qkv[:, Hv * Dv:2 * Hv * Dv], qkv[:, 2 * Hv * Dv:], segs, 520, Hv, Hv, Dv, False, Dv ** -0.5),
+               iters=20)
+    print(f"  fwd  D=80 (ViT): {t * 1e6:8.1f} us  {fl / t / 1e12:7.1f} TF/s")
+
+
 def bench_sampler():
     print("== sampler B=64 V=152064")
     lg = torch.randn(64, 152064, device=dev)
@@ -103,6 +131,8 @@ if __name__ == "__main__":
         bench_skinny()
     if what in ("decode", "all"):
         bench_decode_attn()
+    if what in ("attn", "all"):
+        bench_attn()
     if what in ("sampler", "all"):
         bench_sampler()
     if what in ("misc", "all"):

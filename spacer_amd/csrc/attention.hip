@@ -30,7 +30,7 @@ struct AttnArgs {
     const bf16_t* d_o; float* delta; bf16_t* dq; float* dk; float* dv;
     long q_stride, kv_stride, o_stride;
     const spacer_attn_segment* segs;
-    int num_segs, nqb, T, Hq, Hkv, causal;
+    int num_segs, nqb, T, Hq, Hkv, causal, lpt;
     float scale;
 };
 
@@ -53,7 +53,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     char* vt_lds = smem + AT_RM_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int seg_id = blockIdx.x / a.nqb, qb = blockIdx.x % a.nqb;
+    // longest-first dispatch: later segments (rollouts: prompt prefix + own keys) and later query blocks of a causal
+    // segment have the most key tiles, so they get the lowest block ids and the short blocks fill the tail
+    const int seg_id = a.lpt ? a.num_segs - 1 - blockIdx.x / a.nqb : blockIdx.x / a.nqb;
+    const int qb = a.lpt ? a.nqb - 1 - blockIdx.x % a.nqb : blockIdx.x % a.nqb;
     const int h = blockIdx.y, hk = h / (a.Hq / a.Hkv);
     const spacer_attn_segment seg = a.segs[seg_id];
     const int qb0 = qb * BQ;
@@ -76,7 +79,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     for (int f = 0; f < 2; ++f)
 #pragma unroll
         for (int d = 0; d < DF; ++d) oacc[f][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};     // m_run in log2 units (scores * scale * log2 e)
+    const float c2 = a.scale * 1.4426950408889634f;
 
     const int own_len = a.causal ? min(seg.q_len, qb0 + BQ) : seg.q_len;
     const int n_pre = (seg.pre_len + BKV - 1) / BKV, n_tiles = n_pre + (own_len + BKV - 1) / BKV;
@@ -116,38 +120,50 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
             }
         }
 
-        // ---- mask + online softmax (per q column = per lane&15, replicated over the 4 lane groups)
+        // ---- online softmax in the exp2 domain (per q column = per lane&15, replicated over the 4 lane groups):
+        // p = 2^(s*c - m) with c = scale*log2(e) folded into one FMA; masking code only runs on tiles that need it
+        // (ragged last tile of a key range, causal diagonal) -- wave-uniform; O is rescaled only when some row's
+        // running max moved.
+        const bool need_mask = (kt.rel0 + BKV > kt.len) || (kt.own && a.causal && kt.rel0 + BKV - 1 > wq0);
         bf16x8 pf[2][2];   // [f][32-key half]
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
             const int qi = wq0 + f * 16 + l15;           // query index relative to the segment
             float mx = -INFINITY;
+            if (need_mask) {
+#pragma unroll
+                for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int kr = kt.rel0 + kf * 16 + g * 4 + r;
+                        const bool ok = kr < kt.len && !(kt.own && a.causal && kr > qi);
+                        st[kf][f][r] = ok ? st[kf][f][r] : -INFINITY;
+                    }
+            }
 #pragma unroll
             for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int kr = kt.rel0 + kf * 16 + g * 4 + r;
-                    float s = st[kf][f][r] * a.scale;
-                    const bool ok = kr < kt.len && !(kt.own && a.causal && kr > qi);
-                    s = ok ? s : -INFINITY;
-                    st[kf][f][r] = s;
-                    mx = fmaxf(mx, s);
-                }
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kf][f][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run[f], mx);
+            const float m_new = fmaxf(m_run[f], mx * c2);                     // c2 > 0: max commutes with the scaling
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = __expf(m_run[f] - m_use);     // m_run = -inf -> 0
+            const float alpha = __builtin_amdgcn_exp2f(m_run[f] - m_use);     // m_run = -inf -> 0
             float psum = 0.f;
             float p[4][4];
 #pragma unroll
             for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { p[kf][r] = __expf(st[kf][f][r] - m_use); psum += p[kf][r]; }
+                for (int r = 0; r < 4; ++r) {
+                    p[kf][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kf][f][r], c2, -m_use));
+                    psum += p[kf][r];
+                }
             l_run[f] = l_run[f] * alpha + psum;
             m_run[f] = m_new;
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
 #pragma unroll
-            for (int d = 0; d < DF; ++d) oacc[f][d] *= alpha;
+                for (int d = 0; d < DF; ++d) oacc[f][d] *= alpha;
+            }
             pf[f][0] = pack_slots(p[0], p[1]);
             pf[f][1] = pack_slots(p[2], p[3]);
         }
@@ -179,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
             const f32x4 v = oacc[f][df];
             *(uint2*)(op + df * 16 + g * 4) = make_uint2(pack_bf2(v[0] * inv, v[1] * inv), pack_bf2(v[2] * inv, v[3] * inv));
         }
-        if (a.lse && g == 0) a.lse[(long)h * a.T + tok] = m_run[f] + logf(l);
+        if (a.lse && g == 0) a.lse[(long)h * a.T + tok] = m_run[f] * 0.6931471805599453f + logf(l);
     }
 }
 
@@ -209,25 +225,30 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs a) {
 // ---- dQ: same decomposition as forward; per key tile
 //   S^T = K Q^T ; P^T = exp(scale S^T - lse[q]) ; dP^T = V dO^T ; dS^T = P^T (dP^T - delta[q]) scale
 //   dQ^T += K^T dS^T   (A = K^T frag from the transposed image, B = dS^T from registers)
-template <int D>
+// NF = 16-row query fragments per wave (workgroup = 64*NF query rows).  NF = 1 keeps Q, dO, dQ^T and the prefetched
+// K/V tile of the next step in registers without spilling at D = 128.
+template <int D, int NF>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
-    constexpr int DC = (D + 31) / 32, DF = D / 16;
+    constexpr int DC = (D + 31) / 32, DF = D / 16, BQD = 64 * NF;
     __shared__ __attribute__((aligned(16))) char smem[2 * AT_RM_BYTES + AT_T_BYTES(D)];
     char* k_lds = smem; char* v_lds = smem + AT_RM_BYTES; char* kt_lds = smem + 2 * AT_RM_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int seg_id = blockIdx.x / a.nqb, qb = blockIdx.x % a.nqb;
+    // longest-first dispatch: later segments (rollouts: prompt prefix + own keys) and later query blocks of a causal
+    // segment have the most key tiles, so they get the lowest block ids and the short blocks fill the tail
+    const int seg_id = a.lpt ? a.num_segs - 1 - blockIdx.x / a.nqb : blockIdx.x / a.nqb;
+    const int qb = a.lpt ? a.nqb - 1 - blockIdx.x % a.nqb : blockIdx.x % a.nqb;
     const int h = blockIdx.y, hk = h / (a.Hq / a.Hkv);
     const spacer_attn_segment seg = a.segs[seg_id];
-    const int qb0 = qb * BQ;
+    const int qb0 = qb * BQD;
     if (qb0 >= seg.q_len) return;
     const int l15 = lane & 15, g = lane >> 4;
-    const int wq0 = qb0 + wave * 32;
+    const int wq0 = qb0 + wave * 16 * NF;
 
-    bf16x8 qf[2][DC], dof[2][DC];
-    float lse_q[2], dl_q[2];
+    bf16x8 qf[NF][DC], dof[NF][DC];
+    float lse_q[NF], dl_q[NF];
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
+    for (int f = 0; f < NF; ++f) {
         int qi = wq0 + f * 16 + l15;
         qi = qi < seg.q_len ? qi : seg.q_len - 1;
         const long tok = seg.q_start + qi;
@@ -238,30 +259,45 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         lse_q[f] = a.lse[(long)h * a.T + tok];
         dl_q[f] = a.delta[(long)h * a.T + tok];
     }
-    f32x4 acc[2][DF];
+    f32x4 acc[NF][DF];
 #pragma unroll
-    for (int f = 0; f < 2; ++f)
+    for (int f = 0; f < NF; ++f)
 #pragma unroll
         for (int d = 0; d < DF; ++d) acc[f][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int own_len = a.causal ? min(seg.q_len, qb0 + BQ) : seg.q_len;
+    const int own_len = a.causal ? min(seg.q_len, qb0 + BQD) : seg.q_len;
     const int n_pre = (seg.pre_len + BKV - 1) / BKV, n_tiles = n_pre + (own_len + BKV - 1) / BKV;
 
-    for (int t = 0; t < n_tiles; ++t) {
-        const KeyTile kt = key_tile(seg, n_pre, own_len, t);
-        uint4 kreg[4], vreg[4];
+    const float c2 = a.scale * 1.4426950408889634f;            // exp2 domain: p = 2^(s*c2 - lse*log2 e)
+    float lse2_q[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) lse2_q[f] = lse_q[f] * 1.4426950408889634f;
+
+    uint4 kreg[4], vreg[4];                                    // next tile, in flight under this tile's MFMAs
+    {
+        const KeyTile kt = key_tile(seg, n_pre, own_len, 0);
         const long off = (long)(kt.start_abs + kt.rel0) * a.kv_stride + (long)hk * D;
         tile_load<D>(kreg, a.k + off, a.kv_stride, kt.len - kt.rel0, tid);
         tile_load<D>(vreg, a.v + off, a.kv_stride, kt.len - kt.rel0, tid);
+    }
+    for (int t = 0; t < n_tiles; ++t) {
+        const KeyTile kt = key_tile(seg, n_pre, own_len, t);
         __syncthreads();
         tile_store<D, true, true>(kreg, k_lds, kt_lds, tid);
         tile_store<D, true, false>(vreg, v_lds, nullptr, tid);
         __syncthreads();
-        if (kt.own && a.causal && kt.rel0 > wq0 + 31) continue;
+        if (t + 1 < n_tiles) {
+            const KeyTile nx = key_tile(seg, n_pre, own_len, t + 1);
+            const long off = (long)(nx.start_abs + nx.rel0) * a.kv_stride + (long)hk * D;
+            tile_load<D>(kreg, a.k + off, a.kv_stride, nx.len - nx.rel0, tid);
+            tile_load<D>(vreg, a.v + off, a.kv_stride, nx.len - nx.rel0, tid);
+        }
+        if (kt.own && a.causal && kt.rel0 > wq0 + 16 * NF - 1) continue;
+        const bool need_mask = (kt.rel0 + BKV > kt.len) || (kt.own && a.causal && kt.rel0 + BKV - 1 > wq0);
 
-        bf16x8 dsf[2][2];
+        bf16x8 dsf[NF][2];
 #pragma unroll
-        for (int f = 0; f < 2; ++f) {
+        for (int f = 0; f < NF; ++f) {
             f32x4 st[4], dp[4];
 #pragma unroll
             for (int kf = 0; kf < 4; ++kf) {
@@ -273,14 +309,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
                 }
             }
             const int qi = wq0 + f * 16 + l15;
+            if (need_mask) {
+#pragma unroll
+                for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int kr = kt.rel0 + kf * 16 + g * 4 + r;
+                        st[kf][r] = (kr < kt.len && !(kt.own && a.causal && kr > qi)) ? st[kf][r] : -INFINITY;   // p = 0
+                    }
+            }
             float ds[4][4];
 #pragma unroll
             for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int kr = kt.rel0 + kf * 16 + g * 4 + r;
-                    const bool ok = kr < kt.len && !(kt.own && a.causal && kr > qi);
-                    const float p = ok ? __expf(st[kf][r] * a.scale - lse_q[f]) : 0.f;
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kf][r], c2, -lse2_q[f]));
                     ds[kf][r] = p * (dp[kf][r] - dl_q[f]) * a.scale;
                 }
             dsf[f][0] = pack_slots(ds[0], ds[1]);
@@ -291,12 +334,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const bf16x8 ktf = frag_t(kt_lds, df, c, lane);
-                acc[0][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[0][c], acc[0][df], 0, 0, 0);
-                acc[1][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[1][c], acc[1][df], 0, 0, 0);
+#pragma unroll
+                for (int f = 0; f < NF; ++f)
+                    acc[f][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[f][c], acc[f][df], 0, 0, 0);
             }
     }
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
+    for (int f = 0; f < NF; ++f) {
         const int qi = wq0 + f * 16 + l15;
         if (qi >= seg.q_len) continue;
         bf16_t* op = a.dq + (long)(seg.q_start + qi) * a.q_stride + (long)h * D;
@@ -355,22 +399,33 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
 
     const int q_first = (own && a.causal) ? (kb0 / BKV) * BKV : 0;   // first query row that can see key kb0
     const int rep = a.Hq / a.Hkv;
-    for (int hh = 0; hh < rep; ++hh) {
-        const int h = hk * rep + hh;
-        for (int q0 = q_first; q0 < qs.q_len; q0 += BKV) {
-            uint4 qreg[4], dreg[4];
+    const float c2 = a.scale * 1.4426950408889634f, log2e = 1.4426950408889634f;
+    const int q_tiles = (qs.q_len - q_first + BKV - 1) / BKV, n_iter = rep * q_tiles;   // (q head, query tile) pairs
+    const bool keys_full = (kv_lo == key_abs0) && (kv_hi == key_abs0 + BKV);
+
+    uint4 qreg[4], dreg[4];                                    // next (head, query tile), in flight under the MFMAs
+    auto prefetch = [&](int it) {
+        const int h = hk * rep + it / q_tiles, q0 = q_first + (it % q_tiles) * BKV;
+        const long tok0 = qs.q_start + q0;
+        tile_load<D>(qreg, a.q + tok0 * a.q_stride + (long)h * D, a.q_stride, qs.q_len - q0, tid);
+        tile_load<D>(dreg, a.d_o + tok0 * a.o_stride + (long)h * D, a.o_stride, qs.q_len - q0, tid);
+    };
+    if (n_iter > 0) prefetch(0);
+    for (int it = 0; it < n_iter; ++it) {
+        {
+            const int h = hk * rep + it / q_tiles, q0 = q_first + (it % q_tiles) * BKV;
             const long tok0 = qs.q_start + q0;
-            tile_load<D>(qreg, a.q + tok0 * a.q_stride + (long)h * D, a.q_stride, qs.q_len - q0, tid);
-            tile_load<D>(dreg, a.d_o + tok0 * a.o_stride + (long)h * D, a.o_stride, qs.q_len - q0, tid);
             __syncthreads();
             tile_store<D, true, true>(qreg, q_lds, qt_lds, tid);
             tile_store<D, true, true>(dreg, do_lds, dot_lds, tid);
             if (tid < 128) {
                 const int r = tid & 63;
                 const long tk = min(tok0 + r, (long)qs.q_start + qs.q_len - 1);
-                stat[tid] = (tid < 64 ? a.lse : a.delta)[(long)h * a.T + tk];
+                stat[tid] = tid < 64 ? a.lse[(long)h * a.T + tk] * log2e : a.delta[(long)h * a.T + tk];
             }
             __syncthreads();
+            if (it + 1 < n_iter) prefetch(it + 1);
+            const bool need_mask = !keys_full || (q0 + BKV > qs.q_len) || (own && a.causal && kb0 + BKV - 1 > q0);
 
             float pv[4][4], dsv[4][4];
 #pragma unroll
@@ -384,8 +439,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int qr = qf * 16 + g * 4 + r, qi = q0 + qr;     // lane holds S[q = qr][key = l15]
-                    const bool ok = key_ok && qi < qs.q_len && !(own && a.causal && my_key_rel > qi);
-                    const float p = ok ? __expf(st[r] * a.scale - stat[qr]) : 0.f;
+                    float sv = st[r];
+                    if (need_mask) sv = (key_ok && qi < qs.q_len && !(own && a.causal && my_key_rel > qi)) ? sv : -INFINITY;
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sv, c2, -stat[qr]));
                     pv[qf][r] = p;
                     dsv[qf][r] = p * (dp[r] - stat[64 + qr]) * a.scale;
                 }
@@ -435,6 +491,7 @@ extern "C" int spacer_attn_fwd(const void* q, const void* k, const void* v, void
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (bf16_t*)o; a.lse = lse;
     a.q_stride = q_stride; a.kv_stride = kv_stride; a.o_stride = o_stride; a.segs = segs_dev; a.num_segs = num_segs;
     a.nqb = cdiv(max_q_len, BQ); a.T = T; a.Hq = Hq; a.Hkv = Hkv; a.causal = causal; a.scale = scale;
+    a.lpt = getenv("SPACER_ATTN_FIFO") ? 0 : 1;
     const dim3 grid(num_segs * a.nqb, Hq);
     if (D == 128) hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(attn_fwd_kernel<80>, grid, dim3(256), 0, (hipStream_t)stream, a);
@@ -454,22 +511,24 @@ extern "C" int spacer_attn_bwd(const void* q, const void* k, const void* v, cons
     a.d_o = (const bf16_t*)d_o; a.delta = delta; a.dq = (bf16_t*)dq; a.dk = dk; a.dv = dv;
     a.q_stride = q_stride; a.kv_stride = kv_stride; a.o_stride = o_stride; a.segs = segs_dev; a.num_segs = num_segs;
     a.T = T; a.Hq = Hq; a.Hkv = Hkv; a.causal = causal; a.scale = scale;
+    a.lpt = getenv("SPACER_ATTN_FIFO") ? 0 : 1;
     hipStream_t s = (hipStream_t)stream;
     const int dgrid = (int)(((long)T * Hq * 16 + 255) / 256 < 4096 ? ((long)T * Hq * 16 + 255) / 256 : 4096);
-    a.nqb = cdiv(max_q_len, BQ);
+    constexpr int NFQ = 1;
+    a.nqb = cdiv(max_q_len, 64 * NFQ);
     const dim3 qgrid(num_segs * a.nqb, Hq);
     AttnArgs b = a;
     b.nqb = cdiv(max_q_len, BKV);
     const dim3 kgrid(num_segs * b.nqb, Hkv, num_segs);
     if (D == 128) {
         hipLaunchKernelGGL(attn_delta_kernel<128>, dim3(dgrid), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, qgrid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<128, NFQ>), qgrid, dim3(256), 0, s, a);
         static const int once128 = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AT_RM_BYTES + 2 * AT_T_BYTES(128) + 512);
         (void)once128;
         hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, kgrid, dim3(256), 2 * AT_RM_BYTES + 2 * AT_T_BYTES(128) + 512, s, b);
     } else {
         hipLaunchKernelGGL(attn_delta_kernel<80>, dim3(dgrid), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<80>, qgrid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<80, NFQ>), qgrid, dim3(256), 0, s, a);
         hipLaunchKernelGGL(attn_bwd_dkv_kernel<80>, kgrid, dim3(256), 2 * AT_RM_BYTES + 2 * AT_T_BYTES(80) + 512, s, b);
     }
     SP_CHECK_LAUNCH();

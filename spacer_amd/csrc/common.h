@@ -32,15 +32,16 @@ void spacer_set_error(const char* fmt, ...);
 
 // ---- bf16 <-> f32 ----
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
-    u += 0x7fffu + ((u >> 16) & 1u);                                         // round to nearest even
-    return (bf16_t)(u >> 16);
-}
+// f32 -> bf16 is the gfx950 hardware conversion (v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN), one
+// instruction per PAIR of values; a software RNE costs ~7 VALU ops per value and was a third of the attention
+// kernels' VALU work.
+typedef __attribute__((ext_vector_type(2))) __bf16 hw_bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    const f32x2 f = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, hw_bf16x2));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
 __device__ __forceinline__ float bf_lo(uint32_t p) { return __uint_as_float(p << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t p) { return __uint_as_float(p & 0xffff0000u); }
 
