@@ -260,55 +260,54 @@ __global__ __launch_bounds__(NT) void scatter_add_rows_kernel(const bf16_t* __re
 }
 
 // ------------------------------------------------------------------ transpose with zero padding
-// out[c, r] = in[r, c] for r < R, 0 for R <= r < Rpad.  64x64 tiles: 16-byte global loads, 2-byte transposed LDS
-// writes, 16-byte LDS reads and 16-byte coalesced global stores (rows of 8 source rows per store).
+// out[c, r] = in[r, c] for r < R, 0 for R <= r < Rpad.  64x64 tiles.  A thread loads the same 8 columns of TWO adjacent
+// rows (2 x 16 B), so every transposed LDS store is a full dword {in[r][c], in[r+1][c]} (no sub-dword writes); the LDS
+// image is tile[c][32 dwords] with the 16-byte group index XOR-swizzled by c/8, which makes both the dword stores
+// (2-way at most) and the 16-byte row reads conflict-free; global stores are 16 B, 128 B contiguous per 8 lanes.
 __global__ __launch_bounds__(NT) void transpose_kernel(const bf16_t* __restrict__ in, long ld_in,
                                                        bf16_t* __restrict__ out, long ld_out, int R, int C, int Rpad) {
-    constexpr int ROW = 64 + 8;                          // bf16 per LDS row (144 B: keeps 16-byte alignment, skews banks)
-    __shared__ __attribute__((aligned(16))) bf16_t tile[64 * ROW];   // tile[c][r]
+    __shared__ __attribute__((aligned(16))) uint32_t tile[64 * 32];   // tile[c][row pair], swizzled
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     const int t = threadIdx.x;
     const bool fast = (ld_in % 8 == 0) && (ld_out % 8 == 0) && (((uintptr_t)in | (uintptr_t)out) % 16 == 0);
-    if (fast) {
+    {
+        const int p = t >> 3, cc = (t & 7) * 8;                       // row pair (rows 2p, 2p+1), first of 8 columns
+        uint32_t w[2][4];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int r = (t >> 3) + 32 * j, cc = (t & 7) * 8;       // 8 lanes cover one 128-byte source row segment
+        for (int h = 0; h < 2; ++h) {
+            const int r = r0 + 2 * p + h;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (r0 + r < R) {
-                if (c0 + cc + 8 <= C) v = *(const uint4*)(in + (long)(r0 + r) * ld_in + c0 + cc);
+            if (r < R) {
+                if (fast && c0 + cc + 8 <= C) v = *(const uint4*)(in + (long)r * ld_in + c0 + cc);
                 else {
                     bf16_t tmp[8];
-                    for (int e = 0; e < 8; ++e) tmp[e] = (c0 + cc + e < C) ? in[(long)(r0 + r) * ld_in + c0 + cc + e] : (bf16_t)0;
-                    v = *(const uint4*)tmp;
+                    for (int e = 0; e < 8; ++e) tmp[e] = (c0 + cc + e < C) ? in[(long)r * ld_in + c0 + cc + e] : (bf16_t)0;
+                    v = make_uint4(tmp[0] | (uint32_t)tmp[1] << 16, tmp[2] | (uint32_t)tmp[3] << 16, tmp[4] | (uint32_t)tmp[5] << 16,
+                                   tmp[6] | (uint32_t)tmp[7] << 16);
                 }
             }
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) tile[(cc + e) * ROW + r] = (bf16_t)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu));
+            w[h][0] = v.x; w[h][1] = v.y; w[h][2] = v.z; w[h][3] = v.w;
         }
-        __syncthreads();
+        const int grp = ((p >> 2) ^ (t & 7)) * 4 + (p & 3);            // swizzle key (c >> 3) & 7 == t & 7 for all 8 columns
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int c = (t >> 3) + 32 * j, rr = (t & 7) * 8;
-            if (c0 + c < C && r0 + rr < Rpad) {
-                const uint4 v = *(const uint4*)(tile + c * ROW + rr);
-                if (r0 + rr + 8 <= Rpad) *(uint4*)(out + (long)(c0 + c) * ld_out + r0 + rr) = v;
-                else {
-                    const bf16_t* pv = (const bf16_t*)&v;
-                    for (int e = 0; e < 8 && r0 + rr + e < Rpad; ++e) out[(long)(c0 + c) * ld_out + r0 + rr + e] = pv[e];
-                }
+        for (int e = 0; e < 8; ++e) {
+            const uint32_t lo = (e & 1) ? (w[0][e >> 1] >> 16) : (w[0][e >> 1] & 0xffffu);
+            const uint32_t hi = (e & 1) ? (w[1][e >> 1] & 0xffff0000u) : (w[1][e >> 1] << 16);
+            tile[(cc + e) * 32 + grp] = lo | hi;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = (t >> 3) + 32 * j, g4 = t & 7, rr = g4 * 8;     // 8 lanes write 128 contiguous bytes of out row c
+        if (c0 + c < C && r0 + rr < Rpad) {
+            const uint4 v = *(const uint4*)(tile + c * 32 + ((g4 ^ ((c >> 3) & 7)) * 4));
+            bf16_t* dst = out + (long)(c0 + c) * ld_out + r0 + rr;
+            if (fast && r0 + rr + 8 <= Rpad) *(uint4*)dst = v;
+            else {
+                const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+                for (int e = 0; e < 8 && r0 + rr + e < Rpad; ++e) dst[e] = (bf16_t)((e & 1) ? (wv[e >> 1] >> 16) : (wv[e >> 1] & 0xffffu));
             }
-        }
-    } else {
-        const int tx = t & 63, ty = t >> 6;
-        for (int j = ty; j < 64; j += 4) {
-            const int r = r0 + j, c = c0 + tx;
-            tile[tx * ROW + j] = (r < R && c < C) ? in[(long)r * ld_in + c] : (bf16_t)0;
-        }
-        __syncthreads();
-        for (int j = ty; j < 64; j += 4) {
-            const int c = c0 + j, r = r0 + tx;
-            if (c < C && r < Rpad) out[(long)c * ld_out + r] = tile[j * ROW + tx];
         }
     }
 }

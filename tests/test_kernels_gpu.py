@@ -125,6 +125,13 @@ def test_transpose_pad(dev):
     t = K.transpose_pad(x, 256)
     assert t.shape == (136, 256)
     assert torch.equal(t[:, :200], x.t()) and float(t[:, 200:].float().abs().sum()) == 0.0
+    # odd row count, ragged column tile, strided source view (a q|k|v slice), default padding to a multiple of 64
+    big = rnd((1403, 3 * 200), dev, 2)
+    for view in (big[:, 200:400], big[:, 8:208], big[:77, :64], big[:, 3:131]):     # last one: unaligned -> scalar path
+        tt = K.transpose_pad(view)
+        R = view.shape[0]
+        assert tt.shape == (view.shape[1], (R + 63) // 64 * 64)
+        assert torch.equal(tt[:, :R], view.t()) and float(tt[:, R:].float().abs().sum()) == 0.0
 
 
 # ----------------------------------------------------------------------------------------------- norms
