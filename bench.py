@@ -36,6 +36,8 @@ WORKLOADS = {
     "tiny": ("tiny", 4, 56, 84, 24, 4, 32, 2),
 }
 MFMA_PEAK_TFLOPS = 2500.0     # dense bf16, MI355X_MICROARCH.md
+ROLLOUT_FWD_TF = {"cfg3": 5.69 + 18.7, "cfg4": 5.69 + 18.7}     # ViT fwd + prefill per prompt (TFLOP)
+DECODE_WEIGHT_GB = {"Qwen2-VL-7B": 14.14}                      # 2 (W_L + W_H) bytes streamed per decode step
 ALGO_TF_PER_SAMPLE = {"cfg3": 53.1, "cfg4": 53.1}   # SURVEY 8(d), temporal branch off
 
 
@@ -122,6 +124,7 @@ def main():
     sp = SamplingParams(max_new_tokens=C, top_k=50, top_p=0.95, temperature=1.0, seed=1234 + rank, suppress_eos=True)
     frames = [synthetic_frames(rank * groups + g, F, Hpx, Wpx, dev) for g in range(groups)]   # resident in HBM
     phase = {}
+    roll_stats = {}
 
     def tick(name, t0):
         if args.phase_times:
@@ -133,7 +136,7 @@ def main():
     def step(step_idx):
         t0 = time.perf_counter()
         prompts = [make_prompt(cfg, rank * groups + g, F, Hpx, Wpx, n_text, dev, frames_u8=frames[g])[0] for g in range(groups)]
-        comp = ge.roll.generate(prompts, Kgen, sp, use_graph=not args.no_graph)
+        comp = ge.roll.generate(prompts, Kgen, sp, use_graph=not args.no_graph, stats=roll_stats)
         t0 = tick("rollout", t0)
         for g in range(groups):
             cg = comp[g * Kgen:(g + 1) * Kgen]
@@ -156,6 +159,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     phase.clear()
+    roll_stats.clear()
     K.PROFILER.reset(enabled=True)
     K.PROFILER.by_shape = args.gemm_shapes
     barrier()
@@ -201,6 +205,21 @@ def main():
             "kernels": {k: {"tflops": round(v["tflops"], 2), "launches": v["launches"], "seconds": round(v["seconds"], 4)}
                         for k, v in prof.items()},
         }
+        if roll_stats.get("events"):
+            # the north-star's "fused rollout forward": ViT + LLM prefill of every prompt (MFMA-bound), and the decode loop
+            # (HBM-bound: packed weights + KV), each from HIP events on the launch stream inside the timed region
+            pre = sum(a.elapsed_time(b) for a, b, _ in roll_stats["events"]) * 1e-3
+            dec = sum(b.elapsed_time(c) for _, b, c in roll_stats["events"]) * 1e-3
+            n_prompts = groups * args.steps
+            if args.workload in ROLLOUT_FWD_TF:
+                tf = ROLLOUT_FWD_TF[args.workload] * n_prompts / pre
+                out["rollout_forward"] = {"seconds_per_step": round(pre / args.steps, 4), "tflops": round(tf, 1),
+                                          "frac_of_mfma_peak": round(tf / MFMA_PEAK_TFLOPS, 4),
+                                          "algorithmic_tflop_per_prompt": ROLLOUT_FWD_TF[args.workload]}
+            steps_dec = roll_stats.get("decode_steps", 0)
+            out["decode"] = {"seconds_per_step": round(dec / args.steps, 4), "ms_per_token_step": round(1e3 * dec / max(1, steps_dec), 3),
+                             "weight_stream_tbps": round(DECODE_WEIGHT_GB.get(preset, 0.0) * steps_dec / dec / 1e3, 3),
+                             "peak_tbps": 8.0}
         if args.workload in ALGO_TF_PER_SAMPLE:
             out["step_algorithmic_tflops"] = round(ALGO_TF_PER_SAMPLE[args.workload] * value / world, 2)
         if args.phase_times:

@@ -67,31 +67,42 @@ class RolloutEngine:
 
     # ------------------------------------------------------------------ prefill
     def _prefill(self, prompts: List[PromptInput], era_rule: bool):
+        """ViT + LLM prefill of ALL prompts as one token-packed pass (one attention segment per prompt, one set of GEMMs
+        with M = total prompt tokens): the reference runs this per rollout inside HF generate (TR:463)."""
         cfg, e = self.cfg, self.e
         L, Hkv, D = cfg.layers, cfg.kv_heads, cfg.head_dim
         nP = len(prompts)
-        Pmax = max(p.ids.numel() for p in prompts)
+        plen = [p.ids.numel() for p in prompts]
+        Pmax = max(plen)
+        starts = [0]
+        for P in plen[:-1]:
+            starts.append(starts[-1] + P)
         pk = torch.zeros(L, nP, Pmax, Hkv, D, device=self.dev, dtype=BF16)
         pv = torch.zeros_like(pk)
-        first_logits = torch.empty(nP, cfg.vocab, device=self.dev, dtype=F32)
-        plen, pos_base = [], []
-        for pi, pr in enumerate(prompts):
-            P = pr.ids.numel()
-            video = e.vit_forward(pr.pix, pr.grids) if pr.pix is not None else None
-            x0, _ = e.embed(pr.ids, video)
+        with_video = [p for p in prompts if p.pix is not None]
+        video = None
+        if with_video:
+            pix = with_video[0].pix if len(with_video) == 1 else torch.cat([p.pix for p in with_video], 0)
+            video = e.vit_forward(pix, [g for p in with_video for g in p.grids])
+        ids = prompts[0].ids if nP == 1 else torch.cat([p.ids for p in prompts], 0)
+        x0, _ = e.embed(ids, video)               # video rows fill the placeholder tokens in prompt order
+        pos_list, pos_base = [], []
+        for pr, P in zip(prompts, plen):
             pos3, delta = POS.mrope_positions(pr.ids.tolist(), list(pr.grids or []), cfg, era_rule)
-            cos, sin = POS.mrope_tables(pos3, cfg, self.dev)
-            segs = K.make_segments([(0, P, 0, 0)], self.dev)
-
-            def sink(layer, k, v, pi=pi, P=P):
-                pk[layer, pi, :P].view(P, Hkv * D).copy_(k)
-                pv[layer, pi, :P].view(P, Hkv * D).copy_(v)
-
-            x = e.llm_forward(x0, cos, sin, segs, P, kv_sink=sink)
-            hn = K.rmsnorm_fwd(x[P - 1:P], e.W["llm.norm_w"], cfg.rms_eps)
-            K.gemm_nt(hn, e.W["llm.lm_head"], out=first_logits[pi:pi + 1])
-            plen.append(P)
+            pos_list.append(pos3)
             pos_base.append(P + delta)
+        cos, sin = POS.mrope_tables(torch.cat(pos_list, 1), cfg, self.dev)
+        segs = K.make_segments([(s0, P, 0, 0) for s0, P in zip(starts, plen)], self.dev)
+
+        def sink(layer, k, v):
+            for pi, (s0, P) in enumerate(zip(starts, plen)):
+                pk[layer, pi, :P].view(P, Hkv * D).copy_(k[s0:s0 + P])
+                pv[layer, pi, :P].view(P, Hkv * D).copy_(v[s0:s0 + P])
+
+        x = e.llm_forward(x0, cos, sin, segs, Pmax, kv_sink=sink)
+        last = torch.tensor([s0 + P - 1 for s0, P in zip(starts, plen)], dtype=torch.int64, device=self.dev)
+        hn = K.rmsnorm_fwd(x.index_select(0, last), e.W["llm.norm_w"], cfg.rms_eps)
+        first_logits = K.gemm_nt(hn, e.W["llm.lm_head"], out_dtype=F32)
         return pk, pv, first_logits, plen, pos_base
 
     # ------------------------------------------------------------------ one decode step (graph-capturable)
@@ -143,7 +154,12 @@ class RolloutEngine:
                 outs.append(self.generate(prompts[a:a + per], Kn, sp, use_graph=use_graph, stats=stats))
             return torch.cat(outs, 0)
         dev = self.dev
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if stats is not None else None
+        if ev:
+            ev[0].record()
         pk, pv, first_logits, plen, pos_base = self._prefill(prompts, sp.era_rule)
+        if ev:
+            ev[1].record()
         L, Hkv, D, H = cfg.layers, cfg.kv_heads, cfg.head_dim, cfg.hidden
         st = dict(
             B=B, pk=pk, pv=pv, packed=self._pack(), Kn=Kn, shared_prefix=Kn * (cfg.heads // cfg.kv_heads) <= 64 and Kn > 1,
@@ -185,6 +201,8 @@ class RolloutEngine:
             if not sp.suppress_eos and s % 32 == 0 and bool(st["finished"].all()):
                 break
         if stats is not None:
+            ev[2].record()
             stats["decode_steps"] = stats.get("decode_steps", 0) + n_steps
             stats["graph"] = graph is not None
+            stats.setdefault("events", []).append(tuple(ev))      # (start, prefill done, decode done), HIP events
         return out
