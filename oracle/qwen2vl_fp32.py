@@ -61,6 +61,10 @@ def make_config(
     tie_embeddings: bool = False,
     video_token_id: int = 151656,
     image_token_id: int = 151655,
+    vit_kind: str = "qwen2",
+    vit_window: int = 112,
+    vit_fullatt: Sequence[int] = (),
+    tokens_per_second: int = 2,
 ) -> dict:
     hd = head_dim or hidden // heads
     return dict(
@@ -69,7 +73,8 @@ def make_config(
         vit_heads=vit_heads, vit_mlp=vit_mlp, mrope_section=tuple(mrope_section),
         rope_theta=float(rope_theta), rms_eps=float(rms_eps), patch=patch, tpatch=tpatch,
         merge=merge, tie_embeddings=tie_embeddings, video_token_id=video_token_id,
-        image_token_id=image_token_id,
+        image_token_id=image_token_id, vit_kind=vit_kind, vit_window=vit_window, vit_fullatt=tuple(vit_fullatt),
+        tokens_per_second=tokens_per_second,
     )
 
 
@@ -137,8 +142,73 @@ def vit_segments(grid_thw) -> List[int]:
     return seg
 
 
+def vit_window_index(grid_thw, cfg: dict):
+    """Qwen2.5-VL window regrouping (HF vision_utils.get_vision_window_index, used at modeling_qwen2_5_vl.py:425-431):
+    returns (window_index over merge units, window lengths in PATCHES, in permuted order; empty windows dropped)."""
+    m = cfg["merge"]
+    ws = cfg["vit_window"] // m // cfg["patch"]
+    index, lens, base = [], [], 0
+    for t, h, w_ in grid_thw:
+        lh, lw = h // m, w_ // m
+        idx = torch.arange(t * lh * lw).reshape(t, lh, lw)
+        ph, pw = ws - lh % ws, ws - lw % ws
+        nh, nw = (lh + ph) // ws, (lw + pw) // ws
+        pad = F.pad(idx, (0, pw, 0, ph), "constant", -100).reshape(t, nh, ws, nw, ws).permute(0, 1, 3, 2, 4)
+        pad = pad.reshape(t, nh * nw, ws, ws)
+        lens += [int(n) * m * m for n in (pad != -100).sum([2, 3]).reshape(-1).tolist() if n]
+        flat = pad.reshape(-1)
+        index.append(flat[flat != -100] + base)
+        base += t * lh * lw
+    return torch.cat(index), lens
+
+
+def _vit_attention(q, k, v, segs, hd):
+    outs, s0 = [], 0
+    for L in segs:
+        qs, ks, vs = (z[s0:s0 + L].transpose(0, 1) for z in (q, k, v))      # (heads, L, hd)
+        a = torch.softmax(qs @ ks.transpose(1, 2) / math.sqrt(hd), dim=-1)
+        outs.append((a @ vs).transpose(0, 1).reshape(L, -1))
+        s0 += L
+    return torch.cat(outs, 0)
+
+
+def vit_forward_qwen2_5(w: Weights, cfg: dict, pixel_rows: torch.Tensor, grid_thw, *, return_hidden=False):
+    """Qwen2_5_VisionTransformerPretrainedModel.forward (HF modeling_qwen2_5_vl.py:408-472): patch embed, regroup merge
+    units into windows, 2-D rotary in the permuted order, RMSNorm + biased SwiGLU blocks with window attention except
+    on cfg['vit_fullatt'] (per-frame attention), RMSNorm merger, inverse permutation of the merged rows."""
+    D, Hh = cfg["vit_dim"], cfg["vit_heads"]
+    hd, mu = D // Hh, cfg["merge"] ** 2
+    x = pixel_rows.float() @ w["visual.patch_embed.proj.weight"].float().reshape(D, -1).t()
+    win, win_lens = vit_window_index(grid_thw, cfg)
+    rows = (win[:, None] * mu + torch.arange(mu)[None, :]).reshape(-1)
+    x = x[rows]
+    cos, sin = vit_rope_tables(grid_thw, hd, cfg["merge"])
+    cos, sin = cos[rows][:, None, :], sin[rows][:, None, :]
+    frame_lens = vit_segments(grid_thw)
+    for i in range(cfg["vit_depth"]):
+        p = f"visual.blocks.{i}."
+        h = rms_norm(x, w[p + "norm1.weight"], 1e-6)
+        qkv = h @ w[p + "attn.qkv.weight"].float().t() + w[p + "attn.qkv.bias"].float()
+        q, k, v = qkv.view(-1, 3, Hh, hd).unbind(1)
+        q = q * cos + _rot_half(q) * sin
+        k = k * cos + _rot_half(k) * sin
+        a = _vit_attention(q, k, v, frame_lens if i in cfg["vit_fullatt"] else win_lens, hd)
+        x = x + a @ w[p + "attn.proj.weight"].float().t() + w[p + "attn.proj.bias"].float()
+        h = rms_norm(x, w[p + "norm2.weight"], 1e-6)
+        g = h @ w[p + "mlp.gate_proj.weight"].float().t() + w[p + "mlp.gate_proj.bias"].float()
+        u = h @ w[p + "mlp.up_proj.weight"].float().t() + w[p + "mlp.up_proj.bias"].float()
+        x = x + (F.silu(g) * u) @ w[p + "mlp.down_proj.weight"].float().t() + w[p + "mlp.down_proj.bias"].float()
+    h = rms_norm(x, w["visual.merger.ln_q.weight"], 1e-6).reshape(-1, mu * D)
+    h = gelu_erf(h @ w["visual.merger.mlp.0.weight"].float().t() + w["visual.merger.mlp.0.bias"].float())
+    out = h @ w["visual.merger.mlp.2.weight"].float().t() + w["visual.merger.mlp.2.bias"].float()
+    out = out[torch.argsort(win)]
+    return (out, x) if return_hidden else out
+
+
 def vit_forward(w: Weights, cfg: dict, pixel_rows: torch.Tensor, grid_thw, *, return_hidden=False):
     """pixel_rows: (Np, 3*tpatch*patch*patch) already normalised; returns (Np/merge^2, hidden)."""
+    if cfg.get("vit_kind", "qwen2") == "qwen2_5":
+        return vit_forward_qwen2_5(w, cfg, pixel_rows, grid_thw, return_hidden=return_hidden)
     D, Hh = cfg["vit_dim"], cfg["vit_heads"]
     hd = D // Hh
     x = pixel_rows.float() @ w["visual.patch_embed.proj.weight"].float().reshape(D, -1).t()
@@ -173,7 +243,8 @@ def vit_forward(w: Weights, cfg: dict, pixel_rows: torch.Tensor, grid_thw, *, re
 # --------------------------------------------------------------------------------------
 # M-RoPE position ids
 # --------------------------------------------------------------------------------------
-def mrope_position_ids(input_ids: Sequence[int], grid_thw, cfg: dict, *, era_rule: bool = False):
+def mrope_position_ids(input_ids: Sequence[int], grid_thw, cfg: dict, *, era_rule: bool = False,
+                       second_per_grid_ts: Optional[Sequence[float]] = None):
     """(3, S) t/h/w positions and rope_delta for ONE unpadded sequence.
 
     A run of vision placeholder tokens starting at running position s gets
@@ -181,23 +252,30 @@ def mrope_position_ids(input_ids: Sequence[int], grid_thw, cfg: dict, *, era_rul
     The next text position is s + max(gh, gw)/m (transformers 5.x) or, with ``era_rule``,
     max(all vision positions)+1 (transformers 4.x, the reference's era).  The two agree
     whenever gt <= max(gh, gw)/m  (SURVEY.md 2.3 drift warning).
+    Qwen2.5-VL video runs: temporal index * tokens_per_second * second_per_grid_t (default 1 s): transformers 5.x
+    multiplies by tps * int(seconds) (modeling_qwen2_5_vl.py:1023-1030), the 4.x era floors index * seconds * tps.
     """
     ids = list(int(i) for i in input_ids)
     vis = {cfg["video_token_id"], cfg["image_token_id"]}
     m = cfg["merge"]
     grids = iter(grid_thw)
-    pos, cur, i = [], 0, 0
+    pos, cur, i, n_vis = [], 0, 0, 0
     while i < len(ids):
         if ids[i] in vis:
             gt, gh, gw = next(grids)
             lh, lw = gh // m, gw // m
             n = gt * lh * lw
             assert all(t in vis for t in ids[i:i + n]), "placeholder run shorter than grid"
-            tt = torch.arange(gt).view(gt, 1, 1).expand(gt, lh, lw).reshape(-1) + cur
+            ti = torch.arange(gt)
+            if cfg.get("vit_kind", "qwen2") == "qwen2_5" and ids[i] == cfg["video_token_id"]:
+                sec = 1.0 if second_per_grid_ts is None else float(second_per_grid_ts[n_vis])
+                ti = (ti.double() * sec * cfg["tokens_per_second"]).long() if era_rule else ti * (cfg["tokens_per_second"] * int(sec))
+            n_vis += 1
+            tt = ti.view(gt, 1, 1).expand(gt, lh, lw).reshape(-1) + cur
             hh = torch.arange(lh).view(1, lh, 1).expand(gt, lh, lw).reshape(-1) + cur
             ww = torch.arange(lw).view(1, 1, lw).expand(gt, lh, lw).reshape(-1) + cur
             pos.append(torch.stack([tt, hh, ww]))
-            cur = cur + (max(gt, lh, lw) if era_rule else max(lh, lw))
+            cur = cur + (max(int(ti.max()) + 1, lh, lw) if era_rule else max(lh, lw))
             i += n
         else:
             j = i
@@ -333,10 +411,18 @@ def random_weights(cfg: dict, seed: int = 1234, dtype=torch.float32, std: float 
         w[p + "norm2.weight"] = torch.ones(D, dtype=dtype); w[p + "norm2.bias"] = torch.zeros(D, dtype=dtype)
         w[p + "attn.qkv.weight"] = n(3 * D, D); w[p + "attn.qkv.bias"] = n(3 * D)
         w[p + "attn.proj.weight"] = n(D, D); w[p + "attn.proj.bias"] = n(D)
+        if cfg.get("vit_kind", "qwen2") == "qwen2_5":
+            del w[p + "norm1.bias"], w[p + "norm2.bias"]
+            for nm in ("gate_proj", "up_proj"):
+                w[p + f"mlp.{nm}.weight"] = n(cfg["vit_mlp"], D); w[p + f"mlp.{nm}.bias"] = n(cfg["vit_mlp"])
+            w[p + "mlp.down_proj.weight"] = n(D, cfg["vit_mlp"]); w[p + "mlp.down_proj.bias"] = n(D)
+            continue
         w[p + "mlp.fc1.weight"] = n(cfg["vit_mlp"], D); w[p + "mlp.fc1.bias"] = n(cfg["vit_mlp"])
         w[p + "mlp.fc2.weight"] = n(D, cfg["vit_mlp"]); w[p + "mlp.fc2.bias"] = n(D)
     m = cfg["merge"] ** 2
     w["visual.merger.ln_q.weight"] = torch.ones(D, dtype=dtype); w["visual.merger.ln_q.bias"] = torch.zeros(D, dtype=dtype)
+    if cfg.get("vit_kind", "qwen2") == "qwen2_5":
+        del w["visual.merger.ln_q.bias"]
     w["visual.merger.mlp.0.weight"] = n(m * D, m * D); w["visual.merger.mlp.0.bias"] = n(m * D)
     w["visual.merger.mlp.2.weight"] = n(Hd, m * D); w["visual.merger.mlp.2.bias"] = n(Hd)
     w["model.embed_tokens.weight"] = n(V, Hd)

@@ -17,8 +17,13 @@ from .config import Qwen2VLConfig
 
 
 def mrope_positions(ids: Sequence[int], grids: Sequence[Tuple[int, int, int]], cfg: Qwen2VLConfig,
-                    era_rule: bool = False) -> Tuple[torch.Tensor, int]:
-    """Returns (pos [3, S] int64 on CPU, rope_delta) for one unpadded sequence."""
+                    era_rule: bool = False, second_per_grid_ts: Sequence[float] = None) -> Tuple[torch.Tensor, int]:
+    """Returns (pos [3, S] int64 on CPU, rope_delta) for one unpadded sequence.
+
+    Qwen2.5-VL (cfg.vit_kind == "qwen2_5") spaces the temporal positions of a VIDEO run by
+    tokens_per_second * second_per_grid_t (HF modeling_qwen2_5_vl.py:1023-1030; default 1 s per grid step -- what the
+    reference's scoring forward uses, it deletes the processor's value at SG_RLVR_trainer.py:519-520): transformers 5.x
+    truncates the seconds to an int before multiplying, the 4.x era floors the product per step (``era_rule``)."""
     vis = (cfg.video_token_id, cfg.image_token_id)
     m = cfg.merge
     S = len(ids)
@@ -33,10 +38,14 @@ def mrope_positions(ids: Sequence[int], grids: Sequence[Tuple[int, int, int]], c
             if i + n > S or any(t not in vis for t in ids[i:i + n]):
                 raise ValueError("vision placeholder run does not match its grid")
             ar = torch.arange(n)
-            pos[0, i:i + n] = ar // (lh * lw) + cur
+            t_idx = ar // (lh * lw)
+            if cfg.vit_kind == "qwen2_5" and ids[i] == cfg.video_token_id:
+                sec = 1.0 if second_per_grid_ts is None else float(second_per_grid_ts[gi - 1])
+                t_idx = (t_idx.double() * sec * cfg.tokens_per_second).long() if era_rule else t_idx * (cfg.tokens_per_second * int(sec))
+            pos[0, i:i + n] = t_idx + cur
             pos[1, i:i + n] = (ar // lw) % lh + cur
             pos[2, i:i + n] = ar % lw + cur
-            cur += max(gt, lh, lw) if era_rule else max(lh, lw)
+            cur += max(int(t_idx.max()) + 1, lh, lw) if era_rule else max(lh, lw)
             i += n
         else:
             j = i
@@ -90,6 +99,40 @@ def vit_tables(grids, cfg: Qwen2VLConfig, device) -> Tuple[torch.Tensor, torch.T
     ang = (hw[:, :, None] * inv).reshape(hw.shape[0], -1)                                 # [Np, q]
     ang = torch.cat([ang, ang], dim=1)
     return ang.cos().contiguous(), ang.sin().contiguous()
+
+
+def vit_window_plan(grids, cfg: Qwen2VLConfig):
+    """Qwen2.5-VL window attention layout (HF vision_utils.get_vision_window_index, modeling_qwen2_5_vl.py:425-466).
+
+    Merge units (m x m patches) of every temporal grid step are regrouped so that each (window/m/patch)^2-unit window is
+    contiguous; border windows are ragged.  Returns
+      unit_perm  int64 [Nu]: permuted position u holds original merge unit unit_perm[u]
+      row_perm   int64 [Np]: the same at patch-row granularity (m*m rows per unit)
+      win_segs   attention segments (start, len, 0, 0) of the windows, in permuted patch rows
+    Frames stay contiguous under the permutation, so the full-attention blocks use vit_segments(grids) unchanged."""
+    m, mu = cfg.merge, cfg.merge ** 2
+    ws = cfg.vit_window // cfg.merge // cfg.patch
+    perm: List[torch.Tensor] = []
+    segs: List[Tuple[int, int, int, int]] = []
+    base, row = 0, 0
+    for gt, gh, gw in grids:
+        lh, lw = gh // m, gw // m
+        idx = torch.arange(gt * lh * lw).reshape(gt, lh, lw)
+        ph, pw = ws - lh % ws, ws - lw % ws                    # HF pads a whole extra window when divisible (empty windows)
+        nh, nw = (lh + ph) // ws, (lw + pw) // ws
+        pad = torch.nn.functional.pad(idx, (0, pw, 0, ph), "constant", -100)
+        pad = pad.reshape(gt, nh, ws, nw, ws).permute(0, 1, 3, 2, 4).reshape(gt, nh * nw, ws, ws)
+        lens = (pad != -100).sum([2, 3]).reshape(-1)
+        flat = pad.reshape(-1)
+        perm.append(flat[flat != -100] + base)
+        for n in lens.tolist():
+            if n:
+                segs.append((row, n * mu, 0, 0))
+                row += n * mu
+        base += gt * lh * lw
+    unit_perm = torch.cat(perm)
+    row_perm = (unit_perm[:, None] * mu + torch.arange(mu)[None, :]).reshape(-1)
+    return unit_perm, row_perm, segs
 
 
 def vit_segments(grids) -> List[Tuple[int, int, int, int]]:

@@ -37,16 +37,24 @@ def param_specs(cfg: Qwen2VLConfig) -> List[ParamSpec]:
     D, H, I, V = cfg.vit_dim, cfg.hidden, cfg.intermediate, cfg.vocab
     m4 = cfg.merge ** 2 * D
     sp: List[ParamSpec] = [ParamSpec("vit.patch_w", (D, cfg.patch_kpad))]
+    v25 = cfg.vit_kind == "qwen2_5"
+    Ip = cfg.vit_mlp_pad
     for i in range(cfg.vit_depth):
         p = f"vit.{i}."
-        sp += [ParamSpec(p + "n1_w", (D,)), ParamSpec(p + "n1_b", (D,)),
-               ParamSpec(p + "qkv_w", (3 * D, D)), ParamSpec(p + "qkv_b", (3 * D,)),
-               ParamSpec(p + "proj_w", (D, D)), ParamSpec(p + "proj_b", (D,)),
-               ParamSpec(p + "n2_w", (D,)), ParamSpec(p + "n2_b", (D,)),
-               ParamSpec(p + "fc1_w", (cfg.vit_mlp, D)), ParamSpec(p + "fc1_b", (cfg.vit_mlp,)),
-               ParamSpec(p + "fc2_w", (D, cfg.vit_mlp)), ParamSpec(p + "fc2_b", (D,))]
-    sp += [ParamSpec("merger.ln_w", (D,)), ParamSpec("merger.ln_b", (D,)),
-           ParamSpec("merger.m0_w", (m4, m4)), ParamSpec("merger.m0_b", (m4,)),
+        if v25:     # RMSNorm blocks, gate|up fused and zero-padded to Ip rows each, down zero-padded to Ip columns
+            sp += [ParamSpec(p + "n1_w", (D,)), ParamSpec(p + "qkv_w", (3 * D, D)), ParamSpec(p + "qkv_b", (3 * D,)),
+                   ParamSpec(p + "proj_w", (D, D)), ParamSpec(p + "proj_b", (D,)), ParamSpec(p + "n2_w", (D,)),
+                   ParamSpec(p + "gu_w", (2 * Ip, D)), ParamSpec(p + "gu_b", (2 * Ip,)),
+                   ParamSpec(p + "down_w", (D, Ip)), ParamSpec(p + "down_b", (D,))]
+        else:
+            sp += [ParamSpec(p + "n1_w", (D,)), ParamSpec(p + "n1_b", (D,)),
+                   ParamSpec(p + "qkv_w", (3 * D, D)), ParamSpec(p + "qkv_b", (3 * D,)),
+                   ParamSpec(p + "proj_w", (D, D)), ParamSpec(p + "proj_b", (D,)),
+                   ParamSpec(p + "n2_w", (D,)), ParamSpec(p + "n2_b", (D,)),
+                   ParamSpec(p + "fc1_w", (cfg.vit_mlp, D)), ParamSpec(p + "fc1_b", (cfg.vit_mlp,)),
+                   ParamSpec(p + "fc2_w", (D, cfg.vit_mlp)), ParamSpec(p + "fc2_b", (D,))]
+    sp += [ParamSpec("merger.ln_w", (D,))] + ([] if v25 else [ParamSpec("merger.ln_b", (D,))])
+    sp += [ParamSpec("merger.m0_w", (m4, m4)), ParamSpec("merger.m0_b", (m4,)),
            ParamSpec("merger.m2_w", (H, m4)), ParamSpec("merger.m2_b", (H,))]
     sp.append(ParamSpec("llm.embed", (V, H)))
     for i in range(cfg.layers):
@@ -101,16 +109,33 @@ def _ckpt_to_engine(cfg: Qwen2VLConfig, sd: Dict[str, torch.Tensor]) -> Dict[str
     pad = torch.zeros(cfg.vit_dim, cfg.patch_kpad, dtype=pw.dtype)
     pad[:, :cfg.patch_k] = pw
     out["vit.patch_w"] = pad
+    v25 = cfg.vit_kind == "qwen2_5"
+    I, Ip = cfg.vit_mlp, cfg.vit_mlp_pad
     for i in range(cfg.vit_depth):
         s, d = f"visual.blocks.{i}.", f"vit.{i}."
-        for a, b in (("norm1.weight", "n1_w"), ("norm1.bias", "n1_b"), ("attn.qkv.weight", "qkv_w"), ("attn.qkv.bias", "qkv_b"),
-                     ("attn.proj.weight", "proj_w"), ("attn.proj.bias", "proj_b"), ("norm2.weight", "n2_w"),
-                     ("norm2.bias", "n2_b"), ("mlp.fc1.weight", "fc1_w"), ("mlp.fc1.bias", "fc1_b"),
-                     ("mlp.fc2.weight", "fc2_w"), ("mlp.fc2.bias", "fc2_b")):
-            out[d + b] = sd[s + a]
+        if v25:
+            for a, b in (("norm1.weight", "n1_w"), ("attn.qkv.weight", "qkv_w"), ("attn.qkv.bias", "qkv_b"),
+                         ("attn.proj.weight", "proj_w"), ("attn.proj.bias", "proj_b"), ("norm2.weight", "n2_w"),
+                         ("mlp.down_proj.bias", "down_b")):
+                out[d + b] = sd[s + a]
+            g, u = sd[s + "mlp.gate_proj.weight"], sd[s + "mlp.up_proj.weight"]
+            gu = torch.zeros(2 * Ip, cfg.vit_dim, dtype=g.dtype)
+            gu[:I] = g; gu[Ip:Ip + I] = u
+            gb = torch.zeros(2 * Ip, dtype=g.dtype)
+            gb[:I] = sd[s + "mlp.gate_proj.bias"]; gb[Ip:Ip + I] = sd[s + "mlp.up_proj.bias"]
+            dw = torch.zeros(cfg.vit_dim, Ip, dtype=g.dtype)
+            dw[:, :I] = sd[s + "mlp.down_proj.weight"]
+            out[d + "gu_w"], out[d + "gu_b"], out[d + "down_w"] = gu, gb, dw
+        else:
+            for a, b in (("norm1.weight", "n1_w"), ("norm1.bias", "n1_b"), ("attn.qkv.weight", "qkv_w"), ("attn.qkv.bias", "qkv_b"),
+                         ("attn.proj.weight", "proj_w"), ("attn.proj.bias", "proj_b"), ("norm2.weight", "n2_w"),
+                         ("norm2.bias", "n2_b"), ("mlp.fc1.weight", "fc1_w"), ("mlp.fc1.bias", "fc1_b"),
+                         ("mlp.fc2.weight", "fc2_w"), ("mlp.fc2.bias", "fc2_b")):
+                out[d + b] = sd[s + a]
     for a, b in (("ln_q.weight", "ln_w"), ("ln_q.bias", "ln_b"), ("mlp.0.weight", "m0_w"), ("mlp.0.bias", "m0_b"),
                  ("mlp.2.weight", "m2_w"), ("mlp.2.bias", "m2_b")):
-        out["merger." + b] = sd["visual.merger." + a]
+        if not (v25 and b == "ln_b"):
+            out["merger." + b] = sd["visual.merger." + a]
     out["llm.embed"] = sd["model.embed_tokens.weight"]
     for i in range(cfg.layers):
         s, d = f"model.layers.{i}.", f"llm.{i}."
@@ -139,16 +164,30 @@ def export_state_dict(params: FlatParams) -> Dict[str, torch.Tensor]:
     sd: Dict[str, torch.Tensor] = {}
     sd["visual.patch_embed.proj.weight"] = v["vit.patch_w"][:, :cfg.patch_k].reshape(
         cfg.vit_dim, 3, cfg.tpatch, cfg.patch, cfg.patch).clone()
+    v25 = cfg.vit_kind == "qwen2_5"
+    I, Ip = cfg.vit_mlp, cfg.vit_mlp_pad
     for i in range(cfg.vit_depth):
         s, d = f"visual.blocks.{i}.", f"vit.{i}."
-        for a, b in (("norm1.weight", "n1_w"), ("norm1.bias", "n1_b"), ("attn.qkv.weight", "qkv_w"), ("attn.qkv.bias", "qkv_b"),
-                     ("attn.proj.weight", "proj_w"), ("attn.proj.bias", "proj_b"), ("norm2.weight", "n2_w"),
-                     ("norm2.bias", "n2_b"), ("mlp.fc1.weight", "fc1_w"), ("mlp.fc1.bias", "fc1_b"),
-                     ("mlp.fc2.weight", "fc2_w"), ("mlp.fc2.bias", "fc2_b")):
-            sd[s + a] = v[d + b].clone()
+        if v25:
+            for a, b in (("norm1.weight", "n1_w"), ("attn.qkv.weight", "qkv_w"), ("attn.qkv.bias", "qkv_b"),
+                         ("attn.proj.weight", "proj_w"), ("attn.proj.bias", "proj_b"), ("norm2.weight", "n2_w"),
+                         ("mlp.down_proj.bias", "down_b")):
+                sd[s + a] = v[d + b].clone()
+            sd[s + "mlp.gate_proj.weight"] = v[d + "gu_w"][:I].clone()
+            sd[s + "mlp.up_proj.weight"] = v[d + "gu_w"][Ip:Ip + I].clone()
+            sd[s + "mlp.gate_proj.bias"] = v[d + "gu_b"][:I].clone()
+            sd[s + "mlp.up_proj.bias"] = v[d + "gu_b"][Ip:Ip + I].clone()
+            sd[s + "mlp.down_proj.weight"] = v[d + "down_w"][:, :I].clone()
+        else:
+            for a, b in (("norm1.weight", "n1_w"), ("norm1.bias", "n1_b"), ("attn.qkv.weight", "qkv_w"), ("attn.qkv.bias", "qkv_b"),
+                         ("attn.proj.weight", "proj_w"), ("attn.proj.bias", "proj_b"), ("norm2.weight", "n2_w"),
+                         ("norm2.bias", "n2_b"), ("mlp.fc1.weight", "fc1_w"), ("mlp.fc1.bias", "fc1_b"),
+                         ("mlp.fc2.weight", "fc2_w"), ("mlp.fc2.bias", "fc2_b")):
+                sd[s + a] = v[d + b].clone()
     for a, b in (("ln_q.weight", "ln_w"), ("ln_q.bias", "ln_b"), ("mlp.0.weight", "m0_w"), ("mlp.0.bias", "m0_b"),
                  ("mlp.2.weight", "m2_w"), ("mlp.2.bias", "m2_b")):
-        sd["visual.merger." + a] = v["merger." + b].clone()
+        if not (v25 and b == "ln_b"):
+            sd["visual.merger." + a] = v["merger." + b].clone()
     sd["model.embed_tokens.weight"] = v["llm.embed"].clone()
     qd, kd = cfg.heads * cfg.head_dim, cfg.kv_heads * cfg.head_dim
     for i in range(cfg.layers):
@@ -186,3 +225,11 @@ def random_init_(params: FlatParams, seed: int = 1234, std: float = 0.02) -> Non
                 flat[a:b] = (torch.randn(b - a, device=flat.device, generator=g) * std).to(flat.dtype)
     if "vit.patch_w" in params.v:
         params["vit.patch_w"][:, params.cfg.patch_k:] = 0
+    cfg = params.cfg
+    if cfg.vit_kind == "qwen2_5" and cfg.vit_mlp_pad != cfg.vit_mlp:       # the SwiGLU padding stays exactly zero
+        I, Ip = cfg.vit_mlp, cfg.vit_mlp_pad
+        for i in range(cfg.vit_depth):
+            p = f"vit.{i}."
+            params[p + "gu_w"][I:Ip] = 0; params[p + "gu_w"][Ip + I:] = 0
+            params[p + "gu_b"][I:Ip] = 0; params[p + "gu_b"][Ip + I:] = 0
+            params[p + "down_w"][:, I:] = 0
