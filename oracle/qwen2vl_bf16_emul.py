@@ -22,7 +22,49 @@ def r(x: torch.Tensor) -> torch.Tensor:
     return x.to(torch.bfloat16).float()
 
 
+def _vit_forward_qwen2_5(w, cfg, pixel_rows, grid_thw):
+    """bf16-eager emulation of oracle.vit_forward_qwen2_5 (HF Qwen2.5-VL vision tower)."""
+    D, Hh = cfg["vit_dim"], cfg["vit_heads"]
+    hd, mu = D // Hh, cfg["merge"] ** 2
+    x = r(r(pixel_rows.float()) @ w["visual.patch_embed.proj.weight"].float().reshape(D, -1).t())
+    win, win_lens = O.vit_window_index(grid_thw, cfg)
+    rows = (win[:, None] * mu + torch.arange(mu)[None, :]).reshape(-1)
+    x = x[rows]
+    cos, sin = O.vit_rope_tables(grid_thw, hd, cfg["merge"])
+    cos, sin = cos[rows][:, None, :], sin[rows][:, None, :]
+    frame_lens = O.vit_segments(grid_thw)
+
+    def rms(z, wt):
+        return r(wt.float() * r(z * torch.rsqrt(z.pow(2).mean(-1, keepdim=True) + 1e-6)))
+
+    for i in range(cfg["vit_depth"]):
+        p = f"visual.blocks.{i}."
+        h = rms(x, w[p + "norm1.weight"])
+        qkv = r(h @ w[p + "attn.qkv.weight"].float().t() + w[p + "attn.qkv.bias"].float())
+        q, k, v = qkv.view(-1, 3, Hh, hd).unbind(1)
+        q = r(q * cos + O._rot_half(q) * sin)
+        k = r(k * cos + O._rot_half(k) * sin)
+        outs, s0 = [], 0
+        for L in (frame_lens if i in cfg["vit_fullatt"] else win_lens):
+            qs, ks, vs = (z[s0:s0 + L].transpose(0, 1) for z in (q, k, v))
+            a = r(torch.softmax(r(qs @ ks.transpose(1, 2)) / math.sqrt(hd), dim=-1))
+            outs.append(r(a @ vs).transpose(0, 1).reshape(L, D))
+            s0 += L
+        a = torch.cat(outs, 0)
+        x = r(x + r(a @ w[p + "attn.proj.weight"].float().t() + w[p + "attn.proj.bias"].float()))
+        h = rms(x, w[p + "norm2.weight"])
+        g = r(h @ w[p + "mlp.gate_proj.weight"].float().t() + w[p + "mlp.gate_proj.bias"].float())
+        u = r(h @ w[p + "mlp.up_proj.weight"].float().t() + w[p + "mlp.up_proj.bias"].float())
+        x = r(x + r(r(r(F.silu(g)) * u) @ w[p + "mlp.down_proj.weight"].float().t() + w[p + "mlp.down_proj.bias"].float()))
+    h = rms(x, w["visual.merger.ln_q.weight"]).reshape(-1, mu * D)
+    h = r(O.gelu_erf(r(h @ w["visual.merger.mlp.0.weight"].float().t() + w["visual.merger.mlp.0.bias"].float())))
+    out = r(h @ w["visual.merger.mlp.2.weight"].float().t() + w["visual.merger.mlp.2.bias"].float())
+    return out[torch.argsort(win)]
+
+
 def vit_forward(w, cfg, pixel_rows, grid_thw):
+    if cfg.get("vit_kind", "qwen2") == "qwen2_5":
+        return _vit_forward_qwen2_5(w, cfg, pixel_rows, grid_thw)
     D, Hh = cfg["vit_dim"], cfg["vit_heads"]
     hd = D // Hh
     x = r(r(pixel_rows.float()) @ w["visual.patch_embed.proj.weight"].float().reshape(D, -1).t())

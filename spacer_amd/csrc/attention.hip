@@ -368,7 +368,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nkb = a.nqb;                              // key blocks per segment (host passes ceil(max_q_len/64))
-    const int ks_id = blockIdx.x / nkb, kb = blockIdx.x % nkb, hk = blockIdx.y, qs_id = blockIdx.z;
+    // non-causal launches (vision tower: frames / windows) have no shared prefixes: a segment attends only itself,
+    // so the grid carries no attending-segment dimension there
+    const int ks_id = blockIdx.x / nkb, kb = blockIdx.x % nkb, hk = blockIdx.y, qs_id = a.causal ? (int)blockIdx.z : ks_id;
     const spacer_attn_segment ks = a.segs[ks_id], qs = a.segs[qs_id];
     const int kb0 = kb * BKV;
     if (kb0 >= ks.q_len) return;
@@ -519,7 +521,7 @@ extern "C" int spacer_attn_bwd(const void* q, const void* k, const void* v, cons
     const dim3 qgrid(num_segs * a.nqb, Hq);
     AttnArgs b = a;
     b.nqb = cdiv(max_q_len, BKV);
-    const dim3 kgrid(num_segs * b.nqb, Hkv, num_segs);
+    const dim3 kgrid(num_segs * b.nqb, Hkv, causal ? num_segs : 1);
     if (D == 128) {
         hipLaunchKernelGGL(attn_delta_kernel<128>, dim3(dgrid), dim3(256), 0, s, a);
         hipLaunchKernelGGL((attn_bwd_dq_kernel<128, NFQ>), qgrid, dim3(256), 0, s, a);

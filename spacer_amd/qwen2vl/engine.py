@@ -61,6 +61,8 @@ class Qwen2VLEngine:
     # ================================================================== vision tower
     def vit_forward(self, pix: torch.Tensor, grids: Sequence[Tuple[int, int, int]], tape: Optional[dict] = None):
         """pix bf16 [Np, patch_kpad] (spacer_patchify output) -> merged video embeds bf16 [Np/4, hidden]."""
+        if self.cfg.vit_kind == "qwen2_5":
+            return self._vit25_forward(pix, grids, tape)
         cfg, W = self.cfg, self.W
         D, Hh, hd = cfg.vit_dim, cfg.vit_heads, cfg.vit_head_dim
         Np = pix.shape[0]
@@ -102,6 +104,8 @@ class Qwen2VLEngine:
 
     def vit_backward(self, tape: dict, d_out: torch.Tensor, G: FlatParams) -> None:
         """d_out bf16 [Nv, hidden] = gradient of the merged video embeds; accumulates into G (fp32)."""
+        if self.cfg.vit_kind == "qwen2_5":
+            return self._vit25_backward(tape, d_out, G)
         cfg, W = self.cfg, self.W
         D, Hh, hd = cfg.vit_dim, cfg.vit_heads, cfg.vit_head_dim
         Np = tape["pix"].shape[0]
@@ -139,6 +143,98 @@ class Qwen2VLEngine:
             d_h = K.gemm_nt(d_qkv, self.wT(p + "qkv_w"))
             self._dw(G[p + "qkv_w"], d_qkv, t["h"]); K.bias_grad_(d_qkv, G[p + "qkv_b"])
             K.layernorm_bwd(t["x_in"], W[p + "n1_w"], d_h, t["mean1"], t["rstd1"], dx, G[p + "n1_w"], G[p + "n1_b"])
+            tape["blocks"][i] = None
+        self._dw(G["vit.patch_w"], K.cast_bf16(dx), tape["pix"])
+
+    # ------------------------------------------------------------------ Qwen2.5-VL vision tower
+    def _vit25_forward(self, pix: torch.Tensor, grids, tape: Optional[dict] = None):
+        """HF Qwen2_5_VisionTransformerPretrainedModel.forward (modeling_qwen2_5_vl.py:408-472).  The window regrouping
+        is applied ONCE to the input pixel rows (patch embedding is row-wise), every block then runs in the permuted
+        order with windows (or whole frames on cfg.vit_fullatt blocks) as attention segments, and the merged rows are
+        gathered back at the end: two bf16 row gathers instead of permuting fp32 activations."""
+        cfg, W = self.cfg, self.W
+        D, Hh, hd, Ip = cfg.vit_dim, cfg.vit_heads, cfg.vit_head_dim, cfg.vit_mlp_pad
+        Np = pix.shape[0]
+        unit_perm, row_perm, win_list = POS.vit_window_plan(grids, cfg)
+        frame_list = POS.vit_segments(grids)
+        rows_dev = row_perm.to(self.dev)
+        cos, sin = POS.vit_tables(grids, cfg, self.dev)
+        cos, sin = cos.index_select(0, rows_dev).contiguous(), sin.index_select(0, rows_dev).contiguous()
+        win_segs, frame_segs = K.make_segments(win_list, self.dev), K.make_segments(frame_list, self.dev)
+        max_win, max_frame = max(s[1] for s in win_list), max(s[1] for s in frame_list)
+        scale = hd ** -0.5
+        pix_p = K.gather_rows(pix, rows_dev.int())
+        x = K.gemm_nt(pix_p, W["vit.patch_w"], out_dtype=F32)
+        blocks: List[dict] = []
+        for i in range(cfg.vit_depth):
+            p = f"vit.{i}."
+            segs, max_q = (frame_segs, max_frame) if i in cfg.vit_fullatt else (win_segs, max_win)
+            rstd1 = self._empty(Np)
+            h = K.rmsnorm_fwd(x, W[p + "n1_w"], 1e-6, rstd=rstd1)
+            qkv = K.gemm_nt(h, W[p + "qkv_w"], bias=W[p + "qkv_b"])
+            K.rope_(qkv, cos, sin, 2 * Hh, hd)
+            o, lse = K.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], segs, max_q, Hh, Hh, hd, False, scale)
+            x_mid = K.gemm_nt(o, W[p + "proj_w"], bias=W[p + "proj_b"], residual=x, out_dtype=F32)
+            rstd2 = self._empty(Np)
+            h2 = K.rmsnorm_fwd(x_mid, W[p + "n2_w"], 1e-6, rstd=rstd2)
+            gu = K.gemm_nt(h2, W[p + "gu_w"], bias=W[p + "gu_b"])            # [gate (Ip) | up (Ip)], padding columns are 0
+            a = K.swiglu_fwd(gu)
+            x_out = K.gemm_nt(a, W[p + "down_w"], bias=W[p + "down_b"], residual=x_mid, out_dtype=F32)
+            if tape is not None:
+                blocks.append(dict(x_in=x, rstd1=rstd1, h=h, qkv=qkv, o=o, lse=lse, x_mid=x_mid, rstd2=rstd2, h2=h2, gu=gu, a=a,
+                                   segs=segs, max_q=max_q))
+            x = x_out
+        rstd = self._empty(Np)
+        hm = K.rmsnorm_fwd(x, W["merger.ln_w"], 1e-6, rstd=rstd)
+        m4 = cfg.merge ** 2
+        hm4 = hm.view(Np // m4, m4 * D)
+        m1 = K.gemm_nt(hm4, W["merger.m0_w"], bias=W["merger.m0_b"])
+        g = K.act_fwd(m1, K.SPACER_ACT_GELU_ERF)
+        merged = K.gemm_nt(g, W["merger.m2_w"], bias=W["merger.m2_b"])
+        unit_dev = unit_perm.to(self.dev)
+        out = K.gather_rows(merged, torch.argsort(unit_dev).int())           # back to the original merge-unit order
+        if tape is not None:
+            tape.update(pix=pix_p, blocks=blocks, x_last=x, rstd=rstd, hm4=hm4, m1=m1, g=g, cos=cos, sin=sin,
+                        unit_perm=unit_dev.int())
+        return out
+
+    def _vit25_backward(self, tape: dict, d_out: torch.Tensor, G: FlatParams) -> None:
+        cfg, W = self.cfg, self.W
+        D, Hh, hd = cfg.vit_dim, cfg.vit_heads, cfg.vit_head_dim
+        Np = tape["pix"].shape[0]
+        scale = hd ** -0.5
+        cos, sin = tape["cos"], tape["sin"]
+        d_merged = K.gather_rows(d_out, tape["unit_perm"])                   # out[i] = merged[rev[i]]  =>  d_merged[u] = d_out[perm[u]]
+        d_g = K.gemm_nt(d_merged, self.wT("merger.m2_w"))
+        self._dw(G["merger.m2_w"], d_merged, tape["g"]); K.bias_grad_(d_merged, G["merger.m2_b"])
+        d_m1 = K.act_bwd(tape["m1"], d_g, K.SPACER_ACT_GELU_ERF)
+        d_hm4 = K.gemm_nt(d_m1, self.wT("merger.m0_w"))
+        self._dw(G["merger.m0_w"], d_m1, tape["hm4"]); K.bias_grad_(d_m1, G["merger.m0_b"])
+        dx = self._empty(Np, D)
+        K.rmsnorm_bwd(tape["x_last"], W["merger.ln_w"], d_hm4.view(Np, D), tape["rstd"], dx, G["merger.ln_w"], accumulate=False)
+        for i in reversed(range(cfg.vit_depth)):
+            p = f"vit.{i}."
+            t = tape["blocks"][i]
+            dyb = K.cast_bf16(dx)
+            d_a = K.gemm_nt(dyb, self.wT(p + "down_w"))
+            self._dw(G[p + "down_w"], dyb, t["a"]); K.bias_grad_(dyb, G[p + "down_b"])
+            d_gu = K.swiglu_bwd(t["gu"], d_a)
+            d_h2 = K.gemm_nt(d_gu, self.wT(p + "gu_w"))
+            self._dw(G[p + "gu_w"], d_gu, t["h2"]); K.bias_grad_(d_gu, G[p + "gu_b"])
+            K.rmsnorm_bwd(t["x_mid"], W[p + "n2_w"], d_h2, t["rstd2"], dx, G[p + "n2_w"])
+            dyb = K.cast_bf16(dx)
+            d_o = K.gemm_nt(dyb, self.wT(p + "proj_w"))
+            self._dw(G[p + "proj_w"], dyb, t["o"]); K.bias_grad_(dyb, G[p + "proj_b"])
+            qkv = t["qkv"]
+            d_qkv = torch.empty_like(qkv)
+            dk32, dv32 = self._zeros(Np, D), self._zeros(Np, D)
+            K.attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], t["o"], d_o, t["lse"], t["segs"], t["max_q"], Hh, Hh, hd, False,
+                       scale, dq=d_qkv[:, :D], dk32=dk32, dv32=dv32)
+            K.cast_bf16_strided(dk32, d_qkv[:, D:2 * D]); K.cast_bf16_strided(dv32, d_qkv[:, 2 * D:])
+            K.rope_(d_qkv, cos, sin, 2 * Hh, hd, inverse=True)
+            d_h = K.gemm_nt(d_qkv, self.wT(p + "qkv_w"))
+            self._dw(G[p + "qkv_w"], d_qkv, t["h"]); K.bias_grad_(d_qkv, G[p + "qkv_b"])
+            K.rmsnorm_bwd(t["x_in"], W[p + "n1_w"], d_h, t["rstd1"], dx, G[p + "n1_w"])
             tape["blocks"][i] = None
         self._dw(G["vit.patch_w"], K.cast_bf16(dx), tape["pix"])
 
