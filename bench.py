@@ -31,13 +31,14 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {
     # name: (model preset, frames, H, W, text tokens, K, completion len, prompt groups per GPU)
     "cfg3": ("Qwen2-VL-7B", 16, 280, 364, 360, 8, 512, 8),     # BASELINE.json configs[2]: the config the metric is quoted on
+    "cfg3_qwen25": ("Qwen2.5-VL-7B", 16, 280, 364, 360, 8, 512, 8),   # same shapes on the family the shipped script trains
     "cfg2": ("Qwen2-VL-2B", 8, 280, 364, 360, 4, 512, 4),      # configs[1]
     "cfg4": ("Qwen2-VL-7B", 16, 280, 364, 360, 8, 512, 1),     # configs[3]: 1 group per GPU, as the reference script
     "tiny": ("tiny", 4, 56, 84, 24, 4, 32, 2),
 }
 MFMA_PEAK_TFLOPS = 2500.0     # dense bf16, MI355X_MICROARCH.md
 ROLLOUT_FWD_TF = {"cfg3": 5.69 + 18.7, "cfg4": 5.69 + 18.7}     # ViT fwd + prefill per prompt (TFLOP)
-DECODE_WEIGHT_GB = {"Qwen2-VL-7B": 14.14}                      # 2 (W_L + W_H) bytes streamed per decode step
+DECODE_WEIGHT_GB = {"Qwen2-VL-7B": 14.14, "Qwen2.5-VL-7B": 14.14}                      # 2 (W_L + W_H) bytes streamed per decode step
 ALGO_TF_PER_SAMPLE = {"cfg3": 53.1, "cfg4": 53.1}   # SURVEY 8(d), temporal branch off
 
 

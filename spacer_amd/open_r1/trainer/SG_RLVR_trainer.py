@@ -226,7 +226,10 @@ class SGRLVRTrainer:
             pix[:, :pv.shape[1]] = pv.to(torch.bfloat16)
             g = proc_out["video_grid_thw" if key == "pixel_values_videos" else "image_grid_thw"]
             grids = [tuple(int(v) for v in row) for row in g.tolist()]
-        return PromptInput(ids=ids, pix=pix, grids=grids)
+        sec = proc_out.get("second_per_grid_ts") if hasattr(proc_out, "get") else None
+        if sec is not None:
+            sec = [float(v) for v in (sec.tolist() if hasattr(sec, "tolist") else sec)]
+        return PromptInput(ids=ids, pix=pix, grids=grids, second_per_grid_ts=sec)
 
     def _run_rewards(self, inputs, prompts, completion_ids, n, video_path=None) -> torch.Tensor:
         """TR:576-593 (and the shuffled twin :554-572): decode, wrap, call every reward function."""

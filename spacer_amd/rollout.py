@@ -29,6 +29,10 @@ class PromptInput:
     ids: torch.Tensor                    # int64 [P] on device (unpadded prompt tokens)
     pix: Optional[torch.Tensor] = None   # bf16 [Np, patch_kpad] from spacer_patchify, or None for text-only
     grids: Optional[Sequence[Tuple[int, int, int]]] = None
+    # Qwen2.5-VL: seconds per temporal grid step of each video (HF processor: temporal_patch_size / fps).  Used by the
+    # ROLLOUT positions only -- the reference deletes it before its scoring forwards (SG_RLVR_trainer.py:519-520), so
+    # scoring spaces the temporal positions by the default 1 s.
+    second_per_grid_ts: Optional[Sequence[float]] = None
 
 
 @dataclass
@@ -88,7 +92,7 @@ class RolloutEngine:
         x0, _ = e.embed(ids, video)               # video rows fill the placeholder tokens in prompt order
         pos_list, pos_base = [], []
         for pr, P in zip(prompts, plen):
-            pos3, delta = POS.mrope_positions(pr.ids.tolist(), list(pr.grids or []), cfg, era_rule)
+            pos3, delta = POS.mrope_positions(pr.ids.tolist(), list(pr.grids or []), cfg, era_rule, pr.second_per_grid_ts)
             pos_list.append(pos3)
             pos_base.append(P + delta)
         cos, sin = POS.mrope_tables(torch.cat(pos_list, 1), cfg, self.dev)

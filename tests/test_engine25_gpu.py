@@ -97,3 +97,28 @@ def test_backward_matches_oracle_autograd(setup):
     for w in worst[:8]:
         print("   %.3f %-50s err %.3e max|g| %.3e" % w[:4])
     assert not bad, "gradient mismatch:\n" + "\n".join("%-50s err %.3e max|g| %.3e" % (b[1], b[2], b[3]) for b in bad)
+
+
+def test_greedy_rollout_is_oracle_argmax_and_uses_video_seconds(setup):
+    """Rollout on the Qwen2.5-VL miniature: greedy tokens are arg-maxes of the oracle's next-token logits (bf16 budget
+    3e-2), and the processor's second_per_grid_ts reaches the rollout's M-RoPE positions (the reference keeps it for
+    generate, TR:463, and drops it for scoring, TR:519-520)."""
+    from spacer_amd.rollout import PromptInput, RolloutEngine, SamplingParams
+    s, g = setup, setup["g"]
+    dev = s["pix"].device
+    roll = RolloutEngine(s["eng"])
+    sp = SamplingParams(max_new_tokens=5, top_k=1, top_p=1.0, suppress_eos=True)
+    for sec in (None, [2.0]):
+        pr = PromptInput(g["prompt"].to(dev), s["pix"], [s["grid"]], second_per_grid_ts=sec)
+        out = roll.generate([pr], 2, sp, use_graph=False)
+        assert torch.equal(out[0], out[1])
+        comp = out[0].cpu()
+        ids = torch.cat([g["prompt"], comp])
+        ve = O.vit_forward(s["wb"], g["cfg"], s["rows"], [s["grid"]])
+        pos3, _ = O.mrope_position_ids(ids.tolist(), [s["grid"]], g["cfg"], second_per_grid_ts=sec)
+        lg = O.llm_forward(s["wb"], g["cfg"], O.embed_with_video(s["wb"], g["cfg"], ids, ve), pos3)
+        P = g["prompt"].numel()
+        for t in range(5):
+            row = lg[P - 1 + t].clone()
+            row[TINY.eos_token_id] = float("-inf")
+            assert float(row.max() - row[comp[t]]) < 3e-2, (sec, t, float(row.max() - row[comp[t]]))
