@@ -24,6 +24,7 @@ from typing import Any, Callable, Dict, List, Optional, Sequence, Union
 import torch
 
 from ...grpo import GRPOEngine, GRPOHyper, group_advantages, length_bonus, temporal_bonus
+from ...qwen2vl.checkpoint import config_of_dir, read_checkpoint, write_checkpoint
 from ...qwen2vl.config import Qwen2VLConfig, preset_for
 from ...qwen2vl.weights import FlatParams, export_state_dict, load_state_dict
 from ...rollout import PromptInput, SamplingParams
@@ -170,9 +171,10 @@ class SGRLVRTrainer:
 
         # ---- model (policy) and reference model (a frozen copy, TR:205-217)
         if isinstance(model, str):
-            cfg = model_config or preset_for(model)
+            # architecture: the snapshot's own config.json when `model` is a directory, else the preset its name selects
+            cfg = model_config or config_of_dir(model) or preset_for(model)
             params = FlatParams.empty(cfg, self.device)
-            load_state_dict(params, _read_checkpoint(model))
+            load_state_dict(params, read_checkpoint(model))
             self.model_id = model
         else:
             params, cfg = model, (model_config or model.cfg)
@@ -338,44 +340,21 @@ class SGRLVRTrainer:
         return {"global_step": self.global_step}
 
     def save_model(self, output_dir: Optional[str] = None, _internal_call: bool = False) -> None:
-        """Weights in the original Qwen2-VL checkpoint names (bf16 safetensors) + the step counter."""
+        """What HF ``Trainer.save_model`` leaves for the reference (open_r1/SG-RLVR.py:377-384): bf16 safetensors in the
+        original Qwen2-VL / Qwen2.5-VL tensor names + config.json + tokenizer / processor files, loadable with
+        ``from_pretrained`` (qwen2vl/checkpoint.py), plus the step counter for --resume_from_checkpoint."""
         if self.rank != 0:
             return
         output_dir = output_dir or self.args.output_dir
-        os.makedirs(output_dir, exist_ok=True)
-        sd = {k: v.detach().cpu().contiguous() for k, v in export_state_dict(self.engine.policy).items()}
-        try:
-            from safetensors.torch import save_file
-            save_file(sd, os.path.join(output_dir, "model.safetensors"))
-        except ImportError:
-            torch.save(sd, os.path.join(output_dir, "pytorch_model.bin"))
-        with open(os.path.join(output_dir, "trainer_state.json"), "w") as f:
-            json.dump({"global_step": self.global_step, "model_id": self.model_id, "notes": self._log_lines}, f)
+        write_checkpoint(output_dir, self.engine.policy, source_dir=self.model_id if os.path.isdir(str(self.model_id)) else None,
+                         processor=self.processing_class,
+                         extra_state={"global_step": self.global_step, "model_id": self.model_id, "notes": self._log_lines})
 
     def _load_checkpoint(self, path: str) -> None:
-        load_state_dict(self.engine.policy, _read_checkpoint(path))
+        load_state_dict(self.engine.policy, read_checkpoint(path))
         self.engine.master.flat.copy_(self.engine.policy.flat.float())
         st = os.path.join(path, "trainer_state.json")
         if os.path.exists(st):
             with open(st) as f:
                 self.global_step = int(json.load(f).get("global_step", 0))
             self.engine.step_count = self.global_step
-
-
-def _read_checkpoint(path: str) -> Dict[str, torch.Tensor]:
-    """A directory (or file) of safetensors / .bin shards in the original Qwen2-VL names."""
-    files = [path] if os.path.isfile(path) else sorted(os.path.join(path, f) for f in os.listdir(path)
-                                                       if f.endswith(".safetensors") or f.endswith(".bin"))
-    if not files:
-        raise FileNotFoundError(f"no checkpoint shards under {path}")
-    sd: Dict[str, torch.Tensor] = {}
-    for f in files:
-        if f.endswith(".safetensors"):
-            from safetensors.torch import load_file
-            part = load_file(f)
-        else:
-            part = torch.load(f, map_location="cpu")
-        for k, v in part.items():
-            k = k.replace("model.language_model.", "model.").replace("model.visual.", "visual.")   # transformers 5.x names
-            sd[k] = v
-    return sd
