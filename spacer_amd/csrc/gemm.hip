@@ -115,6 +115,36 @@ __device__ __noinline__ void store_frag(EpiArgs g, int m, int n, f32x4 a) {
     }
 }
 
+// Back half of the epilogue for a row-contiguous group of 4 outputs whose bias / activation were already applied:
+// + residual, convert, one 16-byte (fp32) or 8-byte (bf16) store.  Used by the LDS-staged epilogue of the 256 tile.
+__device__ __forceinline__ void store_row4(const EpiArgs& g, int m, int n, float4 x) {
+    float v[4] = {x.x, x.y, x.z, x.w};
+    const int nv = min(4, g.N - n);
+    if (g.out_f32) {
+        float* c = (float*)g.C + (long)m * g.ldc + n;
+        const float* r = g.resid ? (const float*)g.resid + (long)m * g.ldr + n : nullptr;
+        if (nv == 4 && (g.ldc % 4) == 0 && (!r || (g.ldr % 4) == 0)) {
+            float4 o = x;
+            if (r) { const float4 rr = *(const float4*)r; o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w; }
+            *(float4*)c = o;
+        } else {
+            for (int e = 0; e < nv; ++e) c[e] = v[e] + (r ? r[e] : 0.f);
+        }
+    } else {
+        bf16_t* c = (bf16_t*)g.C + (long)m * g.ldc + n;
+        const bf16_t* r = g.resid ? (const bf16_t*)g.resid + (long)m * g.ldr + n : nullptr;
+        if (nv == 4 && (g.ldc % 4) == 0 && (!r || (g.ldr % 4) == 0)) {
+            if (r) {
+                const uint2 rr = *(const uint2*)r;
+                v[0] += bf_lo(rr.x); v[1] += bf_hi(rr.x); v[2] += bf_lo(rr.y); v[3] += bf_hi(rr.y);
+            }
+            *(uint2*)c = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+        } else {
+            for (int e = 0; e < nv; ++e) c[e] = f2bf(v[e] + (r ? bf2f(r[e]) : 0.f));
+        }
+    }
+}
+
 template <int WAVES_M, int WAVES_N, int FM, int FN>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N == 4) ? 2 : 1) void gemm_bf16_nt_kernel(GemmArgs g) {
     constexpr int NWAVES = WAVES_M * WAVES_N;

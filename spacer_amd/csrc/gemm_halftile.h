@@ -211,13 +211,47 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
         return;
     }
 
-    // ---- epilogue: wave quadrant (mq, nq) fragment (i, j) sits at rows wr*128 + mq*64 + i*16, cols wc*64 + nq*32 + j*16
+    // ---- epilogue, staged through LDS so that every global store instruction of a wave covers ONE full output row of
+    // the tile (1 KiB fp32 / 512 B bf16).  Writing accumulator fragments straight out gives 16 row segments of 32 B per
+    // instruction, and those partial-line writes cost ~25 us per tile (a quarter of a K = 3584 launch).
+    // Two passes (wave row 0, then 1): [128 rows][256 cols] fp32 = the whole 128 KiB; 16-byte chunk index ^= row & 7 keeps
+    // the fragment writes (8 rows per store group) and the row reads conflict-free.  alpha / bias / activation are applied
+    // on the way in, residual + conversion on the way out (one rounding, as before).
     const EpiArgs e = {g.C, g.bias, g.resid, g.ldc, g.ldr, g.M, g.N, g.out_f32, g.act, g.alpha};
+    __syncthreads();                                                         // every wave is done with the operand images
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int pass = 0; pass < 2; ++pass) {
+        if (wr == pass) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            store_frag(e, m0 + wr * 128 + i * 16 + (lane & 15), n0 + wc * 64 + j * 16 + (lane >> 4) * 4, acc[i][j]);
+            for (int j = 0; j < 4; ++j) {
+                const int nl = wc * 64 + j * 16 + (lane >> 4) * 4;              // column inside the tile
+                float b4[4] = {0.f, 0.f, 0.f, 0.f};
+                if (e.bias) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) b4[q] = (n0 + nl + q < e.N) ? bf2f(e.bias[n0 + nl + q]) : 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int row = i * 16 + (lane & 15);
+                    float4 v;
+                    v.x = apply_act(acc[i][j][0] * e.alpha + b4[0], e.act);
+                    v.y = apply_act(acc[i][j][1] * e.alpha + b4[1], e.act);
+                    v.z = apply_act(acc[i][j][2] * e.alpha + b4[2], e.act);
+                    v.w = apply_act(acc[i][j][3] * e.alpha + b4[3], e.act);
+                    *(float4*)(smem + row * 1024 + (((nl >> 2) ^ (row & 7)) << 4)) = v;
+                }
+            }
+        }
+        __syncthreads();
+
+        for (int it = 0; it < 16; ++it) {
+            const int row = it * 8 + wave;                                    // one wave = one tile row
+            const float4 v = *(const float4*)(smem + row * 1024 + ((lane ^ (row & 7)) << 4));
+            const int m = m0 + pass * 128 + row, n = n0 + lane * 4;
+            if (m < e.M && n < e.N) store_row4(e, m, n, v);
+        }
+        if (pass == 0) __syncthreads();
+    }
 }
 
 // Sums the K-split partial tiles of the tail (written by gemm_bf16_nt_256h_kernel) in split order -- deterministic --
