@@ -12,12 +12,12 @@ from spacer_amd import kernels as K  # noqa: E402
 
 # (M, N, K, launches per cfg3 step, fp32 output?)
 SHAPES = [
-    (5498, 37888, 3584, 448, 0), (5498, 3584, 18944, 448, 1), (5498, 3584, 37888, 224, 0), (37888, 3584, 5504, 224, 1),
-    (3584, 18944, 5504, 224, 1), (5498, 18944, 3584, 224, 0), (5498, 3584, 3584, 672, 1), (4160, 5120, 1280, 1024, 0),
-    (5498, 4608, 3584, 448, 0), (1402, 37888, 3584, 224, 0), (4160, 1280, 5120, 1024, 1), (4096, 152064, 3584, 16, 1),
-    (1402, 3584, 18944, 224, 1), (4160, 3840, 1280, 768, 0), (5498, 3584, 4608, 224, 0), (4160, 1280, 1280, 1024, 1),
-    (4608, 3584, 5504, 224, 1), (3584, 3584, 5504, 224, 1), (152064, 3584, 4096, 8, 1), (4096, 3584, 152064, 8, 0),
-    (5120, 1280, 4160, 256, 1), (1280, 5120, 4160, 256, 1), (3840, 1280, 4160, 256, 1), (4160, 1280, 3840, 256, 0),
+    (5498, 37888, 3584, 448, 0), (37888, 3584, 5504, 224, 1), (5498, 3584, 18944, 448, 1), (5498, 3584, 37888, 224, 0),
+    (3584, 18944, 5504, 224, 1), (5498, 18944, 3584, 224, 0), (5498, 3584, 3584, 672, 1), (4160, 5120, 1280, 768, 0),
+    (5498, 4608, 3584, 448, 0), (11216, 37888, 3584, 28, 0), (4096, 152064, 3584, 16, 1), (4160, 1280, 5120, 768, 1),
+    (5498, 3584, 4608, 224, 0), (4608, 3584, 5504, 224, 1), (3584, 3584, 5504, 224, 1), (4160, 1280, 1280, 768, 1),
+    (4160, 3840, 1280, 512, 0), (152064, 3584, 4096, 8, 1), (11216, 3584, 18944, 28, 1), (4096, 3584, 152064, 8, 0),
+    (1280, 5120, 4160, 256, 1), (5120, 1280, 4160, 256, 1), (33280, 5120, 1280, 32, 0), (3840, 1280, 4160, 256, 1),
 ]
 
 if __name__ == "__main__":

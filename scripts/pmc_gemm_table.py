@@ -11,27 +11,44 @@ from gemm_step_shapes import SHAPES  # noqa: E402
 
 
 def per_dispatch(db, counter):
+    """[(kernel short name, value)] of the main GEMM launches in dispatch order, plus {dispatch order index: value} of the
+    split-K reduce launches that follow some of them (their traffic is charged to the GEMM launch they finish)."""
     cur = sqlite3.connect(db).cursor()
-    rows = list(cur.execute("select dispatch_id, value from counters_collection where counter_name = ? and kernel_name like "
-                            "'%gemm_bf16_nt_%' order by dispatch_id", (counter,)))
-    return [v for _, v in rows]
+    rows = list(cur.execute("select dispatch_id, kernel_name, value from counters_collection where counter_name = ? and "
+                            "(kernel_name like '%gemm_bf16_nt_%' or kernel_name like '%gemm_tail_reduce%') order by dispatch_id",
+                            (counter,)))
+    main, extra = [], {}
+    for _, name, v in rows:
+        if "tail_reduce" in name:
+            extra[len(main) - 1] = extra.get(len(main) - 1, 0.0) + v
+        else:
+            main.append(("256h" if "256h" in name else "128", v))
+    return main, extra
 
 
-fetch, write = per_dispatch(sys.argv[1], "FETCH_SIZE"), per_dispatch(sys.argv[2], "WRITE_SIZE")
+(fetch, fx), (write, wx) = per_dispatch(sys.argv[1], "FETCH_SIZE"), per_dispatch(sys.argv[2], "WRITE_SIZE")
 reps = len(fetch) // len(SHAPES)
 assert len(fetch) == len(write) == reps * len(SHAPES), (len(fetch), len(write), len(SHAPES))
-table, tot_bytes, tot_launch, tot_algo = [], 0.0, 0, 0.0
+table, tot = [], {"256h": [0.0, 0, 0.0], "128": [0.0, 0, 0.0]}
 for i, (M, N, K, launches, f32) in enumerate(SHAPES):
-    f = sum(fetch[i * reps:(i + 1) * reps]) / reps
-    w = sum(write[i * reps:(i + 1) * reps]) / reps
+    idx = range(i * reps, (i + 1) * reps)
+    f = sum(fetch[k][1] + fx.get(k, 0.0) for k in idx) / reps
+    w = sum(write[k][1] + wx.get(k, 0.0) for k in idx) / reps
+    kern = fetch[i * reps][0]
     hbm = (2.0 * f + w) * 1024.0
     algo = 2.0 * (M * K + N * K) + (4 if f32 else 2) * M * N
-    table.append(dict(M=M, N=N, K=K, launches_per_step=launches, fetch_kib=f, write_kib=w, hbm_bytes=hbm, algorithmic_bytes=algo,
-                      ratio=hbm / algo))
-    tot_bytes += hbm * launches; tot_launch += launches; tot_algo += algo * launches
-out = dict(kernel="gemm_bf16_nt_kernel", method="rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over "
-           "scripts/gemm_step_shapes.py; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts half of wide reads)",
-           hbm_bytes_per_launch=tot_bytes / tot_launch, algorithmic_bytes_per_launch=tot_algo / tot_launch,
-           launches_per_step=tot_launch, shapes=table)
+    table.append(dict(M=M, N=N, K=K, kernel=kern, launches_per_step=launches, fetch_kib=f, write_kib=w, hbm_bytes=hbm,
+                      algorithmic_bytes=algo, ratio=hbm / algo))
+    t = tot[kern]
+    t[0] += hbm * launches; t[1] += launches; t[2] += algo * launches
+d = tot["256h"]
+out = dict(kernel="gemm_bf16_nt_256h_kernel", method="rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over "
+           "scripts/gemm_step_shapes.py; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts half of wide reads); "
+           "the split-K reduce launch that follows a GEMM launch is charged to it; launch-weighted over the cfg3 step's shapes "
+           "that run on this kernel",
+           hbm_bytes_per_launch=d[0] / max(1, d[1]), algorithmic_bytes_per_launch=d[2] / max(1, d[1]), launches_per_step=d[1],
+           other_kernel_128=dict(hbm_bytes_per_launch=tot["128"][0] / max(1, tot["128"][1]),
+                                 algorithmic_bytes_per_launch=tot["128"][2] / max(1, tot["128"][1]), launches_per_step=tot["128"][1]),
+           shapes=table)
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != "shapes"}))
