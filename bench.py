@@ -87,6 +87,9 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--temporal", action="store_true",
+                    help="T-GRPO as run_SpaceR_SG_RLVR.sh:29 sets it: a second rollout of K/2 generations per prompt on "
+                         "frame-shuffled video feeds the temporal bonus (TR:442-481, 598-617); not the headline config")
     ap.add_argument("--groups", type=int, default=None, help="prompt groups per GPU per step (default: workload's)")
     ap.add_argument("--completion-len", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -138,11 +141,20 @@ def main():
         t0 = time.perf_counter()
         prompts = [make_prompt(cfg, rank * groups + g, F, Hpx, Wpx, n_text, dev, frames_u8=frames[g])[0] for g in range(groups)]
         comp = ge.roll.generate(prompts, Kgen, sp, use_graph=not args.no_graph, stats=roll_stats)
+        scomp = None
+        if args.temporal:                         # the shuffled twin: same text, temporally permuted frames, K/2 generations
+            sprompts = []
+            for g in range(groups):
+                perm = torch.randperm(F, generator=torch.Generator().manual_seed(77 + step_idx * 1009 + rank * groups + g)).to(dev)
+                sprompts.append(make_prompt(cfg, rank * groups + g, F, Hpx, Wpx, n_text, dev, frames_u8=frames[g][perm])[0])
+            ssp = SamplingParams(**{**sp.__dict__, "seed": sp.seed + 1})
+            scomp = ge.roll.generate(sprompts, Kgen // 2, ssp, use_graph=not args.no_graph)
         t0 = tick("rollout", t0)
         for g in range(groups):
             cg = comp[g * Kgen:(g + 1) * Kgen]
             rpf = synthetic_rewards(step_idx, rank * groups + g, Kgen)
-            rewards, _ = temporal_bonus(rpf, None, False, True)
+            srpf = synthetic_rewards(step_idx + 100003, rank * groups + g, Kgen // 2) if scomp is not None else None
+            rewards, _ = temporal_bonus(rpf, srpf, scomp is not None, True)
             rewards = length_bonus(rewards, rpf, torch.full((Kgen,), C), hyper.len_control)
             adv, _ = group_advantages(rewards, Kgen)
             ge.score_and_backward(prompts[g], cg, adv.to(dev), grad_scale=1.0 / groups)
@@ -188,7 +200,8 @@ def main():
         value = samples / elapsed
         gemm = prof.get("gemm_bf16_nt_256h_kernel", dict(tflops=0.0, launches=0, seconds=0.0, flops=0.0, bytes=0.0))
         out = {
-            "metric": "GRPO samples/sec (K=8 rollouts) Qwen2-VL-7B 16-frame" if args.workload in ("cfg3", "cfg4")
+            "metric": ("GRPO samples/sec (K=8 rollouts) Qwen2-VL-7B 16-frame" + (" [T-GRPO twin rollouts on]" if args.temporal else ""))
+            if args.workload in ("cfg3", "cfg4")
             else f"GRPO samples/sec ({args.workload})",
             "value": round(value, 4), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
@@ -221,7 +234,7 @@ def main():
             out["decode"] = {"seconds_per_step": round(dec / args.steps, 4), "ms_per_token_step": round(1e3 * dec / max(1, steps_dec), 3),
                              "weight_stream_tbps": round(DECODE_WEIGHT_GB.get(preset, 0.0) * steps_dec / dec / 1e3, 3),
                              "peak_tbps": 8.0}
-        if args.workload in ALGO_TF_PER_SAMPLE:
+        if args.workload in ALGO_TF_PER_SAMPLE and not args.temporal:
             out["step_algorithmic_tflops"] = round(ALGO_TF_PER_SAMPLE[args.workload] * value / world, 2)
         if args.phase_times:
             out["phase_seconds_per_step"] = {k: round(v / args.steps, 3) for k, v in phase.items()}

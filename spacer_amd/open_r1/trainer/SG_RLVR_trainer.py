@@ -267,17 +267,20 @@ class SGRLVRTrainer:
         has_video = bool(video_inputs)
         sp = SamplingParams(max_new_tokens=self.max_completion_length, top_k=self.args.top_k, top_p=0.95, temperature=1.0,
                             seed=self._sample_seed + 7919 * self.global_step)
-        completion_ids = eng.roll.generate([prompt], G, sp, use_graph=self.args.use_decode_graph)
-
         shuffled_rpf = None
         if self.temporal and has_video:                                                      # T-GRPO (TR:442-481)
             perm = torch.randperm(video_inputs[0].size(0))
             sproc = self.processing_class(text=copy.deepcopy(prompts_text), images=image_inputs,
                                           videos=[video_inputs[0][perm]], **call)
             sprompt = self._prompt_input(sproc)
-            ssp = SamplingParams(**{**sp.__dict__, "seed": sp.seed + 1})
-            shuffled_ids = eng.roll.generate([sprompt], self.shuffled_num_generations, ssp, use_graph=self.args.use_decode_graph)
+            # The reference calls generate twice (G rollouts, then G/2 on the shuffled frames).  Decoding is bound by
+            # streaming the weights, not by the number of rows, so both prompts decode as ONE batch of 2G rows and the
+            # shuffled prompt's surplus rollouts are dropped: the twin costs its prefill, not a second decode loop.
+            both = eng.roll.generate([prompt, sprompt], G, sp, use_graph=self.args.use_decode_graph)
+            completion_ids, shuffled_ids = both[:G], both[G:G + self.shuffled_num_generations]
             shuffled_rpf = self._run_rewards(inputs, prompts, shuffled_ids, self.shuffled_num_generations)
+        else:
+            completion_ids = eng.roll.generate([prompt], G, sp, use_graph=self.args.use_decode_graph)
 
         rewards_per_func = self._run_rewards(inputs, prompts, completion_ids, G, video_path=video_path)
         rewards, temporal_reward = temporal_bonus(rewards_per_func, shuffled_rpf, self.temporal, has_video)
