@@ -219,6 +219,7 @@ def main():
             "kernels": {k: {"tflops": round(v["tflops"], 2), "launches": v["launches"], "seconds": round(v["seconds"], 4)}
                         for k, v in prof.items()},
         }
+        out["hbm_peak_gb"] = round(torch.cuda.max_memory_allocated() / 1e9, 1)      # of 288 GB: replicas, no ZeRO, no recompute
         if roll_stats.get("events"):
             # the north-star's "fused rollout forward": ViT + LLM prefill of every prompt (MFMA-bound), and the decode loop
             # (HBM-bound: packed weights + KV), each from HIP events on the launch stream inside the timed region
