@@ -19,6 +19,7 @@ import json
 import os
 import time
 from collections import defaultdict
+from concurrent.futures import ThreadPoolExecutor
 from typing import Any, Callable, Dict, List, Optional, Sequence, Union
 
 import torch
@@ -249,13 +250,11 @@ class SGRLVRTrainer:
         return out
 
     # ------------------------------------------------------------------ the step (TR:384-686)
-    def compute_loss(self, model, inputs, return_outputs=False, num_items_in_batch=None, *, grad_scale: float = 1.0):
-        if return_outputs:
-            raise ValueError("The GRPOTrainer does not support returning outputs")
+    def _prepare(self, inputs, shuffle_seed: int = 0) -> dict:
+        """Host half of a step (TR:395-430, and the shuffled twin's inputs TR:442-460): chat template, frame decode + resize
+        (qwen_vl_utils), tokenisation + HF patchify.  CPU only, no engine state -- ``train`` runs it for the NEXT sample on a
+        worker thread while the GPU works on the current one, so the step no longer starts with a CPU stall."""
         from ...qwen_vl_utils.vision_process import process_vision_info
-        eng, G = self.engine, self.num_generations
-        prompts = [x["prompt"] for x in inputs]
-        video_path = inputs[0]["path"]
         prompts_text = [maybe_apply_chat_template(ex, self.processing_class)["prompt"] for ex in inputs]
         conv = remove_none_from_data(copy.deepcopy(inputs[0]["prompt"]))
         if inputs[0]["data_type"] in ("image", "video"):
@@ -263,16 +262,28 @@ class SGRLVRTrainer:
         image_inputs, video_inputs, _ = process_vision_info(conv, return_video_kwargs=True)
         call = dict(return_tensors="pt", padding=True, padding_side="left", add_special_tokens=False)
         proc = self.processing_class(text=copy.deepcopy(prompts_text), images=image_inputs, videos=video_inputs, **call)
-        prompt = self._prompt_input(proc)
-        has_video = bool(video_inputs)
+        sproc = None
+        if self.temporal and video_inputs:                                                   # T-GRPO twin (TR:442-460)
+            perm = torch.randperm(video_inputs[0].size(0), generator=torch.Generator().manual_seed(shuffle_seed))
+            sproc = self.processing_class(text=copy.deepcopy(prompts_text), images=image_inputs,
+                                          videos=[video_inputs[0][perm]], **call)
+        return dict(proc=proc, sproc=sproc, has_video=bool(video_inputs))
+
+    def compute_loss(self, model, inputs, return_outputs=False, num_items_in_batch=None, *, grad_scale: float = 1.0,
+                     prepared: Optional[dict] = None):
+        if return_outputs:
+            raise ValueError("The GRPOTrainer does not support returning outputs")
+        eng, G = self.engine, self.num_generations
+        prompts = [x["prompt"] for x in inputs]
+        video_path = inputs[0]["path"]
+        prep = prepared if prepared is not None else self._prepare(inputs, self._sample_seed + 104729 * self.global_step)
+        prompt = self._prompt_input(prep["proc"])
+        has_video = prep["has_video"]
         sp = SamplingParams(max_new_tokens=self.max_completion_length, top_k=self.args.top_k, top_p=0.95, temperature=1.0,
                             seed=self._sample_seed + 7919 * self.global_step)
         shuffled_rpf = None
-        if self.temporal and has_video:                                                      # T-GRPO (TR:442-481)
-            perm = torch.randperm(video_inputs[0].size(0))
-            sproc = self.processing_class(text=copy.deepcopy(prompts_text), images=image_inputs,
-                                          videos=[video_inputs[0][perm]], **call)
-            sprompt = self._prompt_input(sproc)
+        if prep["sproc"] is not None:                                                        # T-GRPO (TR:442-481)
+            sprompt = self._prompt_input(prep["sproc"])
             # The reference calls generate twice (G rollouts, then G/2 on the shuffled frames).  Decoding is bound by
             # streaming the weights, not by the number of rows, so both prompts decode as ONE batch of 2G rows and the
             # shuffled prompt's surplus rollouts are dropped: the twin costs its prefill, not a second decode loop.
@@ -322,14 +333,28 @@ class SGRLVRTrainer:
         n_rows = len(self.train_dataset)
         acc = max(1, a.gradient_accumulation_steps * a.per_device_train_batch_size)
         epoch, t_last = 0, time.time()
+        pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="spacer-prefetch")
+
+        def prep_seed(ep: int, pos: int) -> int:
+            return self._sample_seed + 104729 * (ep * 1000003 + pos)
+
         while self.global_step < self.total_steps:
             idx = shard_indices(n_rows, self.rank, self.world, a.data_seed if a.data_seed is not None else a.seed, epoch)
+            last = (len(idx) // acc) * acc
+            pending = None
             for s in range(0, len(idx) - acc + 1, acc):
                 if self.global_step >= self.total_steps:
                     break
                 loss = 0.0
                 for j in range(acc):
-                    loss += float(self.compute_loss(None, [self.train_dataset[idx[s + j]]], grad_scale=1.0 / acc)) / acc
+                    pos = s + j
+                    if pending is None:
+                        pending = pool.submit(self._prepare, [self.train_dataset[idx[pos]]], prep_seed(epoch, pos))
+                    prepared, pending = pending.result(), None
+                    if pos + 1 < last:                       # the next sample's host work overlaps this one's GPU work
+                        pending = pool.submit(self._prepare, [self.train_dataset[idx[pos + 1]]], prep_seed(epoch, pos + 1))
+                    loss += float(self.compute_loss(None, [self.train_dataset[idx[pos]]], grad_scale=1.0 / acc,
+                                                    prepared=prepared)) / acc
                 self.engine.reduce_gradients()
                 lr = self.engine.optimizer_step(self.world)
                 self.global_step += 1
@@ -340,6 +365,7 @@ class SGRLVRTrainer:
                 if a.save_steps and self.global_step % a.save_steps == 0:
                     self.save_model(os.path.join(a.output_dir, f"checkpoint-{self.global_step}"))
             epoch += 1
+        pool.shutdown(wait=False, cancel_futures=True)
         return {"global_step": self.global_step}
 
     def save_model(self, output_dir: Optional[str] = None, _internal_call: bool = False) -> None:
