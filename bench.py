@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--completion-len", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--grad-comm", choices=("fp32", "bf16"), default="fp32",
+                    help="wire format of the gradient all-reduce (N > 1): fp32 values, or bf16 as DeepSpeed's bf16 mode sends them")
     ap.add_argument("--phase-times", action="store_true", help="print per-phase wall times (adds synchronisations)")
     ap.add_argument("--gemm-shapes", action="store_true", help="also print the GEMM time broken down by (M,N,K) to stderr")
     args = ap.parse_args()
@@ -121,7 +123,7 @@ def main():
     groups = args.groups or groups
     C = args.completion_len or C
     cfg = PRESETS[preset]
-    hyper = GRPOHyper(num_generations=Kgen, temporal=False, len_control=True, total_steps=1000)
+    hyper = GRPOHyper(num_generations=Kgen, temporal=False, len_control=True, total_steps=1000, grad_comm_bf16=args.grad_comm == "bf16")
     params = FlatParams.empty(cfg, dev)
     random_init_(params, seed=1234)
     ge = GRPOEngine(cfg, params, hyper, process_group=pg)
@@ -209,7 +211,7 @@ def main():
             "config": {"workload": f"{args.workload}: {preset} random-init bf16, {F} frames {Hpx}x{Wpx}, {n_text} text tokens, "
                                    f"K={Kgen}, C={C} (EOS suppressed), {groups} prompt groups/GPU, full step "
                                    f"(rollout+ref/policy scoring+backward+AdamW)",
-                       "global_batch": groups * Kgen * world, "parallelism": f"dp{world}", "decode_graph": not args.no_graph},
+                       "global_batch": groups * Kgen * world, "parallelism": f"dp{world}", "decode_graph": not args.no_graph, "grad_comm": args.grad_comm},
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_256h_kernel", "achieved": round(gemm["tflops"], 2),
                          "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gemm["tflops"] / MFMA_PEAK_TFLOPS, 4),
                          "traffic": pmc_traffic(args.workload), "launches": gemm["launches"],

@@ -38,6 +38,7 @@ class GRPOHyper:
     lr_scheduler_type: str = "cosine"  # (:23)
     total_steps: int = 1000
     warmup_steps: int = 0
+    grad_comm_bf16: bool = False      # gradient all-reduce on a bf16 wire (DeepSpeed bf16's communication dtype); fp32 when False
 
 
 # ------------------------------------------------------------------------------------- reward shaping (host)
@@ -87,14 +88,27 @@ def lr_at(step: int, h: GRPOHyper) -> float:
     return h.learning_rate * 0.5 * (1.0 + math.cos(math.pi * prog))
 
 
-def allreduce_flat_(flat: torch.Tensor, pg, bucket_elems: int = 1 << 28) -> torch.Tensor:
+def allreduce_flat_(flat: torch.Tensor, pg, bucket_elems: int = 1 << 28, wire_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
     """SUM all-reduce of one flat tensor in a few large buckets (1 GiB of fp32 each by default), all in flight at
     once.  On MI355X the 8 GPUs are fully connected by point-to-point xGMI links, so collectives are per-link bound:
-    few, big messages; the mean (1/world) is folded into the optimizer's grad_scale instead of a second pass."""
+    few, big messages; the mean (1/world) is folded into the optimizer's grad_scale instead of a second pass.
+
+    wire_dtype = torch.bfloat16 halves the bytes on the links: each bucket is rounded to bf16, summed in bf16 by the
+    collective and widened back into ``flat`` -- what the reference's DeepSpeed bf16 configuration does with its gradient
+    buckets (communication in the training dtype).  Default: exchange the fp32 values themselves."""
     import torch.distributed as dist
-    works = [dist.all_reduce(flat[a:a + bucket_elems], group=pg, async_op=True) for a in range(0, flat.numel(), bucket_elems)]
-    for w in works:
+    if wire_dtype is None or wire_dtype == flat.dtype:
+        works = [dist.all_reduce(flat[a:a + bucket_elems], group=pg, async_op=True) for a in range(0, flat.numel(), bucket_elems)]
+        for w in works:
+            w.wait()
+        return flat
+    pending = []
+    for a in range(0, flat.numel(), bucket_elems):
+        wire = flat[a:a + bucket_elems].to(wire_dtype)
+        pending.append((a, wire, dist.all_reduce(wire, group=pg, async_op=True)))
+    for a, wire, w in pending:
         w.wait()
+        flat[a:a + wire.numel()].copy_(wire)
     return flat
 
 
@@ -144,7 +158,7 @@ class GRPOEngine:
         """Data-parallel exchange: SUM all-reduce of the flat fp32 gradient over RCCL in large buckets (xGMI is
         per-link bound: few, big collectives).  The mean is folded into the optimizer's grad_scale."""
         if self.pg is not None:
-            allreduce_flat_(self.G.flat, self.pg)
+            allreduce_flat_(self.G.flat, self.pg, wire_dtype=torch.bfloat16 if self.h.grad_comm_bf16 else None)
 
     def optimizer_step(self, world_size: int = 1) -> float:
         """Global-norm clip (max_grad_norm) + AdamW on fp32 master, bf16 policy refreshed in the same kernel."""

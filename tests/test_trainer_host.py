@@ -132,6 +132,11 @@ def _dp_worker(rank, world, port, ret):
     allreduce_flat_(flat, pg, bucket_elems=3000)
     others = [torch.randn(10_000, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
     ok_grad = torch.allclose(flat, sum(others)) and not torch.equal(flat, mine)
+    # bf16 wire: every rank ends with the same values, equal to the sum of the bf16-rounded contributions
+    wire = mine.clone()
+    allreduce_flat_(wire, pg, bucket_elems=3000, wire_dtype=torch.bfloat16)
+    want = sum(o.to(torch.bfloat16) for o in others).float()
+    ok_grad = ok_grad and torch.allclose(wire, want, atol=2e-2, rtol=2e-2) and (wire - sum(others)).abs().max() < 5e-2
     # packed metrics: rank 0 group all wrong, rank 1 group all correct
     rpf = torch.tensor([[0.0, 1.0]] * 4) if rank == 0 else torch.tensor([[1.9, 1.0]] * 4)
     rewards = rpf.sum(1)
