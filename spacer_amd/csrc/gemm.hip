@@ -215,13 +215,39 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N == 4) ? 2
         __syncthreads();
     }
 
-    // ---- epilogue: lane owns C[m][n..n+3], m = m0+wm+i*16+(lane&15), n = n0+wn+j*16+(lane>>4)*4 ----
+    // ---- epilogue, staged through LDS ([BM rows][BN cols] fp32 = the whole 64 KiB of the 128x128 tile) so that global
+    // stores cover whole tile rows (512 B fp32 / 256 B bf16) instead of 32-byte fragment segments.  alpha / bias /
+    // activation on the way in, residual + conversion on the way out (one rounding).  16-byte chunk index ^= row & 7.
     const EpiArgs e = {g.C, g.bias, g.resid, g.ldc, g.ldr, g.M, g.N, g.out_f32, g.act, g.alpha};
+    static_assert(BM * BN * 4 <= 2 * STAGE, "output tile must fit the operand buffers");
+    constexpr int ROWB = BN * 4, CPR = BN / 4;                               // row bytes, 16-byte chunks per row
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
+    for (int j = 0; j < FN; ++j) {
+        const int nl = wn + j * 16 + (lane >> 4) * 4;                        // column inside the tile
+        float b4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (e.bias) {
 #pragma unroll
-        for (int j = 0; j < FN; ++j)
-            store_frag(e, m0 + wm + i * 16 + (lane & 15), n0 + wn + j * 16 + (lane >> 4) * 4, acc[i][j]);
+            for (int q = 0; q < 4; ++q) b4[q] = (n0 + nl + q < e.N) ? bf2f(e.bias[n0 + nl + q]) : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int row = wm + i * 16 + (lane & 15);
+            float4 v;
+            v.x = apply_act(acc[i][j][0] * e.alpha + b4[0], e.act);
+            v.y = apply_act(acc[i][j][1] * e.alpha + b4[1], e.act);
+            v.z = apply_act(acc[i][j][2] * e.alpha + b4[2], e.act);
+            v.w = apply_act(acc[i][j][3] * e.alpha + b4[3], e.act);
+            *(float4*)(smem + row * ROWB + (((nl >> 2) ^ (row & 7)) << 4)) = v;
+        }
+    }
+    __syncthreads();
+    constexpr int RPI = NWAVES * 64 / CPR;                                   // tile rows covered per iteration
+    for (int it = 0; it < BM / RPI; ++it) {
+        const int row = it * RPI + tid / CPR, ch = tid % CPR;
+        const float4 v = *(const float4*)(smem + row * ROWB + ((ch ^ (row & 7)) << 4));
+        const int m = m0 + row, n = n0 + ch * 4;
+        if (m < e.M && n < e.N) store_row4(e, m, n, v);
+    }
 }
 
 #include "gemm_halftile.h"
