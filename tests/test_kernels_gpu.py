@@ -369,6 +369,18 @@ def test_patchify_matches_oracle(dev):
         assert float(got[:, 1176:].float().abs().sum()) == 0
 
 
+def test_patchify_matches_hf_golden(dev):
+    """K1 against HF's own pre-processing output (tests/golden/patchify_hf.npz): bf16 rounding of the normalised pixel only."""
+    import numpy as np
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "patchify_hf.npz"))
+    for i in range(3):
+        got, grid = K.patchify(torch.from_numpy(z[f"frames{i}"]).to(dev), kpad=1216)
+        want = torch.from_numpy(z[f"pixel_values{i}"])
+        assert tuple(grid) == tuple(int(v) for v in z[f"grid{i}"])
+        assert_close(got[:, :1176], want, 1e-2, 4e-3, "patchify vs HF")          # |x| < 2.7, bf16: 2^-9 relative
+        assert torch.equal(got[:, :1176].float().cpu(), want.to(BF).float())       # exactly the bf16 rounding of HF's value
+
+
 # ----------------------------------------------------------------------------------------------- loss
 def test_logprob(dev):
     rows, V = 33, 152064 // 16 + 3

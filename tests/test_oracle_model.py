@@ -65,3 +65,16 @@ def test_shared_prefix_mask_equals_independent_rows():
     got = torch.stack([torch.stack([lp[P - 1 if t == 0 else P + k * C + t - 1, g["completions"][k, t]] for t in range(C)])
                        for k in range(Kn)])
     assert (got - g["hf_logps"]).abs().max() < 5e-5
+
+
+def test_patchify_matches_hf_processor():
+    """K1's restatement against HF's own pre-processing output (tests/golden/patchify_hf.npz, scripts/make_golden_patchify.py):
+    rescale, CLIP normalisation, temporal pairing and merge-block-major patch order, bit for bit."""
+    import numpy as np
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "patchify_hf.npz"))
+    cfg = dict(patch=14, tpatch=2, merge=2)
+    for i in range(3):
+        rows, grid = O.patchify_frames(torch.from_numpy(z[f"frames{i}"]), cfg)
+        assert tuple(grid) == tuple(int(v) for v in z[f"grid{i}"])
+        assert torch.equal(rows, torch.from_numpy(z[f"pixel_values{i}"]))
