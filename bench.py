@@ -34,6 +34,7 @@ WORKLOADS = {
     "cfg3_qwen25": ("Qwen2.5-VL-7B", 16, 280, 364, 360, 8, 512, 8),   # same shapes on the family the shipped script trains
     "cfg2": ("Qwen2-VL-2B", 8, 280, 364, 360, 4, 512, 4),      # configs[1]
     "cfg4": ("Qwen2-VL-7B", 16, 280, 364, 360, 8, 512, 1),     # configs[3]: 1 group per GPU, as the reference script
+    "cfg5": ("Qwen2-VL-7B", 32, 448, 448, 360, 8, 512, 8),     # configs[4]: 32 frames @ 448^2 (Np = 16384, Nv = 4096): ViT-bound long-video stress
     "tiny": ("tiny", 4, 56, 84, 24, 4, 32, 2),
 }
 MFMA_PEAK_TFLOPS = 2500.0     # dense bf16, MI355X_MICROARCH.md
