@@ -154,6 +154,19 @@ class GRPOEngine:
             self.engine.backward_group(tape, dlogp, self.G)
         return dict(loss=loss, kl=kl, logps=lp, ref_logps=ref_lp, mask=mask, lengths=lengths)
 
+    def sft_forward_backward(self, ids: torch.Tensor, pix, grids, label_mask: torch.Tensor, *, grad_scale: float = 1.0,
+                             second_per_grid_ts=None) -> float:
+        """Supervised objective of open_r1/sft.py on the same kernels: mean cross-entropy of ids[1:] over the positions whose
+        label is kept (``label_mask`` bool/0-1 [S], True where labels != -100: the reference masks pad and visual tokens,
+        sft.py:170-181), gradients accumulated into G scaled by grad_scale.  Returns the loss."""
+        tape = {}
+        logp = self.engine.score_sequence(ids, pix, grids, tape=tape, second_per_grid_ts=second_per_grid_ts)
+        m = label_mask.reshape(-1)[1:].to(self.dev, torch.float32)
+        n = float(m.sum().clamp_min(1.0))
+        loss = float(-(logp * m).sum() / n)
+        self.engine.backward_group(tape, (-(m / n) * grad_scale).view(1, -1), self.G)
+        return loss
+
     def reduce_gradients(self) -> None:
         """Data-parallel exchange: SUM all-reduce of the flat fp32 gradient over RCCL in large buckets (xGMI is
         per-link bound: few, big collectives).  The mean is folded into the optimizer's grad_scale."""

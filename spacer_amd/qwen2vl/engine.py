@@ -354,6 +354,35 @@ class Qwen2VLEngine:
                         has_video=video is not None)
         return logp.view(Kn, C)
 
+    def score_sequence(self, ids: torch.Tensor, pix: Optional[torch.Tensor], grids, *, tape: Optional[dict] = None,
+                       era_rule: bool = False, second_per_grid_ts=None) -> torch.Tensor:
+        """Teacher-forced log-probs [S-1] of ids[1:] for ONE full sequence (placeholders anywhere, 3-D positions from the
+        whole sequence): the quantity the SFT objective averages (open_r1/sft.py: HF causal-LM loss on ``labels``).  The tape
+        has the layout ``backward_group`` consumes, with dlogp of shape [1, S-1]."""
+        cfg = self.cfg
+        ids = ids.reshape(-1)
+        S = ids.numel()
+        vit_tape = {} if tape is not None else None
+        video = self.vit_forward(pix, grids, vit_tape) if pix is not None else None
+        x0, vrow = self.embed(ids, video)
+        pos3, _ = POS.mrope_positions(ids.tolist(), list(grids or []), cfg, era_rule, second_per_grid_ts)
+        cos, sin = POS.mrope_tables(pos3, cfg, self.dev)
+        segs = K.make_segments([(0, S, 0, 0)], self.dev)
+        llm_tape = [] if tape is not None else None
+        x = self.llm_forward(x0, cos, sin, segs, S, tape=llm_tape)
+        rstd_f = self._empty(S)
+        hn = K.rmsnorm_fwd(x, self.W["llm.norm_w"], cfg.rms_eps, rstd=rstd_f)
+        sel = torch.arange(S - 1, device=self.dev, dtype=torch.int32)
+        hsel = hn[:S - 1]
+        logits = K.gemm_nt(hsel, self.W["llm.lm_head"], out_dtype=F32)
+        targets = ids[1:].contiguous()
+        logp, lse = K.logprob_fwd(logits, targets)
+        if tape is not None:
+            tape.update(vit=vit_tape, llm=llm_tape, ids=ids, vrow=vrow, cos=cos, sin=sin, segs=segs, max_q=S, sel=sel,
+                        x_final=x, rstd_f=rstd_f, hsel=hsel, logits=logits, targets=targets, lse=lse, T=S,
+                        has_video=video is not None)
+        return logp
+
     def backward_group(self, tape: dict, dlogp: torch.Tensor, G: FlatParams) -> None:
         """Back-propagates d loss / d logp (fp32 [K, C]) through lm_head, the LLM, the embeddings and the ViT."""
         cfg, W = self.cfg, self.W

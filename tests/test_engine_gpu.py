@@ -96,3 +96,34 @@ def test_backward_matches_oracle_autograd(setup):
     for w in worst[:8]:
         print("   %.3f %-50s err %.3e max|g| %.3e" % w[:4])
     assert not bad, "gradient mismatch:\n" + "\n".join("%-50s err %.3e max|g| %.3e" % (b[1], b[2], b[3]) for b in bad)
+
+
+def test_sft_loss_and_gradients_match_oracle(setup):
+    """The supervised objective of open_r1/sft.py (HF causal-LM loss, pad and visual tokens ignored) through
+    score_sequence / sft_forward_backward: loss within 5e-3 of the fp32 oracle, gradients within 4 % of each tensor's max."""
+    from spacer_amd.grpo import GRPOEngine, GRPOHyper
+    from spacer_amd.open_r1.sft import label_mask
+    s, g = setup, setup["g"]
+    dev = s["pix"].device
+    ids = torch.cat([g["prompt"], g["completions"][0], g["completions"][1]])
+    keep = label_mask(ids, TINY.pad_token_id, (TINY.vision_start_id, TINY.vision_end_id, TINY.video_token_id, TINY.image_token_id))
+    assert 0 < int(keep.sum()) < ids.numel()
+    # oracle: mean CE of the shifted labels
+    wr = {k: v.clone().requires_grad_(True) for k, v in s["wb"].items()}
+    lg = O.full_logits(wr, g["cfg"], ids, s["rows"], [s["grid"]])
+    lp = torch.log_softmax(lg[:-1], -1).gather(1, ids[1:, None]).squeeze(1)
+    m = keep[1:].float()
+    loss_o = -(lp * m).sum() / m.sum()
+    loss_o.backward()
+    ge = GRPOEngine(TINY, s["params"], GRPOHyper(), ref=s["params"])
+    loss = ge.sft_forward_backward(ids.to(dev), s["pix"], [s["grid"]], keep)
+    assert abs(loss - float(loss_o)) < 5e-3, (loss, float(loss_o))
+    got = export_state_dict(ge.G)
+    got["visual.patch_embed.proj.weight"] = got["visual.patch_embed.proj.weight"].reshape(TINY.vit_dim, -1)
+    bad = []
+    for name, ref in wr.items():
+        gr = ref.grad if ref.grad is not None else torch.zeros_like(ref)
+        err, scale = float((got[name].float().cpu() - gr).abs().max()), float(gr.abs().max())
+        if err > 0.04 * scale + 2e-4:
+            bad.append((name, err, scale))
+    assert not bad, bad
