@@ -143,15 +143,19 @@ def main():
     def step(step_idx):
         t0 = time.perf_counter()
         prompts = [make_prompt(cfg, rank * groups + g, F, Hpx, Wpx, n_text, dev, frames_u8=frames[g])[0] for g in range(groups)]
-        comp = ge.roll.generate(prompts, Kgen, sp, use_graph=not args.no_graph, stats=roll_stats)
         scomp = None
-        if args.temporal:                         # the shuffled twin: same text, temporally permuted frames, K/2 generations
+        if args.temporal:                         # the shuffled twin: same text, temporally permuted frames
             sprompts = []
             for g in range(groups):
                 perm = torch.randperm(F, generator=torch.Generator().manual_seed(77 + step_idx * 1009 + rank * groups + g)).to(dev)
                 sprompts.append(make_prompt(cfg, rank * groups + g, F, Hpx, Wpx, n_text, dev, frames_u8=frames[g][perm])[0])
-            ssp = SamplingParams(**{**sp.__dict__, "seed": sp.seed + 1})
-            scomp = ge.roll.generate(sprompts, Kgen // 2, ssp, use_graph=not args.no_graph)
+            # main and twin rollouts decode as ONE batch (2 x groups x K rows <= 128: the weights stream once); the twin's
+            # surplus K/2 rollouts per prompt are dropped, as SGRLVRTrainer does
+            both = ge.roll.generate(prompts + sprompts, Kgen, sp, use_graph=not args.no_graph, stats=roll_stats)
+            comp = both[:groups * Kgen]
+            scomp = both[groups * Kgen:].view(groups, Kgen, -1)[:, :Kgen // 2].reshape(groups * (Kgen // 2), -1)
+        else:
+            comp = ge.roll.generate(prompts, Kgen, sp, use_graph=not args.no_graph, stats=roll_stats)
         t0 = tick("rollout", t0)
         for g in range(groups):
             cg = comp[g * Kgen:(g + 1) * Kgen]

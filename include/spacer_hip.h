@@ -66,7 +66,7 @@ long spacer_gemm_workspace_bytes(void);
  * Pure host function; profilers use it to attribute a launch to the kernel rocprof will name. */
 int spacer_gemm_tile(int M, int N, int K, int have_workspace);
 
-/* Skinny GEMM for the decode loop (M <= 64 rows, weights streamed once from HBM, split-K):
+/* Skinny GEMM for the decode loop (M <= 64 rows; <= 128 with packed weights; weights streamed once from HBM, split-K):
  * C32[M,N] += A[M,K] . B[N,K]^T  (fp32 atomics; C may be the fp32 residual stream itself).  K % 256 == 0.
  * epi must be NULL or {out_f32 = 1, residual = C}.  Replaces the per-token projections inside HF
  * generate's loop (TR:463). */
@@ -82,7 +82,7 @@ int spacer_gemm_skinny_packed_bf16(const void* A, long lda, const void* Bpacked,
 /* Decode-loop MLP front half in one launch:  Y[M, inter] (bf16) = silu(A . Wgate^T) * (A . Wup^T)   (HF Qwen2MLP's
  * act_fn(gate_proj(x)) * up_proj(x) inside generate, TR:463).  W = [gate (inter rows) | up (inter rows)] x K is packed
  * by spacer_pack_weight_frag_swiglu so each 16-column MFMA fragment holds 8 gate + 8 up columns of the same outputs;
- * every block owns the whole K, so there is no fp32 partial buffer and no separate SwiGLU kernel.  M <= 64. */
+ * every block owns the whole K, so there is no fp32 partial buffer and no separate SwiGLU kernel.  M <= 128. */
 int spacer_pack_weight_frag_swiglu(const void* W, long ld, void* out, int inter, int K, spacer_stream_t stream);
 int spacer_gemm_skinny_swiglu_bf16(const void* A, long lda, const void* Bpacked, void* Y, long ldy, int M, int inter, int K,
                                    spacer_stream_t stream);

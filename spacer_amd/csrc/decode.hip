@@ -24,13 +24,18 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 // SWIGLU (packed weights only, whole K per block): the 16 columns of a wave are [8 gate | 8 up] columns of the same 8
 // outputs (spacer_pack_weight_frag_swiglu), so lanes l and l^8 hold gate and up of one element; the epilogue writes
 // y = silu(gate) * up as bf16 [M, N/2] and C is that bf16 buffer -- no fp32 round trip, no separate SwiGLU launch.
-template <bool PACKED, bool SWIGLU = false>
+// MT = 64-row blocks of A handled per weight pass: 1 (M <= 64, 256-wide K slices) or 2 (M <= 128, 128-wide K slices -- the
+// same 64 KiB of LDS and two workgroups per CU; every weight fragment feeds 8 instead of 4 MFMAs, so 128 rows stream the
+// weights once instead of twice).
+template <bool PACKED, bool SWIGLU = false, int MT = 1>
 __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __restrict__ A, long lda,
                                                              const bf16_t* __restrict__ B, long ldb,
                                                              float* __restrict__ C, long ldc, int M, int N, int K,
                                                              int slices_per_range, int mflush) {
-    constexpr int KS = 256, ROWB = KS * 2;                 // 512-byte LDS rows, 16-byte chunk index ^= row & 15
-    __shared__ __attribute__((aligned(16))) char smem[2][64 * ROWB];
+    constexpr int KS = 256 / MT, ROWB = KS * 2;            // LDS row bytes (512 / 256); 16-byte chunk index ^= row & 15
+    constexpr int NU = KS / 32, MF = 4 * MT;               // MFMA k-steps per slice, 16-row A fragments
+    constexpr int CH = KS / 8, CHS = (MT == 1) ? 5 : 4;    // 16-byte chunks per LDS row and log2
+    __shared__ __attribute__((aligned(16))) char smem[2][64 * MT * ROWB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 64 + wave * 16;
@@ -38,14 +43,14 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __res
     const int s_begin = blockIdx.y * slices_per_range, s_end = min(total_slices, s_begin + slices_per_range);
     if (s_begin >= s_end) return;
 
-    // ---- staging map: instruction j of a thread covers row (tid >> 5) + 8 j, 16-byte chunk tid & 31
-    // (a wave reads 2 rows x 512 contiguous bytes per load instruction)
-    const int ar0 = tid >> 5, ach = tid & 31;
+    // ---- staging map: instruction j of a thread covers row (tid >> CHS) + (256 / CH) j, 16-byte chunk tid & (CH - 1)
+    // (a wave reads whole rows of the slice: 2 x 512 or 4 x 256 contiguous bytes per load instruction); 8 per thread
+    const int ar0 = tid >> CHS, ach = tid & (CH - 1);
     uint4 areg[8];
     auto load_a = [&](int slice) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int row = ar0 + 8 * j;
+            const int row = ar0 + (256 / CH) * j;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (row < M) v = *(const uint4*)(A + (long)row * lda + slice * KS + ach * 8);
             areg[j] = v;
@@ -54,48 +59,48 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __res
     auto store_a = [&](char* buf) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int row = ar0 + 8 * j;
+            const int row = ar0 + (256 / CH) * j;
             *(uint4*)(buf + row * ROWB + ((ach ^ (row & 15)) * 16)) = areg[j];
         }
     };
     const bf16_t* bbase;
     if (PACKED) bbase = B + ((long)min(n0 >> 4, (N >> 4) - 1) * (K >> 5)) * 512 + lane * 8;
     else bbase = B + (long)min(n0 + l15, N - 1) * ldb + g * 8;
-    auto load_w = [&](u32x4 (&w)[8], int slice) {
+    auto load_w = [&](u32x4 (&w)[NU], int slice) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const bf16_t* p = PACKED ? bbase + ((long)slice * 8 + u) * 512 : bbase + slice * KS + u * 32;
+        for (int u = 0; u < NU; ++u) {
+            const bf16_t* p = PACKED ? bbase + ((long)slice * NU + u) * 512 : bbase + slice * KS + u * 32;
             w[u] = __builtin_nontemporal_load((const u32x4*)p);
         }
     };
-    f32x4 acc[4];
+    f32x4 acc[MF];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    auto compute = [&](const u32x4 (&w)[8], const char* buf) {
+    for (int i = 0; i < MF; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](const u32x4 (&w)[NU], const char* buf) {
         // A fragments double-buffered by hand and the scheduler fenced per k-step (left alone hipcc hoists all 32
         // fragment reads of the slice and spills)
-        bf16x8 af[2][4];
-        auto read_a = [&](bf16x8 (&dst)[4], int u) {
+        bf16x8 af[2][MF];
+        auto read_a = [&](bf16x8 (&dst)[MF], int u) {
             const int ch = u * 4 + g;
 #pragma unroll
-            for (int mf = 0; mf < 4; ++mf) {
+            for (int mf = 0; mf < MF; ++mf) {
                 const int row = mf * 16 + l15;
                 dst[mf] = *(const bf16x8*)(buf + row * ROWB + ((ch ^ (row & 15)) * 16));
             }
         };
         read_a(af[0], 0);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (u + 1 < 8) read_a(af[(u + 1) & 1], u + 1);
+        for (int u = 0; u < NU; ++u) {
+            if (u + 1 < NU) read_a(af[(u + 1) & 1], u + 1);
             const bf16x8 wf = __builtin_bit_cast(bf16x8, w[u]);
 #pragma unroll
-            for (int mf = 0; mf < 4; ++mf)
+            for (int mf = 0; mf < MF; ++mf)
                 acc[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][mf], wf, acc[mf], 0, 0, 0);   // D[m][n]
             __builtin_amdgcn_sched_barrier(0);
         }
     };
 
-    u32x4 wa[8], wb[8];
+    u32x4 wa[NU], wb[NU];
     load_a(s_begin);
     load_w(wa, s_begin);
     int s = s_begin;
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __res
         bf16_t* Y = (bf16_t*)C;
         const int col = (n0 >> 1) + (l15 & 7);                               // output column of this gate/up pair
 #pragma unroll
-        for (int mf = 0; mf < 4; ++mf)
+        for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float other = __shfl_xor(acc[mf][r], 8);
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __res
     const bool whole_k = (s_begin == 0 && s_end == total_slices);
     if (n < N) {
 #pragma unroll
-        for (int mf = 0; mf < 4; ++mf)
+        for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = mf * 16 + g * 4 + r;
@@ -578,14 +583,15 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
 static int launch_skinny(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
                          const spacer_gemm_epilogue* epi, bool packed, hipStream_t s) {
     SP_REQUIRE(A && B && C, SPACER_EINVAL, "gemm_skinny: null operand");
-    SP_REQUIRE(M > 0 && M <= 64, SPACER_EINVAL, "gemm_skinny: M=%d must be in 1..64", M);
+    SP_REQUIRE(M > 0 && M <= (packed ? 128 : 64), SPACER_EINVAL, "gemm_skinny: M=%d must be in 1..%d", M, packed ? 128 : 64);
     SP_REQUIRE(K % 256 == 0, SPACER_EINVAL, "gemm_skinny: K=%d must be a multiple of 256", K);
+    const int MTv = M > 64 ? 2 : 1, KSv = 256 / MTv;          // 65..128 rows: two 64-row blocks per weight pass, 128-wide K slices
     SP_REQUIRE(lda % 8 == 0 && (packed || ldb % 8 == 0), SPACER_EINVAL, "gemm_skinny: lda/ldb must be multiples of 8");
     SP_REQUIRE(!packed || N % 16 == 0, SPACER_EINVAL, "gemm_skinny: packed weights need N %% 16 == 0");
     SP_REQUIRE(!epi || (epi->out_f32 && !epi->bias && epi->act == 0 && (!epi->residual || epi->residual == C)),
                SPACER_EINVAL, "gemm_skinny: only fp32 accumulate-into-C is supported (C32 += A.B^T)");
     // K ranges: 1 (no atomics) when the column groups alone fill the chip, else just enough ranges for ~2 workgroups / CU
-    const int col_groups = cdiv(N, 64), slices = K / 256;
+    const int col_groups = cdiv(N, 64), slices = K / KSv;
     int ranges = 1;
     // SPACER_SKINNY_BLOCKS=1 forces one K range per column group (no atomics: bit-reproducible sums); read per call so
     // a test can switch it
@@ -595,7 +601,10 @@ static int launch_skinny(const void* A, long lda, const void* B, long ldb, void*
     const int spr = cdiv(slices, ranges);
     ranges = cdiv(slices, spr);
     const int mflush = getenv("SPACER_PROBE_NOFLUSH") ? 0 : M;
-    if (packed)
+    if (packed && MTv == 2)
+        hipLaunchKernelGGL((gemm_skinny_kernel<true, false, 2>), dim3(col_groups, ranges), dim3(256), 0, s, (const bf16_t*)A, lda,
+                           (const bf16_t*)B, ldb, (float*)C, ldc, M, N, K, spr, mflush);
+    else if (packed)
         hipLaunchKernelGGL(gemm_skinny_kernel<true>, dim3(col_groups, ranges), dim3(256), 0, s, (const bf16_t*)A, lda,
                            (const bf16_t*)B, ldb, (float*)C, ldc, M, N, K, spr, mflush);
     else
@@ -637,12 +646,16 @@ extern "C" int spacer_pack_weight_frag_swiglu(const void* W, long ld, void* out,
 extern "C" int spacer_gemm_skinny_swiglu_bf16(const void* A, long lda, const void* Bpacked, void* Y, long ldy, int M, int inter,
                                               int K, spacer_stream_t stream) {
     SP_REQUIRE(A && Bpacked && Y, SPACER_EINVAL, "gemm_skinny_swiglu: null operand");
-    SP_REQUIRE(M > 0 && M <= 64, SPACER_EINVAL, "gemm_skinny_swiglu: M=%d must be in 1..64", M);
+    SP_REQUIRE(M > 0 && M <= 128, SPACER_EINVAL, "gemm_skinny_swiglu: M=%d must be in 1..128", M);
     SP_REQUIRE(K % 256 == 0 && inter % 32 == 0 && lda % 8 == 0, SPACER_EINVAL,
                "gemm_skinny_swiglu: need K %% 256 == 0, inter %% 32 == 0, lda %% 8 == 0");
     const int N = 2 * inter;
-    hipLaunchKernelGGL((gemm_skinny_kernel<true, true>), dim3(cdiv(N, 64), 1), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)A, lda, (const bf16_t*)Bpacked, 0L, (float*)Y, ldy, M, N, K, K / 256, M);
+    if (M > 64)
+        hipLaunchKernelGGL((gemm_skinny_kernel<true, true, 2>), dim3(cdiv(N, 64), 1), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)A, lda, (const bf16_t*)Bpacked, 0L, (float*)Y, ldy, M, N, K, K / 128, M);
+    else
+        hipLaunchKernelGGL((gemm_skinny_kernel<true, true, 1>), dim3(cdiv(N, 64), 1), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)A, lda, (const bf16_t*)Bpacked, 0L, (float*)Y, ldy, M, N, K, K / 256, M);
     SP_CHECK_LAUNCH();
     return SPACER_OK;
 }

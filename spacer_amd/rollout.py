@@ -47,7 +47,7 @@ class SamplingParams:
 
 
 class RolloutEngine:
-    MAX_ROWS = 64   # rows per skinny-GEMM call
+    MAX_ROWS = 128  # rows per decode batch: the packed skinny GEMMs stream the weights once for up to 128 rows
 
     def __init__(self, engine: Qwen2VLEngine):
         self.e = engine

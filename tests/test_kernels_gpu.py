@@ -114,13 +114,23 @@ def test_gemm_skinny(dev, M, N, K):
         assert_close(c2, c0 + a.float() @ b.float().t(), 5e-3, 2e-3, "skinny packed")
 
 
-@pytest.mark.parametrize("M,I,Kd", [(64, 18944, 3584), (8, 512, 256), (33, 96, 1536)])
+@pytest.mark.parametrize("M,I,Kd", [(64, 18944, 3584), (8, 512, 256), (33, 96, 1536), (128, 2048, 1024), (97, 96, 512)])
 def test_gemm_skinny_swiglu(dev, M, I, Kd):
     a, w = rnd((M, Kd), dev, 1, 0.5), rnd((2 * I, Kd), dev, 2, 0.05)
     y = K.gemm_skinny_swiglu(a, K.pack_weight_frag_swiglu(w), I)
     gu = a.float() @ w.float().t()
     want = torch.nn.functional.silu(gu[:, :I]) * gu[:, I:]
     assert_close(y, want, 2e-2, 1e-2, "skinny swiglu")
+
+
+@pytest.mark.parametrize("M,N,Kd", [(128, 3584, 3584), (96, 4608, 3584), (65, 512, 18944), (100, 1008, 256)])
+def test_gemm_skinny_packed_up_to_128_rows(dev, M, N, Kd):
+    """65..128 rows: two 64-row blocks per weight pass (128-wide K slices), packed weights only."""
+    a, b = rnd((M, Kd), dev, 1, 0.5), rnd((N, Kd), dev, 2, 0.05)
+    c0 = rnd((M, N), dev, 3, dtype=torch.float32)
+    c = c0.clone()
+    K.gemm_skinny_packed_acc(a, K.pack_weight_frag(b), c, N)
+    assert_close(c, c0 + a.float() @ b.float().t(), 5e-3, 2e-3, "skinny packed, M > 64")
 
 
 def test_transpose_pad(dev):

@@ -125,3 +125,18 @@ def test_full_grpo_step_matches_oracle(tiny, dev):
     delta = ge.master["llm.1.down_w"] - before
     assert float(delta.abs().max()) > 0 and float(delta.abs().max()) <= 1.01e-3 * 1.2   # |AdamW step 1| ~ lr
     assert torch.equal(ge.policy["llm.1.down_w"], ge.master["llm.1.down_w"].to(torch.bfloat16))
+
+
+def test_more_than_64_rows_decode_as_one_batch(tiny, dev):
+    """65..128 rows go through the two-block skinny GEMMs in ONE decode batch; greedy tokens equal the <= 64-row chunks'."""
+    eng = Qwen2VLEngine(TINY, tiny["params"])
+    roll = RolloutEngine(eng)
+    sp = SamplingParams(max_new_tokens=6, top_k=1, top_p=1.0, suppress_eos=True)
+    prompts = [tiny["prompts"][0], tiny["prompts"][1], tiny["prompts"][0]]
+    st = {}
+    big = roll.generate(prompts, 24, sp, use_graph=True, stats=st)                 # 72 rows, one batch
+    assert big.shape == (72, 6) and st["decode_steps"] == 5
+    roll.MAX_ROWS = 64                                                           # instance override: chunks of 2 + 1 prompts
+    small = roll.generate(prompts, 24, sp, use_graph=False)
+    assert torch.equal(big, small)
+    assert torch.equal(big[:24], big[48:])                                      # same prompt, greedy -> same rollouts
