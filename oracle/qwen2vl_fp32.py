@@ -28,7 +28,7 @@ Everything here is plain torch on fp32 tensors, written for clarity, not speed.
 from __future__ import annotations
 
 import math
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence
 
 import torch
 import torch.nn.functional as F

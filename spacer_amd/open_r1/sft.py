@@ -7,7 +7,6 @@ loss (mean cross-entropy of the shifted labels) computed and back-propagated by 
 """
 from __future__ import annotations
 
-import copy
 import json
 import os
 import sys

@@ -20,14 +20,14 @@ import os
 import time
 from collections import defaultdict
 from concurrent.futures import ThreadPoolExecutor
-from typing import Any, Callable, Dict, List, Optional, Sequence, Union
+from typing import Callable, Dict, List, Optional, Sequence, Union
 
 import torch
 
 from ...grpo import GRPOEngine, GRPOHyper, group_advantages, length_bonus, temporal_bonus
 from ...qwen2vl.checkpoint import config_of_dir, read_checkpoint, write_checkpoint
 from ...qwen2vl.config import Qwen2VLConfig, preset_for
-from ...qwen2vl.weights import FlatParams, export_state_dict, load_state_dict
+from ...qwen2vl.weights import FlatParams, load_state_dict
 from ...rollout import PromptInput, SamplingParams
 from ..config import GRPOConfig, GRPOScriptArguments
 

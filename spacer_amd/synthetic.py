@@ -3,7 +3,7 @@ a prompt of <|vision_start|> Nv x <|video_pad|> <|vision_end|> followed by rando
 U[0, 2] (reward functions on decoded text are meaningless for random weights; they are timed on the golden table)."""
 from __future__ import annotations
 
-from typing import List, Tuple
+from typing import Tuple
 
 import torch
 

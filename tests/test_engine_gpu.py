@@ -117,7 +117,7 @@ def test_sft_loss_and_gradients_match_oracle(setup):
     loss_o.backward()
     ge = GRPOEngine(TINY, s["params"], GRPOHyper(), ref=s["params"])
     loss = ge.sft_forward_backward(ids.to(dev), s["pix"], [s["grid"]], keep)
-    assert abs(loss - float(loss_o)) < 5e-3, (loss, float(loss_o))
+    assert abs(loss - float(loss_o.detach())) < 5e-3, (loss, float(loss_o.detach()))
     got = export_state_dict(ge.G)
     got["visual.patch_embed.proj.weight"] = got["visual.patch_embed.proj.weight"].reshape(TINY.vit_dim, -1)
     bad = []
