@@ -48,9 +48,9 @@ template <int D>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     constexpr int DC = (D + 31) / 32;      // 32-wide contraction chunks for QK^T (D=80 -> 3, zero padded)
     constexpr int DF = D / 16;             // 16-wide d blocks of O^T
-    __shared__ __attribute__((aligned(16))) char smem[AT_RM_BYTES + AT_T_BYTES(D)];
+    __shared__ __attribute__((aligned(16))) char smem[2 * AT_RM_BYTES];    // K and V tiles, both row-major
     char* k_lds = smem;
-    char* vt_lds = smem + AT_RM_BYTES;
+    char* v_lds = smem + AT_RM_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // longest-first dispatch: later segments (rollouts: prompt prefix + own keys) and later query blocks of a causal
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         const KeyTile kt = key_tile(seg, n_pre, own_len, t);
         __syncthreads();
         tile_store<D, true, false>(kreg, k_lds, nullptr, tid);
-        tile_store<D, false, true>(vreg, nullptr, vt_lds, tid);
+        tile_store<D, true, false>(vreg, v_lds, nullptr, tid);
         __syncthreads();
         if (t + 1 < n_tiles) {
             const KeyTile nx = key_tile(seg, n_pre, own_len, t + 1);
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         for (int df = 0; df < DF; ++df)
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const bf16x8 vf = frag_t(vt_lds, df, c, lane);
+                const bf16x8 vf = frag_tr(v_lds, df, c, lane);       // V^T fragment by transposing read
                 oacc[0][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[0][c], oacc[0][df], 0, 0, 0);
                 oacc[1][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[1][c], oacc[1][df], 0, 0, 0);
             }
@@ -230,8 +230,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs a) {
 template <int D, int NF>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     constexpr int DC = (D + 31) / 32, DF = D / 16, BQD = 64 * NF;
-    __shared__ __attribute__((aligned(16))) char smem[2 * AT_RM_BYTES + AT_T_BYTES(D)];
-    char* k_lds = smem; char* v_lds = smem + AT_RM_BYTES; char* kt_lds = smem + 2 * AT_RM_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[2 * AT_RM_BYTES];
+    char* k_lds = smem; char* v_lds = smem + AT_RM_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // longest-first dispatch: later segments (rollouts: prompt prefix + own keys) and later query blocks of a causal
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     for (int t = 0; t < n_tiles; ++t) {
         const KeyTile kt = key_tile(seg, n_pre, own_len, t);
         __syncthreads();
-        tile_store<D, true, true>(kreg, k_lds, kt_lds, tid);
+        tile_store<D, true, false>(kreg, k_lds, nullptr, tid);
         tile_store<D, true, false>(vreg, v_lds, nullptr, tid);
         __syncthreads();
         if (t + 1 < n_tiles) {
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         for (int df = 0; df < DF; ++df)
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const bf16x8 ktf = frag_t(kt_lds, df, c, lane);
+                const bf16x8 ktf = frag_tr(k_lds, df, c, lane);      // K^T fragment by transposing read
 #pragma unroll
                 for (int f = 0; f < NF; ++f)
                     acc[f][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[f][c], acc[f][df], 0, 0, 0);
@@ -361,10 +361,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 template <int D>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     constexpr int DC = (D + 31) / 32, DF = D / 16;
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 RM + 2 T images + 512 B of row statistics
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // Q and dO row-major images + 512 B of row statistics
     char* q_lds = smem; char* do_lds = smem + AT_RM_BYTES;
-    char* qt_lds = smem + 2 * AT_RM_BYTES; char* dot_lds = qt_lds + AT_T_BYTES(D);
-    float* stat = (float*)(dot_lds + AT_T_BYTES(D));   // [0..63] lse, [64..127] delta
+    float* stat = (float*)(smem + 2 * AT_RM_BYTES);    // [0..63] lse, [64..127] delta
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nkb = a.nqb;                              // key blocks per segment (host passes ceil(max_q_len/64))
@@ -418,8 +417,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
             const int h = hk * rep + it / q_tiles, q0 = q_first + (it % q_tiles) * BKV;
             const long tok0 = qs.q_start + q0;
             __syncthreads();
-            tile_store<D, true, true>(qreg, q_lds, qt_lds, tid);
-            tile_store<D, true, true>(dreg, do_lds, dot_lds, tid);
+            tile_store<D, true, false>(qreg, q_lds, nullptr, tid);
+            tile_store<D, true, false>(dreg, do_lds, nullptr, tid);
             if (tid < 128) {
                 const int r = tid & 63;
                 const long tk = min(tok0 + r, (long)qs.q_start + qs.q_len - 1);
@@ -452,10 +451,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
             const bf16x8 sf0 = pack_slots(dsv[0], dsv[1]), sf1 = pack_slots(dsv[2], dsv[3]);
 #pragma unroll
             for (int df = 0; df < DF; ++df) {
-                dva[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t(dot_lds, df, 0, lane), pf0, dva[df], 0, 0, 0);
-                dva[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t(dot_lds, df, 1, lane), pf1, dva[df], 0, 0, 0);
-                dka[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t(qt_lds, df, 0, lane), sf0, dka[df], 0, 0, 0);
-                dka[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t(qt_lds, df, 1, lane), sf1, dka[df], 0, 0, 0);
+                dva[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(do_lds, df, 0, lane), pf0, dva[df], 0, 0, 0);
+                dva[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(do_lds, df, 1, lane), pf1, dva[df], 0, 0, 0);
+                dka[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(q_lds, df, 0, lane), sf0, dka[df], 0, 0, 0);
+                dka[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(q_lds, df, 1, lane), sf1, dka[df], 0, 0, 0);
             }
         }
     }
@@ -525,13 +524,13 @@ extern "C" int spacer_attn_bwd(const void* q, const void* k, const void* v, cons
     if (D == 128) {
         hipLaunchKernelGGL(attn_delta_kernel<128>, dim3(dgrid), dim3(256), 0, s, a);
         hipLaunchKernelGGL((attn_bwd_dq_kernel<128, NFQ>), qgrid, dim3(256), 0, s, a);
-        static const int once128 = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AT_RM_BYTES + 2 * AT_T_BYTES(128) + 512);
+        static const int once128 = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AT_RM_BYTES + 512);
         (void)once128;
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, kgrid, dim3(256), 2 * AT_RM_BYTES + 2 * AT_T_BYTES(128) + 512, s, b);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, kgrid, dim3(256), 2 * AT_RM_BYTES + 512, s, b);
     } else {
         hipLaunchKernelGGL(attn_delta_kernel<80>, dim3(dgrid), dim3(256), 0, s, a);
         hipLaunchKernelGGL((attn_bwd_dq_kernel<80, NFQ>), qgrid, dim3(256), 0, s, a);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<80>, kgrid, dim3(256), 2 * AT_RM_BYTES + 2 * AT_T_BYTES(80) + 512, s, b);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<80>, kgrid, dim3(256), 2 * AT_RM_BYTES + 512, s, b);
     }
     SP_CHECK_LAUNCH();
     return SPACER_OK;

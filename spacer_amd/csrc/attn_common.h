@@ -79,6 +79,24 @@ __device__ __forceinline__ bf16x8 frag_t(const char* t_lds, int db, int c, int l
     const uint2 hi = *(const uint2*)(t_lds + d * AT_T_ROW_BYTES + ((((2 * c + 1) * 4 + g) ^ sw) * 8));
     return __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
 }
+// The same operand fragment as frag_t, but read from the ROW-MAJOR image with gfx950's transposing LDS read
+// (ds_read_b64_tr_b16): inside each 16-lane group the lanes supply the addresses of a [4 rows][16 columns] block -- lane i
+// the 8 bytes of row i >> 2, columns 4 (i & 3) .. +3 -- and lane i receives column i of the 4 rows.  Group g asks for rows
+// (2c)*16 + 4g .. +3 (slots 0..3) and (2c+1)*16 + 4g .. +3 (slots 4..7), columns db*16 .. +15, so no transposed image, no
+// transposing store pass (VALU repacking + ds_write_b64) is needed at all.  (Semantics: scripts/probes/tr_probe.hip.)
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+__device__ __forceinline__ bf16x8 frag_tr(const char* rm_lds, int db, int c, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    const int chunk = db * 2 + ((i & 3) >> 1), sub = (i & 1) * 8;
+    const int r0 = (2 * c) * 16 + 4 * g + (i >> 2), r1 = r0 + 16;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4_t*)(rm_lds + r0 * AT_RM_ROW_BYTES + ((chunk ^ (r0 & 15)) * 16) + sub));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4_t*)(rm_lds + r1 * AT_RM_ROW_BYTES + ((chunk ^ (r1 & 15)) * 16) + sub));
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    const s16x8_t both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, both);
+}
 // pack two stacked C-layout tiles (rows 2c*16.., (2c+1)*16..) into the matching contraction-slot operand
 __device__ __forceinline__ bf16x8 pack_slots(const float (&a)[4], const float (&b)[4]) {
     return __builtin_bit_cast(bf16x8, make_uint4(pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3]), pack_bf2(b[0], b[1]), pack_bf2(b[2], b[3])));
