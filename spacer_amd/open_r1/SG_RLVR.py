@@ -14,7 +14,7 @@ import torch
 
 from . import rewards as R
 from .config import parse_args
-from .trainer import SGRLVRTrainer
+from .trainer import Qwen2VLGRPOVLLMTrainerModified, SGRLVRTrainer
 
 EXAMPLE_MAP = {"table": [[0, 3], [5, 7]], "chair": [[9, 3]], "window": [[6, 5]]}
 _THINK = ("Please think about this question as if you were a human pondering deeply. "
@@ -74,6 +74,21 @@ def main(script_args, training_args, model_args):
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         torch.distributed.init_process_group("nccl")           # RCCL over xGMI
         pg = torch.distributed.group.WORLD
+    topology = None
+    if training_args.use_vllm:                  # N training ranks + the last rank as the dedicated rollout GPU
+        if pg is None:
+            raise ValueError("--use_vllm true needs one process more than training GPUs (torchrun --nproc_per_node N+1): the last "
+                             "rank is the rollout engine, as the reference needs one GPU more than --num_processes")
+        from ..rollout_server import make_topology
+        from .trainer.vllm_grpo_trainer_modified import run_rollout_rank
+        topology = make_topology(pg)
+        if topology.is_server:
+            from ..qwen2vl.checkpoint import config_of_dir
+            from ..qwen2vl.config import preset_for
+            cfg = config_of_dir(model_args.model_name_or_path) or preset_for(model_args.model_name_or_path)
+            served = run_rollout_rank(cfg, topology, torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
+            print(f"[spacer_amd] rollout rank served {served} generate requests", flush=True)
+            return
     reward_funcs = [R.reward_funcs_registry[n] for n in script_args.reward_funcs]
     if os.path.exists(script_args.map_annotation):
         R.load_map(script_args.map_annotation)
@@ -83,10 +98,13 @@ def main(script_args, training_args, model_args):
     processor = AutoProcessor.from_pretrained(model_args.model_name_or_path)
     processor.pad_token_id = processor.tokenizer.pad_token_id
     processor.eos_token_id = processor.tokenizer.eos_token_id
-    trainer = SGRLVRTrainer(model=model_args.model_name_or_path, reward_funcs=reward_funcs, args=training_args,
-                            script_args=script_args, train_dataset=rows, processing_class=processor,
-                            attn_implementation=model_args.attn_implementation, max_pixels=script_args.max_pixels,
-                            min_pixels=script_args.min_pixels, process_group=pg)
+    common = dict(model=model_args.model_name_or_path, reward_funcs=reward_funcs, args=training_args, script_args=script_args,
+                  train_dataset=rows, processing_class=processor, attn_implementation=model_args.attn_implementation,
+                  max_pixels=script_args.max_pixels, min_pixels=script_args.min_pixels)
+    if topology is not None:
+        trainer = Qwen2VLGRPOVLLMTrainerModified(topology=topology, **common)
+    else:
+        trainer = SGRLVRTrainer(process_group=pg, **common)          # SG-RLVR.py:360 hard-codes this class
     trainer.train(resume_from_checkpoint=training_args.resume_from_checkpoint)
     trainer.save_model(training_args.output_dir)
 

@@ -62,6 +62,10 @@ class GRPOConfig:                              # the trl.GRPOConfig / TrainingAr
     deepspeed: Optional[str] = None
     top_k: int = 50                # era default of the GenerationConfig the reference builds
     use_decode_graph: bool = True
+    # vLLM-trainer topology (trl.GRPOConfig fields read by vllm_grpo_trainer_modified.py:300,325,362): generation on a dedicated GPU
+    use_vllm: bool = False
+    vllm_device: str = "auto"                  # "auto" = the first GPU index after the training ranks (:325-327)
+    vllm_gpu_memory_utilization: float = 0.9   # accepted and ignored
 
 
 @dataclass

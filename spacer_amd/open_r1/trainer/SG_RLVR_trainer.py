@@ -249,6 +249,10 @@ class SGRLVRTrainer:
             out[:, i] = torch.tensor([float(v) for v in vals], dtype=torch.float32)
         return out
 
+    def _generate(self, prompts: List[PromptInput], n: int, sp: SamplingParams) -> torch.Tensor:
+        """TR:463-481: n sampled completions per prompt, int64 [len(prompts) * n, C].  The rollout-server trainer overrides this."""
+        return self.engine.roll.generate(prompts, n, sp, use_graph=self.args.use_decode_graph)
+
     # ------------------------------------------------------------------ the step (TR:384-686)
     def _prepare(self, inputs, shuffle_seed: int = 0) -> dict:
         """Host half of a step (TR:395-430, and the shuffled twin's inputs TR:442-460): chat template, frame decode + resize
@@ -287,11 +291,11 @@ class SGRLVRTrainer:
             # The reference calls generate twice (G rollouts, then G/2 on the shuffled frames).  Decoding is bound by
             # streaming the weights, not by the number of rows, so both prompts decode as ONE batch of 2G rows and the
             # shuffled prompt's surplus rollouts are dropped: the twin costs its prefill, not a second decode loop.
-            both = eng.roll.generate([prompt, sprompt], G, sp, use_graph=self.args.use_decode_graph)
+            both = self._generate([prompt, sprompt], G, sp)
             completion_ids, shuffled_ids = both[:G], both[G:G + self.shuffled_num_generations]
             shuffled_rpf = self._run_rewards(inputs, prompts, shuffled_ids, self.shuffled_num_generations)
         else:
-            completion_ids = eng.roll.generate([prompt], G, sp, use_graph=self.args.use_decode_graph)
+            completion_ids = self._generate([prompt], G, sp)
 
         rewards_per_func = self._run_rewards(inputs, prompts, completion_ids, G, video_path=video_path)
         rewards, temporal_reward = temporal_bonus(rewards_per_func, shuffled_rpf, self.temporal, has_video)
