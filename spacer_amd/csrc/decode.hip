@@ -491,6 +491,228 @@ __global__ __launch_bounds__(NW * 64, (NW == 4) ? 2 : 1) void attn_decode_mfma_k
     }
 }
 
+// =============================================================================== decode attention, shared prompt: one launch + merge
+// The prompt-key blocks (role A: prompt, kv head, key split -- 64 (rollout, head) columns) and the tail-key blocks (role B:
+// sequence, kv head -- REP columns) are independent until the final softmax merge, so they run in ONE launch (512 co-resident
+// workgroups at the cfg3 shape) and a small merge kernel combines the PRE_SPLITS prompt partials with the tail partial.
+// Before: prefix kernel -> tail kernel (which also merged) = two latency-bound launches in series, 21.5 us per layer at an
+// empty tail.  V tiles are staged row-major and read through the transposing LDS read (frag_tr) in both roles; role A keeps
+// two K/V tiles in flight in registers.
+template <int REP>
+__global__ __launch_bounds__(256, 2) void attn_decode_split_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ pk,
+                                                                   const bf16_t* __restrict__ pv, const int* __restrict__ plen,
+                                                                   const bf16_t* __restrict__ tk, const bf16_t* __restrict__ tv,
+                                                                   const int* __restrict__ tail_len, float* __restrict__ pre,
+                                                                   float* __restrict__ tailp, int n_prefix_blocks, int Kn, int Pmax,
+                                                                   int Cmax, int Hq, int Hkv, float scale) {
+    constexpr int D = 128, DC = 4, DF = 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];               // 64 KiB: A: K + V images; B: 4 wave-private V images
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    f32x4 oacc[DF];
+#pragma unroll
+    for (int d = 0; d < DF; ++d) oacc[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // one 64-key tile of scores st (K-major C layout) -> online softmax -> O^T += V^T . P^T with V^T fragments from `v_img`
+    auto softmax_pv = [&](f32x4 (&st)[4], int key0, int n_valid, const char* v_img) {
+        float p[4][4], mx = -INFINITY;
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sv = (key0 + kf * 16 + g * 4 + r < n_valid) ? st[kf][r] * scale : -INFINITY;
+                p[kf][r] = sv;
+                mx = fmaxf(mx, sv);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);           // finite: a visited tile has >= 1 valid key
+        const float alpha = __expf(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { p[kf][r] = __expf(p[kf][r] - m_new); psum += p[kf][r]; }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < DF; ++d) oacc[d] *= alpha;
+        const bf16x8 pf0 = pack_slots(p[0], p[1]), pf1 = pack_slots(p[2], p[3]);
+#pragma unroll
+        for (int df = 0; df < DF; ++df) {
+            oacc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(v_img, df, 0, lane), pf0, oacc[df], 0, 0, 0);
+            oacc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(v_img, df, 1, lane), pf1, oacc[df], 0, 0, 0);
+        }
+    };
+
+    if ((int)blockIdx.x < n_prefix_blocks) {
+        // ------------------------------------------------------------------ role A: prompt keys x all columns of the prompt
+        const int sp = blockIdx.x % PRE_SPLITS, hk = (blockIdx.x / PRE_SPLITS) % Hkv, pr = blockIdx.x / (PRE_SPLITS * Hkv);
+        char* k_lds = smem;
+        char* v_lds = smem + AT_RM_BYTES;
+        const int P = plen[pr];
+        const int tiles = (P + 63) >> 6, tps = (tiles + PRE_SPLITS - 1) / PRE_SPLITS;
+        const int t0 = sp * tps, t1 = min(tiles, t0 + tps);
+        const int col = wave * 16 + l15;                       // (rollout, head) column of this lane
+        const bool col_ok = col < Kn * REP;
+        bf16x8 qf[DC];
+        {
+            const int kr = col_ok ? col / REP : 0, hr = col_ok ? col % REP : 0;
+            const bf16_t* qp = q + ((long)(pr * Kn + kr) * Hq + hk * REP + hr) * D;
+#pragma unroll
+            for (int dc = 0; dc < DC; ++dc) {
+                uint4 t = make_uint4(0, 0, 0, 0);
+                if (col_ok) t = *(const uint4*)(qp + dc * 32 + g * 8);
+                qf[dc] = __builtin_bit_cast(bf16x8, t);
+            }
+        }
+        const long row_stride = (long)Hkv * D;
+        uint4 ka[4], va[4], kb[4], vb[4];
+        auto fetch = [&](uint4 (&kr_)[4], uint4 (&vr_)[4], int t) {
+            const long off = (((long)pr * Pmax + t * 64) * Hkv + hk) * D;
+            tile_load<D>(kr_, pk + off, row_stride, P - t * 64, tid);
+            tile_load<D>(vr_, pv + off, row_stride, P - t * 64, tid);
+        };
+        auto step = [&](uint4 (&kr_)[4], uint4 (&vr_)[4], int t) {
+            __syncthreads();
+            tile_store<D, true, false>(kr_, k_lds, nullptr, tid);
+            tile_store<D, true, false>(vr_, v_lds, nullptr, tid);
+            __syncthreads();
+            if (t + 2 < t1) fetch(kr_, vr_, t + 2);              // this register set is free again: two tiles stay in flight
+            f32x4 st[4];
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf) {
+                st[kf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int dc = 0; dc < DC; ++dc)
+                    st[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rm(k_lds, kf, dc, lane), qf[dc], st[kf], 0, 0, 0);
+            }
+            softmax_pv(st, t * 64, P, v_lds);
+        };
+        if (t0 < t1) fetch(ka, va, t0);
+        if (t0 + 1 < t1) fetch(kb, vb, t0 + 1);
+        for (int t = t0; t < t1; t += 2) {
+            step(ka, va, t);
+            if (t + 1 < t1) step(kb, vb, t + 1);
+        }
+        l_run += __shfl_xor(l_run, 16, 64);
+        l_run += __shfl_xor(l_run, 32, 64);
+        // lane holds O^T[d = df*16 + g*4 + r][col]; partial record = [D floats O | m | l]
+        float* rec = pre + (((long)(pr * Hkv + hk) * PRE_SPLITS + sp) * 64 + col) * (D + 2);
+#pragma unroll
+        for (int df = 0; df < DF; ++df)
+            *(float4*)(rec + df * 16 + g * 4) = make_float4(oacc[df][0], oacc[df][1], oacc[df][2], oacc[df][3]);
+        if (g == 0) { rec[D] = m_run; rec[D + 1] = l_run; }
+        return;
+    }
+    // ---------------------------------------------------------------------- role B: the sequence's own (generated) keys
+    const int bi = blockIdx.x - n_prefix_blocks;
+    const int b = bi / Hkv, hk = bi % Hkv;
+    const int total = *tail_len + 1;
+    char* v_img = smem + wave * AT_RM_BYTES;
+    bf16x8 qf[DC];
+    {
+        const bf16_t* qp = q + ((long)b * Hq + hk * REP + min(l15, REP - 1)) * D;
+#pragma unroll
+        for (int dc = 0; dc < DC; ++dc) {
+            uint4 t = make_uint4(0, 0, 0, 0);
+            if (l15 < REP) t = *(const uint4*)(qp + dc * 32 + g * 8);
+            qf[dc] = __builtin_bit_cast(bf16x8, t);
+        }
+    }
+    auto key_ptr = [&](const bf16_t* base, int key) -> const bf16_t* {
+        return base + (((long)b * Cmax + min(key, total - 1)) * Hkv + hk) * D;
+    };
+    for (int k0 = wave * 64; k0 < total; k0 += 4 * 64) {
+        // V tile -> registers first (lane: 16-byte chunk l15 of rows (g + 4 i) * 4 + j), then K fragments straight from memory
+        uint4 vreg[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) vreg[i][j] = *(const uint4*)(key_ptr(tv, k0 + (g + 4 * i) * 4 + j) + l15 * 8);
+        f32x4 st[4];
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf) {
+            st[kf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const bf16_t* kp = key_ptr(tk, k0 + kf * 16 + l15) + g * 8;
+#pragma unroll
+            for (int dc = 0; dc < DC; ++dc) {
+                const bf16x8 kfr = __builtin_bit_cast(bf16x8, *(const uint4*)(kp + dc * 32));
+                st[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[dc], st[kf], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = (g + 4 * i) * 4 + j;
+                *(uint4*)(v_img + row * AT_RM_ROW_BYTES + ((l15 ^ (row & 15)) * 16)) = vreg[i][j];
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private image complete before any lane reads fragments
+        __builtin_amdgcn_wave_barrier();
+        softmax_pv(st, k0, total, v_img);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragments read before the next tile overwrites the image
+        __builtin_amdgcn_wave_barrier();
+    }
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    __syncthreads();                                   // every wave is done with its V image
+    float* mo = (float*)smem;                          // [4][D][16] O^T, then [4][16] m, [4][16] l
+    float* mm = mo + 4 * D * 16;
+    float* ml = mm + 4 * 16;
+#pragma unroll
+    for (int df = 0; df < DF; ++df)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mo[(wave * D + df * 16 + g * 4 + r) * 16 + l15] = oacc[df][r];
+    if (g == 0) { mm[wave * 16 + l15] = m_run; ml[wave * 16 + l15] = l_run; }
+    __syncthreads();
+    float* rec0 = tailp + (long)bi * REP * (D + 2);
+    for (int i = tid; i < REP * (D + 2); i += 256) {
+        const int qh = i / (D + 2), d = i % (D + 2);
+        float M = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) M = fmaxf(M, mm[w * 16 + qh]);        // finite: wave 0 always has key 0
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float mw = mm[w * 16 + qh];
+            const float f = (mw == -INFINITY) ? 0.f : __expf(mw - M);
+            acc += (d < D ? mo[(w * D + d) * 16 + qh] : ml[w * 16 + qh]) * f;
+        }
+        rec0[i] = d == D ? M : acc;                    // [D floats O | m | l] like the prefix records (slot D+1 = l)
+    }
+}
+
+// o[b, head, :] = softmax-merge of the PRE_SPLITS prompt partials (column (b - pr*Kn)*REP + qh) and the tail partial
+template <int REP>
+__global__ __launch_bounds__(256) void attn_decode_merge_kernel(const float* __restrict__ pre, const float* __restrict__ tailp,
+                                                                bf16_t* __restrict__ o, int Kn, int Hq, int Hkv) {
+    constexpr int D = 128;
+    const int b = blockIdx.x, hk = blockIdx.y, pr = b / Kn;
+    const float* tp = tailp + ((long)b * Hkv + hk) * REP * (D + 2);
+    for (int i = threadIdx.x; i < REP * D; i += 256) {
+        const int qh = i / D, d = i % D;
+        const int col = (b - pr * Kn) * REP + qh;
+        const float* pp = pre + ((long)(pr * Hkv + hk) * PRE_SPLITS * 64 + col) * (D + 2);
+        const float mt = tp[qh * (D + 2) + D];
+        float M = mt;
+        float ms[PRE_SPLITS];
+#pragma unroll
+        for (int sp = 0; sp < PRE_SPLITS; ++sp) { ms[sp] = pp[(long)sp * 64 * (D + 2) + D]; M = fmaxf(M, ms[sp]); }
+        const float ft = __expf(mt - M);
+        float L = tp[qh * (D + 2) + D + 1] * ft, O = tp[qh * (D + 2) + d] * ft;
+#pragma unroll
+        for (int sp = 0; sp < PRE_SPLITS; ++sp) {
+            const float* q1 = pp + (long)sp * 64 * (D + 2);
+            const float f = (ms[sp] == -INFINITY) ? 0.f : __expf(ms[sp] - M);
+            L += q1[D + 1] * f;
+            O += q1[d] * f;
+        }
+        o[((long)b * Hq + hk * REP + qh) * D + d] = f2bf(O / L);
+    }
+}
+
 // =============================================================================== decode attention (VALU reference form)
 // Workgroup = (sequence b, kv head).  16 lanes x 8 dims cover one key; a wave scores 4 keys per step, the
 // 4 waves stride over keys; all `REP` q heads of the GQA group are scored against each loaded key/value.
@@ -713,6 +935,30 @@ static int launch_attn_decode(const void* q, const void* prefix_k, const void* p
                            (const bf16_t*)prefix_k, (const bf16_t*)prefix_v, prefix_len, prompt_of, (const bf16_t*)tail_k, \
                            (const bf16_t*)tail_v, tail_len_dev, (bf16_t*)o, Pmax, Cmax, Hq, Hkv, scale, pre_ws, Kn); \
     }
+    if (pre_ws && !valu && getenv("SPACER_DECODE_ATTN_SERIAL") == nullptr) {
+        SP_REQUIRE(Kn > 0 && Kn * rep <= 64 && B % Kn == 0, SPACER_EINVAL, "attn_decode_shared: Kn*rep=%d must be <= 64", Kn * rep);
+        const int nA = (B / Kn) * Hkv * PRE_SPLITS;
+        float* tailp = pre_ws + (long)(B / Kn) * Hkv * PRE_SPLITS * 64 * (128 + 2);
+#define LAUNCH_SPLIT(R)                                                                                                 \
+        {                                                                                                               \
+            static const int once = hipFuncSetAttribute((const void*)attn_decode_split_kernel<R>,                       \
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 4 * AT_RM_BYTES);   \
+            (void)once;                                                                                                 \
+            hipLaunchKernelGGL((attn_decode_split_kernel<R>), dim3(nA + B * Hkv), dim3(256), 4 * AT_RM_BYTES, s, (const bf16_t*)q, \
+                               (const bf16_t*)prefix_k, (const bf16_t*)prefix_v, prefix_len, (const bf16_t*)tail_k,       \
+                               (const bf16_t*)tail_v, tail_len_dev, pre_ws, tailp, nA, Kn, Pmax, Cmax, Hq, Hkv, scale);   \
+            hipLaunchKernelGGL((attn_decode_merge_kernel<R>), dim3(B, Hkv), dim3(256), 0, s, (const float*)pre_ws,       \
+                               (const float*)tailp, (bf16_t*)o, Kn, Hq, Hkv);                                           \
+        }
+        switch (rep) {
+            case 1: LAUNCH_SPLIT(1); break; case 2: LAUNCH_SPLIT(2); break; case 3: LAUNCH_SPLIT(3); break; case 4: LAUNCH_SPLIT(4); break;
+            case 5: LAUNCH_SPLIT(5); break; case 6: LAUNCH_SPLIT(6); break; case 7: LAUNCH_SPLIT(7); break; case 8: LAUNCH_SPLIT(8); break;
+            default: SP_REQUIRE(false, SPACER_EINVAL, "attn_decode: GQA ratio %d not instantiated", rep);
+        }
+#undef LAUNCH_SPLIT
+        SP_CHECK_LAUNCH();
+        return SPACER_OK;
+    }
     if (pre_ws) {
         SP_REQUIRE(Kn > 0 && Kn * rep <= 64 && B % Kn == 0, SPACER_EINVAL, "attn_decode_shared: Kn*rep=%d must be <= 64", Kn * rep);
 #define LAUNCH_PRE(R)                                                                                                   \
@@ -750,7 +996,8 @@ extern "C" int spacer_attn_decode(const void* q, const void* prefix_k, const voi
 }
 
 extern "C" long spacer_attn_decode_workspace_bytes(int n_prompts, int Hkv) {
-    return (long)n_prompts * Hkv * PRE_SPLITS * 64 * (128 + 2) * (long)sizeof(float);
+    // PRE_SPLITS prompt partials of 64 columns + one tail partial per (sequence, head) (Kn * rep <= 64 of them per prompt)
+    return (long)n_prompts * Hkv * (PRE_SPLITS + 1) * 64 * (128 + 2) * (long)sizeof(float);
 }
 
 extern "C" int spacer_attn_decode_shared(const void* q, const void* prefix_k, const void* prefix_v, const int* prefix_len,

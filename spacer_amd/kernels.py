@@ -273,6 +273,10 @@ def attn_decode(q, prefix_k, prefix_v, prefix_len, prompt_of, tail_k, tail_v, ta
     return out
 
 
+def attn_decode_workspace_bytes(n_prompts: int, Hkv: int) -> int:
+    return int(_lib.load().spacer_attn_decode_workspace_bytes(n_prompts, Hkv))
+
+
 def attn_decode_shared(q, prefix_k, prefix_v, prefix_len, prompt_of, tail_k, tail_v, tail_len_dev, Kn, Hq, Hkv, D, scale, *,
                        out=None, workspace=None):
     """attn_decode with the prompt keys scored once per prompt for its Kn rollouts (rows b = prompt*Kn + k)."""

@@ -167,7 +167,7 @@ class RolloutEngine:
         L, Hkv, D, H = cfg.layers, cfg.kv_heads, cfg.head_dim, cfg.hidden
         st = dict(
             B=B, pk=pk, pv=pv, packed=self._pack(), Kn=Kn, shared_prefix=Kn * (cfg.heads // cfg.kv_heads) <= 64 and Kn > 1,
-            attn_ws=torch.empty(nP * cfg.kv_heads * 8 * 64 * (cfg.head_dim + 2), device=dev, dtype=F32),
+            attn_ws=torch.empty(K.attn_decode_workspace_bytes(nP, cfg.kv_heads) // 4, device=dev, dtype=F32),
             plen=torch.tensor(plen, dtype=torch.int32, device=dev),
             prompt_of=torch.arange(B, dtype=torch.int32, device=dev) // Kn,
             pos_base=torch.tensor(pos_base, dtype=torch.int32, device=dev).repeat_interleave(Kn).contiguous(),
