@@ -19,3 +19,9 @@ for rows, cols, f32 in [(5498, 3584, True), (4160, 1280, True)]:
     t = e0.elapsed_time(e1) / 20 * 1e-3
     nbytes = rows * cols * (4 + 2 + 4 + 4)
     print(f"  rmsnorm_bwd {rows}x{cols}: {t*1e6:7.1f} us  {nbytes/t/1e12:5.2f} TB/s")
+    # variants: no accumulate
+    for acc in (True, False):
+        e0.record()
+        for _ in range(20): K.rmsnorm_bwd(x, w, dy, rstd, dx, dw, accumulate=acc)
+        e1.record(); torch.cuda.synchronize()
+        print(f"    accumulate={acc}: {e0.elapsed_time(e1) / 20 * 1e3:7.1f} us")
