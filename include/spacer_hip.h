@@ -62,6 +62,15 @@ int spacer_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, void* 
 
 long spacer_gemm_workspace_bytes(void);
 
+/* SwiGLU MLP input half in one launch (HF Qwen2MLP.forward: act_fn(gate_proj(x)) * up_proj(x), modeling_qwen2_vl.py Qwen2MLP;
+ * Qwen2.5-VL vision MLP with biases): W bf16 [2*inter, K] = [gate_proj rows | up_proj rows], bias bf16 [2*inter] or NULL.
+ *   act bf16 [M, inter] = silu(A.Wgate^T + bgate) * (A.Wup^T + bup);   gu bf16 [M, 2*inter] (or NULL) = the rounded gate|up.
+ * Same bits as spacer_gemm_bf16_nt into gu + spacer_swiglu_fwd.  Only shapes the 256-tile kernel takes:
+ * spacer_gemm_swiglu_fused(M, inter, K) != 0 (inter % 128 == 0, K % 64 == 0, large enough M); otherwise SPACER_EINVAL. */
+int spacer_gemm_swiglu_fused(int M, int inter, int K);
+int spacer_gemm_swiglu_bf16(const void* A, long lda, const void* W, long ldb, const void* bias, void* act, long ld_act, void* gu,
+                            long ld_gu, int M, int inter, int K, spacer_stream_t stream);
+
 /* Which tile spacer_gemm_bf16_nt runs an [M,N,K] problem on: 256 (gemm_bf16_nt_256h_kernel) or 128 (gemm_bf16_nt_kernel).
  * Pure host function; profilers use it to attribute a launch to the kernel rocprof will name. */
 int spacer_gemm_tile(int M, int N, int K, int have_workspace);

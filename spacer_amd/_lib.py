@@ -69,10 +69,11 @@ SIGNATURES = {
     "spacer_decode_rope_table": [_p, _p, _f, _p, _p, _i, _i, _p],
     "spacer_decode_qkv_finish": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "spacer_swiglu_f32_fwd": [_p, _p, _i, _i, _p],
+    "spacer_gemm_swiglu_bf16": [_p, _l, _p, _l, _p, _p, _l, _p, _l, _i, _i, _i, _p],
     "spacer_sumsq_f32": [_p, _l, _p, _p],
     "spacer_adamw_step": [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _f, _p, _f, _f, _p],
 }
-OTHER_SYMBOLS = ["spacer_last_error", "spacer_version", "spacer_sample_workspace_bytes", "spacer_attn_decode_workspace_bytes", "spacer_gemm_tile", "spacer_gemm_workspace_bytes"]
+OTHER_SYMBOLS = ["spacer_last_error", "spacer_version", "spacer_sample_workspace_bytes", "spacer_attn_decode_workspace_bytes", "spacer_gemm_tile", "spacer_gemm_workspace_bytes", "spacer_gemm_swiglu_fused"]
 
 _lib = None
 
@@ -97,6 +98,8 @@ def load() -> C.CDLL:
     lib.spacer_sample_workspace_bytes.restype = C.c_long
     lib.spacer_gemm_tile.argtypes = [_i, _i, _i, _i]
     lib.spacer_gemm_tile.restype = _i
+    lib.spacer_gemm_swiglu_fused.argtypes = [_i, _i, _i]
+    lib.spacer_gemm_swiglu_fused.restype = _i
     lib.spacer_gemm_workspace_bytes.argtypes = []
     lib.spacer_gemm_workspace_bytes.restype = C.c_long
     lib.spacer_attn_decode_workspace_bytes.argtypes = [_i, _i]

@@ -37,6 +37,11 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int full_tiles, splits;     // 256h kernel: tiles owned whole / K splits of each remaining (tail) tile
     float* slabs;               // split-K workspace (caller's): [tail tile][split][256x256] fp32 partial tiles
+    // fused SwiGLU (256h kernel only, swiglu_inter = I > 0): B = [gate rows 0..I) | up rows I..2I); tile column tn takes gate
+    // rows tn*128.. as its columns 0..127 and up rows I + tn*128.. as its columns 128..255, and the epilogue writes
+    // act[m, tn*128 + c] = silu(gate) * up into C (bf16 [M, I]); gate|up themselves go to C2 (bf16 [M, 2I]) when it is given.
+    int swiglu_inter;
+    void* C2; long ldc2;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -300,6 +305,7 @@ extern "C" int spacer_gemm_bf16_nt(const void* A, long lda, const void* B, long 
     SP_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, SPACER_EINVAL, "gemm: lda/ldb must be multiples of 8 elements");
     SP_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, SPACER_EINVAL, "gemm: A/B must be 16-byte aligned");
     GemmArgs g;
+    g.swiglu_inter = 0; g.C2 = nullptr; g.ldc2 = 0;
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.bias = epi ? (const bf16_t*)epi->bias : nullptr;
@@ -334,6 +340,39 @@ extern "C" int spacer_gemm_bf16_nt(const void* A, long lda, const void* B, long 
         g.tiles_m = cdiv(M, 128); g.tiles_n = cdiv(N, 128);
         hipLaunchKernelGGL((gemm_bf16_nt_kernel<2, 2, 4, 4>), dim3(g.tiles_m * g.tiles_n), dim3(256), LDS, s, g);
     }
+    SP_CHECK_LAUNCH();
+    return SPACER_OK;
+}
+
+// act[M, I] (bf16) = silu(A . Wgate^T + bgate) * (A . Wup^T + bup) with W = [gate rows | up rows] ([2I, K]), in ONE launch on the
+// 256-tile kernel: the gate and up columns of the same outputs meet in one tile (see GemmArgs::swiglu_inter).  gu (bf16
+// [M, 2I], may be NULL) additionally receives the rounded gate|up values the backward pass needs.  Bit-identical to
+// spacer_gemm_bf16_nt into gu followed by spacer_swiglu_fwd.  Returns SPACER_EINVAL when the problem would not run on the
+// 256 tile (spacer_gemm_swiglu_fused(M, inter, K) == 0): the caller then takes the two-step path.
+extern "C" int spacer_gemm_swiglu_fused(int M, int inter, int K) {
+    return inter > 0 && inter % 128 == 0 && K % BK == 0 && choose_tile(M, 2 * inter, K, false) == 256;
+}
+
+extern "C" int spacer_gemm_swiglu_bf16(const void* A, long lda, const void* W, long ldb, const void* bias, void* act, long ld_act,
+                                       void* gu, long ld_gu, int M, int inter, int K, spacer_stream_t stream) {
+    SP_REQUIRE(A && W && act, SPACER_EINVAL, "gemm_swiglu: null operand");
+    SP_REQUIRE(M > 0 && inter > 0 && K > 0, SPACER_EINVAL, "gemm_swiglu: empty shape M=%d I=%d K=%d", M, inter, K);
+    SP_REQUIRE(spacer_gemm_swiglu_fused(M, inter, K), SPACER_EINVAL,
+               "gemm_swiglu: M=%d I=%d K=%d does not run on the 256 tile (I %% 128, K %% %d); use gemm + swiglu_fwd", M, inter, K, BK);
+    SP_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ld_act % 4 == 0 && (!gu || ld_gu % 4 == 0), SPACER_EINVAL, "gemm_swiglu: leading dimensions");
+    SP_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)act % 8) == 0 && ((uintptr_t)gu % 8) == 0, SPACER_EINVAL,
+               "gemm_swiglu: misaligned operand");
+    GemmArgs g;
+    g.A = (const bf16_t*)A; g.B = (const bf16_t*)W; g.C = act;
+    g.lda = lda; g.ldb = ldb; g.ldc = ld_act; g.M = M; g.N = 2 * inter; g.K = K;
+    g.bias = (const bf16_t*)bias; g.resid = nullptr; g.ldr = 0; g.out_f32 = 0; g.act = SPACER_ACT_NONE; g.alpha = 1.f;
+    g.swiglu_inter = inter; g.C2 = gu; g.ldc2 = ld_gu;
+    g.tiles_m = cdiv(M, 256); g.tiles_n = inter / 128;
+    g.full_tiles = g.tiles_m * g.tiles_n; g.splits = 1; g.slabs = nullptr;      // no K-split tail: the reduce kernel has no SwiGLU form
+    constexpr int LDS = 8 * 128 * BK * 2;
+    static const int once = hipFuncSetAttribute((const void*)gemm_bf16_nt_256h_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)once;
+    hipLaunchKernelGGL((gemm_bf16_nt_256h_kernel<true>), dim3((unsigned)g.full_tiles), dim3(512), LDS, (hipStream_t)stream, g);
     SP_CHECK_LAUNCH();
     return SPACER_OK;
 }

@@ -76,7 +76,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
             const int hr = (wave * 2 + i) * 8 + (lane >> 3);                 // image row
             const int chunk = (lane & 7) ^ ((hr >> 1) & 7);                  // logical 16-B chunk this lane fetches
             int ra = m0 + (hr >> 6) * 128 + h * 64 + (hr & 63);
-            int rb = n0 + (hr >> 5) * 64 + h * 32 + (hr & 31);
+            const int lcol = (hr >> 5) * 64 + h * 32 + (hr & 31);            // tile column this B row produces
+            int rb = n0 + lcol;
+            if (g.swiglu_inter) rb = (lcol < 128 ? 0 : g.swiglu_inter - 128) + tn * 128 + lcol;
             ra = ra < g.M ? ra : g.M - 1;
             rb = rb < g.N ? rb : g.N - 1;
             offA[h][i] = (unsigned)((long)ra * g.lda + chunk * 8);
@@ -218,6 +220,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
     // the fragment writes (8 rows per store group) and the row reads conflict-free.  alpha / bias / activation are applied
     // on the way in, residual + conversion on the way out (one rounding, as before).
     const EpiArgs e = {g.C, g.bias, g.resid, g.ldc, g.ldr, g.M, g.N, g.out_f32, g.act, g.alpha};
+    const int sw = g.swiglu_inter;
     __syncthreads();                                                         // every wave is done with the operand images
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
@@ -227,8 +230,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
                 const int nl = wc * 64 + j * 16 + (lane >> 4) * 4;              // column inside the tile
                 float b4[4] = {0.f, 0.f, 0.f, 0.f};
                 if (e.bias) {
+                    const int nb = sw ? (nl < 128 ? 0 : sw - 128) + tn * 128 + nl : n0 + nl;   // weight row of that column
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) b4[q] = (n0 + nl + q < e.N) ? bf2f(e.bias[n0 + nl + q]) : 0.f;
+                    for (int q = 0; q < 4; ++q) b4[q] = (nb + q < e.N) ? bf2f(e.bias[nb + q]) : 0.f;
                 }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -244,11 +248,35 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
         }
         __syncthreads();
 
-        for (int it = 0; it < 16; ++it) {
-            const int row = it * 8 + wave;                                    // one wave = one tile row
-            const float4 v = *(const float4*)(smem + row * 1024 + ((lane ^ (row & 7)) << 4));
-            const int m = m0 + pass * 128 + row, n = n0 + lane * 4;
-            if (m < e.M && n < e.N) store_row4(e, m, n, v);
+        if (sw) {
+            // SwiGLU: a half wave per tile row; lane l reads the gate chunk l and the up chunk l + 32 of the row, rounds both to
+            // bf16 (what the unfused path stores and swiglu_fwd_kernel reads back) and writes 4 outputs = 8 bytes
+            for (int it = 0; it < 8; ++it) {
+                const int row = it * 16 + wave * 2 + (lane >> 5), l = lane & 31;
+                const float4 gv = *(const float4*)(smem + row * 1024 + ((l ^ (row & 7)) << 4));
+                const float4 uv = *(const float4*)(smem + row * 1024 + (((l + 32) ^ (row & 7)) << 4));
+                const int m = m0 + pass * 128 + row;
+                if (m < e.M) {
+                    const uint32_t g01 = pack_bf2(gv.x, gv.y), g23 = pack_bf2(gv.z, gv.w);
+                    const uint32_t u01 = pack_bf2(uv.x, uv.y), u23 = pack_bf2(uv.z, uv.w);
+                    if (g.C2) {
+                        bf16_t* c2 = (bf16_t*)g.C2 + (long)m * g.ldc2 + tn * 128 + l * 4;
+                        *(uint2*)c2 = make_uint2(g01, g23);
+                        *(uint2*)(c2 + sw) = make_uint2(u01, u23);
+                    }
+                    const float g0 = bf_lo(g01), g1 = bf_hi(g01), g2 = bf_lo(g23), g3 = bf_hi(g23);
+                    const uint32_t o01 = pack_bf2(g0 * (1.f / (1.f + __expf(-g0))) * bf_lo(u01), g1 * (1.f / (1.f + __expf(-g1))) * bf_hi(u01));
+                    const uint32_t o23 = pack_bf2(g2 * (1.f / (1.f + __expf(-g2))) * bf_lo(u23), g3 * (1.f / (1.f + __expf(-g3))) * bf_hi(u23));
+                    *(uint2*)((bf16_t*)e.C + (long)m * e.ldc + tn * 128 + l * 4) = make_uint2(o01, o23);
+                }
+            }
+        } else {
+            for (int it = 0; it < 16; ++it) {
+                const int row = it * 8 + wave;                                // one wave = one tile row
+                const float4 v = *(const float4*)(smem + row * 1024 + ((lane ^ (row & 7)) << 4));
+                const int m = m0 + pass * 128 + row, n = n0 + lane * 4;
+                if (m < e.M && n < e.N) store_row4(e, m, n, v);
+            }
         }
         if (pass == 0) __syncthreads();
     }

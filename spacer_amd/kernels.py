@@ -7,6 +7,7 @@ eager / CPU fallback: tensors must live on a GPU and the library must be built.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -122,6 +123,32 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = N
         s0, e0 = PROFILER.records[-1][1], PROFILER.records[-1][2]
         PROFILER.records.append((f"gemm[{M}x{N}x{K}]", s0, e0, 2.0 * M * N * ka, 0.0))
     return out
+
+
+def gemm_swiglu(a: torch.Tensor, w_gu: torch.Tensor, *, bias=None, keep_gu: bool = True):
+    """SwiGLU input half of an MLP: returns (act [M, I] bf16, gu [M, 2I] bf16 or None) with
+    act = silu(a @ Wgate^T + b) * (a @ Wup^T + b), w_gu = [gate rows | up rows] ([2I, K]).  One launch (gate|up GEMM with the
+    SwiGLU in its epilogue) when the shape runs on the 256 tile, else GEMM + swiglu_fwd; the bits are the same either way.
+    ``keep_gu=False`` (no backward: reference model, rollout prefill) skips writing gate|up in the fused form."""
+    M, K = a.shape
+    two_i = w_gu.shape[0]
+    inter = two_i // 2
+    if not _lib.load().spacer_gemm_swiglu_fused(M, inter, K) or os.environ.get("SPACER_GEMM_SWIGLU_UNFUSED"):   # env: A/B runs
+        gu = gemm_nt(a, w_gu, bias=bias)
+        return swiglu_fwd(gu), (gu if keep_gu else None)
+    act = torch.empty(M, inter, device=a.device, dtype=BF16)
+    gu = torch.empty(M, two_i, device=a.device, dtype=BF16) if keep_gu else None
+    t0 = PROFILER.begin()
+    check(_lib.load().spacer_gemm_swiglu_bf16(_ptr(a), _rowmajor(a), _ptr(w_gu), _rowmajor(w_gu), _ptr(bias), _ptr(act), _rowmajor(act),
+                                              _ptr(gu), _rowmajor(gu) if gu is not None else 0, M, inter, K, _stream()),
+          "gemm_swiglu_bf16")
+    if t0 is not None:
+        PROFILER.end("gemm_bf16_nt_256h_kernel", t0, 2.0 * M * two_i * K,
+                     2.0 * (M * K + two_i * K) + 2.0 * M * (inter + (two_i if keep_gu else 0)))
+        if PROFILER.by_shape:
+            s0, e0 = PROFILER.records[-1][1], PROFILER.records[-1][2]
+            PROFILER.records.append((f"gemm_swiglu[{M}x{two_i}x{K}]", s0, e0, 2.0 * M * two_i * K, 0.0))
+    return act, gu
 
 
 def gemm_skinny_acc(a: torch.Tensor, b: torch.Tensor, c32: torch.Tensor) -> torch.Tensor:

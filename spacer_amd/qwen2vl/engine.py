@@ -177,8 +177,8 @@ class Qwen2VLEngine:
             x_mid = K.gemm_nt(o, W[p + "proj_w"], bias=W[p + "proj_b"], residual=x, out_dtype=F32)
             rstd2 = self._empty(Np)
             h2 = K.rmsnorm_fwd(x_mid, W[p + "n2_w"], 1e-6, rstd=rstd2)
-            gu = K.gemm_nt(h2, W[p + "gu_w"], bias=W[p + "gu_b"])            # [gate (Ip) | up (Ip)], padding columns are 0
-            a = K.swiglu_fwd(gu)
+            # [gate (Ip) | up (Ip)], padding columns are 0; SwiGLU in the GEMM epilogue, gate|up kept only for a backward pass
+            a, gu = K.gemm_swiglu(h2, W[p + "gu_w"], bias=W[p + "gu_b"], keep_gu=tape is not None)
             x_out = K.gemm_nt(a, W[p + "down_w"], bias=W[p + "down_b"], residual=x_mid, out_dtype=F32)
             if tape is not None:
                 blocks.append(dict(x_in=x, rstd1=rstd1, h=h, qkv=qkv, o=o, lse=lse, x_mid=x_mid, rstd2=rstd2, h2=h2, gu=gu, a=a,
@@ -259,8 +259,7 @@ class Qwen2VLEngine:
             x_mid = K.gemm_nt(o, W[p + "o_w"], residual=x, out_dtype=F32)
             rstd2 = self._empty(T)
             h2 = K.rmsnorm_fwd(x_mid, W[p + "ln2_w"], cfg.rms_eps, rstd=rstd2)
-            gu = K.gemm_nt(h2, W[p + "gu_w"])
-            a = K.swiglu_fwd(gu)
+            a, gu = K.gemm_swiglu(h2, W[p + "gu_w"], keep_gu=tape is not None)       # SwiGLU in the gate|up GEMM's epilogue
             x_out = K.gemm_nt(a, W[p + "down_w"], residual=x_mid, out_dtype=F32)
             if tape is not None:
                 tape.append(dict(x_in=x, rstd1=rstd1, h=h, qkv=qkv, o=o, lse=lse, x_mid=x_mid, rstd2=rstd2, h2=h2, gu=gu, a=a))

@@ -323,6 +323,27 @@ def test_attention_decode_shared_prefix(dev):
             assert_close(o[b], want, 2e-2, 2e-2, f"shared decode attn b={b} tl={tl}")
 
 
+def test_gemm_swiglu_epilogue_is_the_two_step_path(dev):
+    """gate|up GEMM with the SwiGLU in its epilogue == GEMM into gu + swiglu_fwd, bit for bit (ragged M, bias, no gu)."""
+    for M, I, Kd, with_bias in ((3000, 2048, 512, False), (4160, 3456, 1280, True), (5498, 1024, 256, False), (1402, 18944, 3584, False)):
+        a = rnd((M, Kd), dev, 1, 0.5)
+        w = rnd((2 * I, Kd), dev, 2, 0.05)
+        b = rnd((2 * I,), dev, 3, 0.2) if with_bias else None
+        assert K._lib.load().spacer_gemm_swiglu_fused(M, I, Kd) == 1
+        gu_ref = K.gemm_nt(a, w, bias=b, split_k=False)
+        act_ref = K.swiglu_fwd(gu_ref)
+        act, gu = K.gemm_swiglu(a, w, bias=b, keep_gu=True)
+        assert torch.equal(gu, gu_ref), f"gu differs: {(gu.float() - gu_ref.float()).abs().max().item()}"
+        assert torch.equal(act, act_ref), f"act differs: {(act.float() - act_ref.float()).abs().max().item()}"
+        act2, none = K.gemm_swiglu(a, w, bias=b, keep_gu=False)
+        assert none is None and torch.equal(act2, act_ref)
+    # a shape the 256 tile does not take falls back to the two launches
+    a, w = rnd((40, 128), dev, 4, 0.5), rnd((2 * 192, 128), dev, 5, 0.05)
+    assert K._lib.load().spacer_gemm_swiglu_fused(40, 192, 128) == 0
+    act, gu = K.gemm_swiglu(a, w)
+    assert torch.equal(act, K.swiglu_fwd(K.gemm_nt(a, w)))
+
+
 # ----------------------------------------------------------------------------------------------- element-wise
 def test_swiglu_act_bias_cast(dev):
     rows, I = 50, 512
