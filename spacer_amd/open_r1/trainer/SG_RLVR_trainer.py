@@ -273,29 +273,43 @@ class SGRLVRTrainer:
                                           videos=[video_inputs[0][perm]], **call)
         return dict(proc=proc, sproc=sproc, has_video=bool(video_inputs))
 
+    def _rollout(self, preps: List[dict]) -> List[dict]:
+        """TR:463-481 for one or SEVERAL prepared samples in one generate call.  The reference calls generate per sample (and a
+        second time with G/2 for the frame-shuffled twin).  Decoding is bound by streaming the weights, not by the number of
+        rows, so every prompt handed in -- the twins too, and all micro-batches of a gradient-accumulation step, which sample
+        from the same weights -- decodes as ONE batch; a twin's surplus G/2 rollouts are dropped, so it costs its prefill,
+        not a second decode loop.  Returns per sample dict(prompt, completion_ids [G, C], shuffled_ids [G/2, C] or None)."""
+        G = self.num_generations
+        sp = SamplingParams(max_new_tokens=self.max_completion_length, top_k=self.args.top_k, top_p=0.95, temperature=1.0,
+                            seed=self._sample_seed + 7919 * self.global_step)
+        prompts, slots = [], []
+        for prep in preps:
+            slots.append((len(prompts), prep["sproc"] is not None))
+            prompts.append(self._prompt_input(prep["proc"]))
+            if prep["sproc"] is not None:
+                prompts.append(self._prompt_input(prep["sproc"]))
+        ids = self._generate(prompts, G, sp)
+        out = []
+        for at, twin in slots:
+            shuffled = ids[(at + 1) * G:(at + 1) * G + self.shuffled_num_generations] if twin else None
+            out.append(dict(prompt=prompts[at], completion_ids=ids[at * G:(at + 1) * G], shuffled_ids=shuffled))
+        return out
+
     def compute_loss(self, model, inputs, return_outputs=False, num_items_in_batch=None, *, grad_scale: float = 1.0,
-                     prepared: Optional[dict] = None):
+                     prepared: Optional[dict] = None, rolled: Optional[dict] = None):
         if return_outputs:
             raise ValueError("The GRPOTrainer does not support returning outputs")
         eng, G = self.engine, self.num_generations
         prompts = [x["prompt"] for x in inputs]
         video_path = inputs[0]["path"]
         prep = prepared if prepared is not None else self._prepare(inputs, self._sample_seed + 104729 * self.global_step)
-        prompt = self._prompt_input(prep["proc"])
         has_video = prep["has_video"]
-        sp = SamplingParams(max_new_tokens=self.max_completion_length, top_k=self.args.top_k, top_p=0.95, temperature=1.0,
-                            seed=self._sample_seed + 7919 * self.global_step)
+        if rolled is None:                      # stand-alone call: this sample's rollouts only
+            rolled = self._rollout([prep])[0]
+        prompt, completion_ids = rolled["prompt"], rolled["completion_ids"]
         shuffled_rpf = None
-        if prep["sproc"] is not None:                                                        # T-GRPO (TR:442-481)
-            sprompt = self._prompt_input(prep["sproc"])
-            # The reference calls generate twice (G rollouts, then G/2 on the shuffled frames).  Decoding is bound by
-            # streaming the weights, not by the number of rows, so both prompts decode as ONE batch of 2G rows and the
-            # shuffled prompt's surplus rollouts are dropped: the twin costs its prefill, not a second decode loop.
-            both = self._generate([prompt, sprompt], G, sp)
-            completion_ids, shuffled_ids = both[:G], both[G:G + self.shuffled_num_generations]
-            shuffled_rpf = self._run_rewards(inputs, prompts, shuffled_ids, self.shuffled_num_generations)
-        else:
-            completion_ids = self._generate([prompt], G, sp)
+        if rolled["shuffled_ids"] is not None:                                               # T-GRPO (TR:442-481, :554-572)
+            shuffled_rpf = self._run_rewards(inputs, prompts, rolled["shuffled_ids"], self.shuffled_num_generations)
 
         rewards_per_func = self._run_rewards(inputs, prompts, completion_ids, G, video_path=video_path)
         rewards, temporal_reward = temporal_bonus(rewards_per_func, shuffled_rpf, self.temporal, has_video)
@@ -344,21 +358,24 @@ class SGRLVRTrainer:
 
         while self.global_step < self.total_steps:
             idx = shard_indices(n_rows, self.rank, self.world, a.data_seed if a.data_seed is not None else a.seed, epoch)
-            last = (len(idx) // acc) * acc
-            pending = None
-            for s in range(0, len(idx) - acc + 1, acc):
+            starts = list(range(0, len(idx) - acc + 1, acc))
+
+            def submit(s0: int):
+                return [pool.submit(self._prepare, [self.train_dataset[idx[s0 + j]]], prep_seed(epoch, s0 + j)) for j in range(acc)]
+
+            pending = submit(starts[0]) if starts else None
+            for n, s in enumerate(starts):
                 if self.global_step >= self.total_steps:
                     break
+                preps = [f.result() for f in pending]
+                # the next optimizer step's host work (chat template, frame decode + resize, patchify) overlaps this one's GPU work
+                pending = submit(starts[n + 1]) if n + 1 < len(starts) else None
+                rolled = self._rollout(preps)        # ONE decode batch for all micro-batches of the step (same weights)
                 loss = 0.0
                 for j in range(acc):
-                    pos = s + j
-                    if pending is None:
-                        pending = pool.submit(self._prepare, [self.train_dataset[idx[pos]]], prep_seed(epoch, pos))
-                    prepared, pending = pending.result(), None
-                    if pos + 1 < last:                       # the next sample's host work overlaps this one's GPU work
-                        pending = pool.submit(self._prepare, [self.train_dataset[idx[pos + 1]]], prep_seed(epoch, pos + 1))
-                    loss += float(self.compute_loss(None, [self.train_dataset[idx[pos]]], grad_scale=1.0 / acc,
-                                                    prepared=prepared)) / acc
+                    loss += float(self.compute_loss(None, [self.train_dataset[idx[s + j]]], grad_scale=1.0 / acc, prepared=preps[j],
+                                                    rolled=rolled[j])) / acc
+                    rolled[j] = None
                 self.engine.reduce_gradients()
                 lr = self.engine.optimizer_step(self.world)
                 self.global_step += 1
@@ -368,6 +385,9 @@ class SGRLVRTrainer:
                     t_last = time.time()
                 if a.save_steps and self.global_step % a.save_steps == 0:
                     self.save_model(os.path.join(a.output_dir, f"checkpoint-{self.global_step}"))
+            if pending:
+                for f in pending:
+                    f.cancel()
             epoch += 1
         pool.shutdown(wait=False, cancel_futures=True)
         return {"global_step": self.global_step}

@@ -64,3 +64,31 @@ def test_trainer_two_steps(dev, tmp_path):
     t2 = SGRLVRTrainer(model=ck, reward_funcs=[format_reward], args=GRPOConfig(output_dir=str(tmp_path), max_steps=1),
                        train_dataset=rows, processing_class=FakeProcessor(TINY), device=dev, model_config=TINY)
     assert torch.equal(t2.engine.policy.flat, trainer.engine.policy.flat)
+
+
+def test_accumulation_micro_batches_roll_out_together(dev, tmp_path):
+    """All micro-batches of a gradient-accumulation step sample from the same weights: ONE generate call (prompts + T-GRPO
+    twins of every micro-batch in one decode batch), then per-sample rewards / scoring / backward, one optimizer step."""
+    g = load_tiny()
+    params = FlatParams.empty(TINY, dev)
+    load_state_dict(params, g["w"])
+    rows = []
+    for i in range(4):
+        frames = torch.randint(0, 256, (6, 3, 56, 84), generator=torch.Generator().manual_seed(10 + i), dtype=torch.uint8)
+        rows.append(dict(prompt=[{"role": "user", "content": [{"type": "video"}, {"type": "text", "text": f"clip {i} ?"}]}],
+                         path=frames, data_type="video", problem_type="multiple choice", solution="<answer>A</answer>",
+                         problem_id=i, options=["A. x", "B. y"], data_source="other"))
+    args = GRPOConfig(output_dir=str(tmp_path), max_completion_length=6, num_generations=4, learning_rate=1e-4, max_steps=2,
+                      gradient_accumulation_steps=2, logging_steps=1, save_steps=0, seed=5)
+    trainer = SGRLVRTrainer(model=params, reward_funcs=[accuracy_reward, format_reward], args=args,
+                            script_args=GRPOScriptArguments(temporal=True, len_control=True), train_dataset=rows,
+                            processing_class=FakeProcessor(TINY), device=dev)
+    calls = []
+    inner = trainer._generate
+    trainer._generate = lambda prompts, n, sp: (calls.append(len(prompts)), inner(prompts, n, sp))[1]
+    SEEN.clear()
+    assert trainer.train()["global_step"] == 2
+    assert calls == [4, 4]                                  # per optimizer step: 2 samples x (prompt + shuffled twin)
+    assert sorted((s["n"], s["video_path"]) for s in SEEN) == [(2, False)] * 4 + [(4, True)] * 4
+    logs = [json.loads(line) for line in open(os.path.join(str(tmp_path), "trainer_log.jsonl"))]
+    assert len(logs) == 2 and all(lg["kl"] >= 0 for lg in logs)
