@@ -25,3 +25,14 @@ for rows, cols, f32 in [(5498, 3584, True), (4160, 1280, True)]:
         for _ in range(20): K.rmsnorm_bwd(x, w, dy, rstd, dx, dw, accumulate=acc)
         e1.record(); torch.cuda.synchronize()
         print(f"    accumulate={acc}: {e0.elapsed_time(e1) / 20 * 1e3:7.1f} us")
+rows, cols = 4160, 1280
+x = torch.randn(rows, cols, device=dev); w = torch.randn(cols, device=dev).bfloat16(); dy = torch.randn(rows, cols, device=dev).bfloat16()
+mean = torch.randn(rows, device=dev) * 0.1; rstd = torch.rand(rows, device=dev) + 0.5
+dx = torch.zeros(rows, cols, device=dev); dw = torch.zeros(cols, device=dev); db = torch.zeros(cols, device=dev)
+for _ in range(3): K.layernorm_bwd(x, w, dy, mean, rstd, dx, dw, db)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20): K.layernorm_bwd(x, w, dy, mean, rstd, dx, dw, db)
+e1.record(); torch.cuda.synchronize()
+print(f"  layernorm_bwd {rows}x{cols}: {e0.elapsed_time(e1) / 20 * 1e3:7.1f} us")

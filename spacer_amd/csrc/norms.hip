@@ -90,16 +90,18 @@ __global__ __launch_bounds__(NT) void norm_fwd_kernel(const void* __restrict__ x
 constexpr int ROWS_PER_BLOCK = 16;
 static int rows_per_block() { return ROWS_PER_BLOCK; }
 
-template <bool XF32, bool LAYER>
+// IT = 16-byte column groups per thread (cols <= NT * 4 * IT): sized to the row so that the per-thread arrays of a 1280- or
+// 3584-wide row do not carry the registers of an 8192-wide one (254 VGPRs, 1-2 waves per SIMD with IT = 8 for every shape).
+template <bool XF32, bool LAYER, int IT>
 __global__ __launch_bounds__(NT) void norm_bwd_kernel(const void* __restrict__ x, const bf16_t* __restrict__ w,
                                                       const bf16_t* __restrict__ dy, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, void* __restrict__ dx,
                                                       int dx_acc, float* __restrict__ dw, float* __restrict__ db,
                                                       int rows, int cols, int rpb) {
     __shared__ float red[32];
-    float dwp[MAXIT][4], dbp[MAXIT][4], wv[MAXIT][4];
+    float dwp[IT][4], dbp[IT][4], wv[IT][4];
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
+    for (int it = 0; it < IT; ++it) {
         const int c = (it * NT + threadIdx.x) * 4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { dwp[it][e] = 0.f; dbp[it][e] = 0.f; wv[it][e] = 0.f; }
@@ -108,11 +110,11 @@ __global__ __launch_bounds__(NT) void norm_bwd_kernel(const void* __restrict__ x
     const int r0 = blockIdx.x * rpb, r1 = min(rows, r0 + rpb);
     // the loads of row r+1 are issued before the block reductions of row r: a row is one dependent chain
     // (load -> reduce -> store), and with one row in flight per block the kernel ran at 1.8 TB/s
-    float xn[MAXIT][4], dn[MAXIT][4];
+    float xn[IT][4], dn[IT][4];
     auto fetch = [&](int row) {
         const long base = (long)row * cols;
 #pragma unroll
-        for (int it = 0; it < MAXIT; ++it) {
+        for (int it = 0; it < IT; ++it) {
             const int c = (it * NT + threadIdx.x) * 4;
             if (c < cols) {
                 load4<XF32>(x, base + c, xn[it]);
@@ -124,10 +126,10 @@ __global__ __launch_bounds__(NT) void norm_bwd_kernel(const void* __restrict__ x
     for (int row = r0; row < r1; ++row) {
         const long base = (long)row * cols;
         const float rs = rstd[row], mu = LAYER ? mean[row] : 0.f;
-        float xh[MAXIT][4], g[MAXIT][4];
+        float xh[IT][4], g[IT][4];
         float s1 = 0.f, s2 = 0.f;   // sum(g), sum(g * xhat) with g = dy * w
 #pragma unroll
-        for (int it = 0; it < MAXIT; ++it) {
+        for (int it = 0; it < IT; ++it) {
             const int c = (it * NT + threadIdx.x) * 4;
             if (c < cols) {
 #pragma unroll
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(NT) void norm_bwd_kernel(const void* __restrict__ x
         float m1 = 0.f;
         if (LAYER) m1 = block_sum(s1, red) / cols;
 #pragma unroll
-        for (int it = 0; it < MAXIT; ++it) {
+        for (int it = 0; it < IT; ++it) {
             const int c = (it * NT + threadIdx.x) * 4;
             if (c < cols) {
                 float o[4];
@@ -164,13 +166,114 @@ __global__ __launch_bounds__(NT) void norm_bwd_kernel(const void* __restrict__ x
         }
     }
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
+    for (int it = 0; it < IT; ++it) {
         const int c = (it * NT + threadIdx.x) * 4;
         if (c < cols) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (dw) atomicAdd(dw + c + e, dwp[it][e]);
                 if (LAYER && db) atomicAdd(db + c + e, dbp[it][e]);
+            }
+        }
+    }
+}
+
+// Narrow rows (cols <= 64 * 4 * WG = 1536: the vision tower's 1280): one WAVE per row instead of one workgroup.  A 1280-wide row
+// is 5 KiB -- a 256-thread block spends its time in the two block-wide reductions (4 barriers per row, rows strictly one after
+// the other: 80-128 us for 4160 x 1280); here the reductions are wave shuffles, the 4 waves of a block walk 4 rows at once
+// (next row's loads in flight), and the per-wave dw / db partials meet in LDS before the one atomic per column per block.
+constexpr int WROWS = 32;     // rows per block (8 per wave)
+template <bool XF32, bool LAYER, int WG>
+__global__ __launch_bounds__(NT) void norm_bwd_wave_kernel(const void* __restrict__ x, const bf16_t* __restrict__ w,
+                                                           const bf16_t* __restrict__ dy, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, void* __restrict__ dx, int dx_acc,
+                                                           float* __restrict__ dw, float* __restrict__ db, int rows, int cols) {
+    __shared__ float part[2][3][64 * 4 * WG];           // waves 1..3 park their dw (and db) partials here
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float dwp[WG][4], dbp[WG][4], wv[WG][4];
+#pragma unroll
+    for (int it = 0; it < WG; ++it) {
+        const int c = (it * 64 + lane) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { dwp[it][e] = 0.f; dbp[it][e] = 0.f; wv[it][e] = 0.f; }
+        if (c < cols) loadbf4(w, c, wv[it]);
+    }
+    const int r0 = blockIdx.x * WROWS, r1 = min(rows, r0 + WROWS);
+    float xn[WG][4], dn[WG][4];
+    auto fetch = [&](int row) {
+        const long base = (long)row * cols;
+#pragma unroll
+        for (int it = 0; it < WG; ++it) {
+            const int c = (it * 64 + lane) * 4;
+            if (c < cols) { load4<XF32>(x, base + c, xn[it]); loadbf4(dy, base + c, dn[it]); }
+        }
+    };
+    if (r0 + wave < r1) fetch(r0 + wave);
+    for (int row = r0 + wave; row < r1; row += 4) {
+        const long base = (long)row * cols;
+        const float rs = rstd[row], mu = LAYER ? mean[row] : 0.f;
+        float xh[WG][4], g[WG][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < WG; ++it) {
+            const int c = (it * 64 + lane) * 4;
+            if (c < cols) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xv = xn[it][e], dv = dn[it][e];
+                    xh[it][e] = (xv - mu) * rs;
+                    g[it][e] = dv * wv[it][e];
+                    s1 += g[it][e];
+                    s2 += g[it][e] * xh[it][e];
+                    dwp[it][e] += dv * xh[it][e];
+                    dbp[it][e] += dv;
+                }
+            }
+        }
+        if (row + 4 < r1) fetch(row + 4);
+        const float m2 = wave_sum(s2) / cols;
+        const float m1 = LAYER ? wave_sum(s1) / cols : 0.f;
+#pragma unroll
+        for (int it = 0; it < WG; ++it) {
+            const int c = (it * 64 + lane) * 4;
+            if (c < cols) {
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = rs * (g[it][e] - m1 - xh[it][e] * m2);
+                if (dx_acc) {
+                    float old[4];
+                    load4<XF32>(dx, base + c, old);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += old[e];
+                }
+                store4<XF32>(dx, base + c, o);
+            }
+        }
+    }
+    // ---- the block's 4 partials -> wave 0 -> one atomic per column
+    if (wave > 0) {
+#pragma unroll
+        for (int it = 0; it < WG; ++it)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                part[0][wave - 1][(it * 64 + lane) * 4 + e] = dwp[it][e];
+                if (LAYER) part[1][wave - 1][(it * 64 + lane) * 4 + e] = dbp[it][e];
+            }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int it = 0; it < WG; ++it) {
+            const int c = (it * 64 + lane) * 4;
+            if (c < cols) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float a = dwp[it][e], b = dbp[it][e];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { a += part[0][k][c + e]; if (LAYER) b += part[1][k][c + e]; }
+                    if (dw) atomicAdd(dw + c + e, a);
+                    if (LAYER && db) atomicAdd(db + c + e, b);
+                }
             }
         }
     }
@@ -217,14 +320,18 @@ extern "C" int spacer_rmsnorm_bwd(const void* x, int x_f32, const void* w, const
                                   int dx_accumulate, float* dw, int rows, int cols, spacer_stream_t stream) {
     if (int rc = check_shape("rmsnorm_bwd", rows, cols)) return rc;
     const int rpb = rows_per_block(), grid = cdiv(rows, rpb);
-    if (x_f32)
-        hipLaunchKernelGGL((norm_bwd_kernel<true, false>), dim3(grid), dim3(NT), 0, (hipStream_t)stream, x,
-                           (const bf16_t*)w, (const bf16_t*)dy, nullptr, rstd, dx, dx_accumulate, dw, nullptr, rows,
-                           cols, rpb);
-    else
-        hipLaunchKernelGGL((norm_bwd_kernel<false, false>), dim3(grid), dim3(NT), 0, (hipStream_t)stream, x,
-                           (const bf16_t*)w, (const bf16_t*)dy, nullptr, rstd, dx, dx_accumulate, dw, nullptr, rows,
-                           cols, rpb);
+#define BWD(F32, IT)                                                                                                     \
+    hipLaunchKernelGGL((norm_bwd_kernel<F32, false, IT>), dim3(grid), dim3(NT), 0, (hipStream_t)stream, x, (const bf16_t*)w, \
+                       (const bf16_t*)dy, nullptr, rstd, dx, dx_accumulate, dw, nullptr, rows, cols, rpb)
+    const int it = cols <= NT * 4 * 2 ? 2 : cols <= NT * 4 * 4 ? 4 : MAXIT;
+    if (cols <= 64 * 4 * 6) {
+        if (x_f32) hipLaunchKernelGGL((norm_bwd_wave_kernel<true, false, 6>), dim3(cdiv(rows, WROWS)), dim3(NT), 0, (hipStream_t)stream, x,
+                                      (const bf16_t*)w, (const bf16_t*)dy, nullptr, rstd, dx, dx_accumulate, dw, nullptr, rows, cols);
+        else hipLaunchKernelGGL((norm_bwd_wave_kernel<false, false, 6>), dim3(cdiv(rows, WROWS)), dim3(NT), 0, (hipStream_t)stream, x,
+                                (const bf16_t*)w, (const bf16_t*)dy, nullptr, rstd, dx, dx_accumulate, dw, nullptr, rows, cols);
+    } else if (x_f32) { if (it == 2) BWD(true, 2); else if (it == 4) BWD(true, 4); else BWD(true, MAXIT); }
+    else { if (it == 2) BWD(false, 2); else if (it == 4) BWD(false, 4); else BWD(false, MAXIT); }
+#undef BWD
     SP_CHECK_LAUNCH();
     return SPACER_OK;
 }
@@ -234,12 +341,18 @@ extern "C" int spacer_layernorm_bwd(const void* x, int x_f32, const void* w, con
                                     int cols, spacer_stream_t stream) {
     if (int rc = check_shape("layernorm_bwd", rows, cols)) return rc;
     const int rpb = rows_per_block(), grid = cdiv(rows, rpb);
-    if (x_f32)
-        hipLaunchKernelGGL((norm_bwd_kernel<true, true>), dim3(grid), dim3(NT), 0, (hipStream_t)stream, x,
-                           (const bf16_t*)w, (const bf16_t*)dy, mean, rstd, dx, dx_accumulate, dw, db, rows, cols, rpb);
-    else
-        hipLaunchKernelGGL((norm_bwd_kernel<false, true>), dim3(grid), dim3(NT), 0, (hipStream_t)stream, x,
-                           (const bf16_t*)w, (const bf16_t*)dy, mean, rstd, dx, dx_accumulate, dw, db, rows, cols, rpb);
+#define BWD(F32, IT)                                                                                                     \
+    hipLaunchKernelGGL((norm_bwd_kernel<F32, true, IT>), dim3(grid), dim3(NT), 0, (hipStream_t)stream, x, (const bf16_t*)w,  \
+                       (const bf16_t*)dy, mean, rstd, dx, dx_accumulate, dw, db, rows, cols, rpb)
+    const int it = cols <= NT * 4 * 2 ? 2 : cols <= NT * 4 * 4 ? 4 : MAXIT;
+    if (cols <= 64 * 4 * 6) {
+        if (x_f32) hipLaunchKernelGGL((norm_bwd_wave_kernel<true, true, 6>), dim3(cdiv(rows, WROWS)), dim3(NT), 0, (hipStream_t)stream, x,
+                                      (const bf16_t*)w, (const bf16_t*)dy, mean, rstd, dx, dx_accumulate, dw, db, rows, cols);
+        else hipLaunchKernelGGL((norm_bwd_wave_kernel<false, true, 6>), dim3(cdiv(rows, WROWS)), dim3(NT), 0, (hipStream_t)stream, x,
+                                (const bf16_t*)w, (const bf16_t*)dy, mean, rstd, dx, dx_accumulate, dw, db, rows, cols);
+    } else if (x_f32) { if (it == 2) BWD(true, 2); else if (it == 4) BWD(true, 4); else BWD(true, MAXIT); }
+    else { if (it == 2) BWD(false, 2); else if (it == 4) BWD(false, 4); else BWD(false, MAXIT); }
+#undef BWD
     SP_CHECK_LAUNCH();
     return SPACER_OK;
 }
