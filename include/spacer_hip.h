@@ -87,6 +87,10 @@ int spacer_gemm_skinny_bf16(const void* A, long lda, const void* B, long ldb, vo
 int spacer_pack_weight_frag(const void* W, long ld, void* out, int N, int K, spacer_stream_t stream);
 int spacer_gemm_skinny_packed_bf16(const void* A, long lda, const void* Bpacked, void* C, long ldc, int M, int N, int K,
                                    spacer_stream_t stream);
+/* Store form, C32 = A . W^T (no accumulate, C needs no zero fill): only for wide N (>= 448 * 64 columns), where every workgroup
+ * covers the whole K range -- the lm_head projection of the decode step (HF lm_head inside generate).  SPACER_EINVAL otherwise. */
+int spacer_gemm_skinny_packed_store_bf16(const void* A, long lda, const void* Bpacked, void* C, long ldc, int M, int N, int K,
+                                         spacer_stream_t stream);
 
 /* Decode-loop MLP front half in one launch:  Y[M, inter] (bf16) = silu(A . Wgate^T) * (A . Wup^T)   (HF Qwen2MLP's
  * act_fn(gate_proj(x)) * up_proj(x) inside generate, TR:463).  W = [gate (inter rows) | up (inter rows)] x K is packed

@@ -36,6 +36,7 @@ SIGNATURES = {
     "spacer_gemm_skinny_bf16": [_p, _l, _p, _l, _p, _l, _i, _i, _i, C.POINTER(GemmEpilogue), _p],
     "spacer_pack_weight_frag": [_p, _l, _p, _i, _i, _p],
     "spacer_gemm_skinny_packed_bf16": [_p, _l, _p, _p, _l, _i, _i, _i, _p],
+    "spacer_gemm_skinny_packed_store_bf16": [_p, _l, _p, _p, _l, _i, _i, _i, _p],
     "spacer_pack_weight_frag_swiglu": [_p, _l, _p, _i, _i, _p],
     "spacer_gemm_skinny_swiglu_bf16": [_p, _l, _p, _p, _l, _i, _i, _i, _p],
     "spacer_transpose_bf16": [_p, _l, _p, _l, _i, _i, _i, _p],

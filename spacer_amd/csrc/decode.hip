@@ -31,7 +31,7 @@ template <bool PACKED, bool SWIGLU = false, int MT = 1>
 __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __restrict__ A, long lda,
                                                              const bf16_t* __restrict__ B, long ldb,
                                                              float* __restrict__ C, long ldc, int M, int N, int K,
-                                                             int slices_per_range, int mflush) {
+                                                             int slices_per_range, int mflush, int overwrite) {
     constexpr int KS = 256 / MT, ROWB = KS * 2;            // LDS row bytes (512 / 256); 16-byte chunk index ^= row & 15
     constexpr int NU = KS / 32, MF = 4 * MT;               // MFMA k-steps per slice, 16-row A fragments
     constexpr int CH = KS / 8, CHS = (MT == 1) ? 5 : 4;    // 16-byte chunks per LDS row and log2
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __res
                 const int m = mf * 16 + g * 4 + r;
                 if (m < mflush) {
                     float* c = C + (long)m * ldc + n;
-                    if (whole_k) *c += acc[mf][r];
+                    if (whole_k) *c = overwrite ? acc[mf][r] : *c + acc[mf][r];      // overwrite: C = A.B^T, no zero fill needed
                     else atomicAdd(c, acc[mf][r]);
                 }
             }
@@ -803,7 +803,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
 }  // namespace
 
 static int launch_skinny(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
-                         const spacer_gemm_epilogue* epi, bool packed, hipStream_t s) {
+                         const spacer_gemm_epilogue* epi, bool packed, hipStream_t s, bool overwrite = false) {
     SP_REQUIRE(A && B && C, SPACER_EINVAL, "gemm_skinny: null operand");
     SP_REQUIRE(M > 0 && M <= (packed ? 128 : 64), SPACER_EINVAL, "gemm_skinny: M=%d must be in 1..%d", M, packed ? 128 : 64);
     SP_REQUIRE(K % 256 == 0, SPACER_EINVAL, "gemm_skinny: K=%d must be a multiple of 256", K);
@@ -822,16 +822,17 @@ static int launch_skinny(const void* A, long lda, const void* B, long ldb, void*
     if (col_groups < 448) ranges = min(slices, cdiv(target_blocks, col_groups));
     const int spr = cdiv(slices, ranges);
     ranges = cdiv(slices, spr);
+    SP_REQUIRE(!overwrite || ranges == 1, SPACER_EINVAL, "gemm_skinny: C = A.B^T (store form) needs whole-K workgroups; N=%d splits K %d ways", N, ranges);
     const int mflush = getenv("SPACER_PROBE_NOFLUSH") ? 0 : M;
     if (packed && MTv == 2)
         hipLaunchKernelGGL((gemm_skinny_kernel<true, false, 2>), dim3(col_groups, ranges), dim3(256), 0, s, (const bf16_t*)A, lda,
-                           (const bf16_t*)B, ldb, (float*)C, ldc, M, N, K, spr, mflush);
+                           (const bf16_t*)B, ldb, (float*)C, ldc, M, N, K, spr, mflush, overwrite ? 1 : 0);
     else if (packed)
         hipLaunchKernelGGL(gemm_skinny_kernel<true>, dim3(col_groups, ranges), dim3(256), 0, s, (const bf16_t*)A, lda,
-                           (const bf16_t*)B, ldb, (float*)C, ldc, M, N, K, spr, mflush);
+                           (const bf16_t*)B, ldb, (float*)C, ldc, M, N, K, spr, mflush, overwrite ? 1 : 0);
     else
         hipLaunchKernelGGL(gemm_skinny_kernel<false>, dim3(col_groups, ranges), dim3(256), 0, s, (const bf16_t*)A, lda,
-                           (const bf16_t*)B, ldb, (float*)C, ldc, M, N, K, spr, mflush);
+                           (const bf16_t*)B, ldb, (float*)C, ldc, M, N, K, spr, mflush, overwrite ? 1 : 0);
     SP_CHECK_LAUNCH();
     return SPACER_OK;
 }
@@ -844,6 +845,11 @@ extern "C" int spacer_gemm_skinny_bf16(const void* A, long lda, const void* B, l
 extern "C" int spacer_gemm_skinny_packed_bf16(const void* A, long lda, const void* Bpacked, void* C, long ldc, int M, int N,
                                               int K, spacer_stream_t stream) {
     return launch_skinny(A, lda, Bpacked, 0, C, ldc, M, N, K, nullptr, true, (hipStream_t)stream);
+}
+
+extern "C" int spacer_gemm_skinny_packed_store_bf16(const void* A, long lda, const void* Bpacked, void* C, long ldc, int M, int N,
+                                                    int K, spacer_stream_t stream) {
+    return launch_skinny(A, lda, Bpacked, 0, C, ldc, M, N, K, nullptr, true, (hipStream_t)stream, true);
 }
 
 extern "C" int spacer_pack_weight_frag(const void* W, long ld, void* out, int N, int K, spacer_stream_t stream) {
@@ -874,10 +880,10 @@ extern "C" int spacer_gemm_skinny_swiglu_bf16(const void* A, long lda, const voi
     const int N = 2 * inter;
     if (M > 64)
         hipLaunchKernelGGL((gemm_skinny_kernel<true, true, 2>), dim3(cdiv(N, 64), 1), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16_t*)A, lda, (const bf16_t*)Bpacked, 0L, (float*)Y, ldy, M, N, K, K / 128, M);
+                           (const bf16_t*)A, lda, (const bf16_t*)Bpacked, 0L, (float*)Y, ldy, M, N, K, K / 128, M, 0);
     else
         hipLaunchKernelGGL((gemm_skinny_kernel<true, true, 1>), dim3(cdiv(N, 64), 1), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16_t*)A, lda, (const bf16_t*)Bpacked, 0L, (float*)Y, ldy, M, N, K, K / 256, M);
+                           (const bf16_t*)A, lda, (const bf16_t*)Bpacked, 0L, (float*)Y, ldy, M, N, K, K / 256, M, 0);
     SP_CHECK_LAUNCH();
     return SPACER_OK;
 }

@@ -179,6 +179,15 @@ def gemm_skinny_packed_acc(a: torch.Tensor, bp: torch.Tensor, c32: torch.Tensor,
     return c32
 
 
+def gemm_skinny_packed_store(a: torch.Tensor, bp: torch.Tensor, c32: torch.Tensor, N: int) -> torch.Tensor:
+    """c32[M,N] (fp32) = a[M,K] @ W[N,K]^T (store, no accumulate) for wide N (lm_head): no zero fill of c32 needed."""
+    M, K = a.shape
+    assert bp.numel() == N * K and c32.dtype == torch.float32
+    check(_lib.load().spacer_gemm_skinny_packed_store_bf16(_ptr(a), _rowmajor(a), _ptr(bp), _ptr(c32), _rowmajor(c32), M, N, K,
+                                                           _stream()), "gemm_skinny_packed_store_bf16")
+    return c32
+
+
 def pack_weight_frag_swiglu(w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[2*I, K] = [gate | up] rows -> fragment-major copy with 8 gate + 8 up columns per fragment (gemm_skinny_swiglu)."""
     N, K = w.shape

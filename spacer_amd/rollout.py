@@ -134,8 +134,11 @@ class RolloutEngine:
             a = K.gemm_skinny_swiglu(h2, PW[p + "gu_w"], I, out=st["a"])      # gate|up GEMM + SwiGLU in one launch
             K.gemm_skinny_packed_acc(a, PW[p + "down_w"], x, cfg.hidden)
         hn = K.rmsnorm_fwd(x, W["llm.norm_w"], cfg.rms_eps, out=st["h"])
-        st["logits"].zero_()
-        K.gemm_skinny_packed_acc(hn, PW["llm.lm_head"], st["logits"], cfg.vocab)
+        if cfg.vocab >= 448 * 64:                        # whole-K workgroups: plain stores, no zero fill of the logits
+            K.gemm_skinny_packed_store(hn, PW["llm.lm_head"], st["logits"], cfg.vocab)
+        else:
+            st["logits"].zero_()
+            K.gemm_skinny_packed_acc(hn, PW["llm.lm_head"], st["logits"], cfg.vocab)
         st["step"].add_(1)
         st["tail_len"].add_(1)
         K.sample_top_p(st["logits"], st["step"], top_k=sp.top_k, top_p=sp.top_p, temperature=sp.temperature, seed=sp.seed,

@@ -507,3 +507,17 @@ def test_sampler_support_and_distribution(dev):
     assert int(fin.sum()) == B                      # every live row drew eos
     ids = K.sample_top_p(logits, step, top_k=1, top_p=1.0, eos_id=top, suppress_eos=True)
     assert all(int(t) != top for t in ids.tolist())
+
+
+def test_skinny_gemm_store_form(dev):
+    """lm_head form of the packed decode GEMM: C = A.W^T by plain stores (stale C contents must not leak in)."""
+    M, N, Kd = 37, 448 * 64 + 128, 512
+    a, w = rnd((M, Kd), dev, 1, 0.5), rnd((N, Kd), dev, 2, 0.05)
+    wp = K.pack_weight_frag(w)
+    c = torch.full((M, N), 7.0, device=dev)
+    K.gemm_skinny_packed_store(a, wp, c, N)
+    ref = torch.zeros(M, N, device=dev)
+    K.gemm_skinny_packed_acc(a, wp, ref, N)
+    assert torch.equal(c, ref)
+    with pytest.raises(K.SpacerError):                       # narrow N splits K across workgroups: no store form
+        K.gemm_skinny_packed_store(a, K.pack_weight_frag(w[:1024]), torch.zeros(M, 1024, device=dev), 1024)
