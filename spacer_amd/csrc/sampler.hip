@@ -90,13 +90,26 @@ __global__ __launch_bounds__(SNT) void sample_kernel(const float* __restrict__ l
                 }
             }
             __syncthreads();
-            if (tid == 0) {
-                int cum = 0, bsel = 0;
-                for (int bb = 255; bb >= 0; --bb) {
-                    if (cum + hist[bb] >= k) { bsel = bb; break; }
-                    cum += hist[bb];
+            if (tid < 64) {
+                // first bin, walking down from 255, where the running count reaches k -- by one wave (4 bins per lane, shuffle
+                // prefix) instead of one thread walking 256 dependent LDS reads per pass (that walk was half of the kernel's time)
+                int hb[4], own = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { hb[q] = hist[255 - (lane * 4 + q)]; own += hb[q]; }
+                int incl = own;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+                int cum = incl - own, pos = 256, cum_at = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (pos == 256 && cum + hb[q] >= k) { pos = lane * 4 + q; cum_at = cum; }
+                    cum += hb[q];
                 }
-                sel_bin = bsel; sel_k = k - cum;
+                int first = pos;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o, 64));
+                if (first == 256) { if (lane == 63) { sel_bin = 0; sel_k = k - incl; } }  // k exceeds the population (cannot happen for count >= k): what the serial walk left
+                else if (pos == first) { sel_bin = 255 - pos; sel_k = k - cum_at; }
             }
             __syncthreads();
             prefix = (prefix << 8) | (uint32_t)sel_bin;

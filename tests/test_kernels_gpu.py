@@ -521,3 +521,30 @@ def test_skinny_gemm_store_form(dev):
     assert torch.equal(c, ref)
     with pytest.raises(K.SpacerError):                       # narrow N splits K across workgroups: no store form
         K.gemm_skinny_packed_store(a, K.pack_weight_frag(w[:1024]), torch.zeros(M, 1024, device=dev), 1024)
+
+
+def test_sampler_mass_ties_take_the_exact_select_path(dev):
+    """More than CAP (1024) logits tied at the top: the candidate bound overflows and the exact 4-pass radix select over the whole
+    row runs (the path whose bin walk is done by one wave).  Every draw must be one of the tied maxima; and with a strict top-k
+    below the tie level the support is exactly those k tokens."""
+    V, B = 6000, 16
+    g = torch.Generator().manual_seed(3)
+    base = torch.randn(V, generator=g)
+    tied = torch.randperm(V, generator=g)[:2000]
+    base[tied] = 5.0
+    logits = base.repeat(B, 1).to(dev).contiguous()
+    step = torch.zeros(1, dtype=torch.int32, device=dev)
+    tied_set = set(tied.tolist())
+    for s in range(4):
+        step.fill_(s)
+        ids = K.sample_top_p(logits, step, top_k=50, top_p=0.95, seed=5)
+        assert all(t in tied_set for t in ids.tolist())
+    base2 = base.clone()
+    hot = torch.randperm(V, generator=g)[:7]
+    base2[hot] = torch.tensor([9.0, 8.5, 8.0, 7.5, 7.0, 6.5, 6.0])
+    logits2 = base2.repeat(B, 1).to(dev).contiguous()
+    seen = set()
+    for s in range(40):
+        step.fill_(s)
+        seen.update(K.sample_top_p(logits2, step, top_k=5, top_p=1.0, seed=9).tolist())
+    assert seen <= set(hot[:5].tolist()) and len(seen) >= 3
