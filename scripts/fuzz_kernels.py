@@ -1,0 +1,177 @@
+"""Randomised parity sweep of the hot kernels against fp32 torch on the GPU (run by hand:  python scripts/fuzz_kernels.py [seconds]).
+The fixed-shape parity tests live in tests/; this sweep draws ragged shapes / segment layouts to look for corner cases
+(ragged last tiles, K-split tails, tails crossing key tiles, windows of odd sizes).  Exits non-zero on the first mismatch."""
+import math
+import os
+import random
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from spacer_amd import kernels as K  # noqa: E402
+from test_kernels_gpu import attn_ref, dense_mask  # noqa: E402
+
+dev = torch.device("cuda:0")
+BF = torch.bfloat16
+
+
+def rnd(shape, scale=1.0, dtype=BF):
+    return (torch.randn(*shape, device=dev) * scale).to(dtype)
+
+
+def close(got, want, atol, rtol, what):
+    err = (got.float() - want.float()).abs()
+    tol = atol + rtol * want.float().abs()
+    if bool((err > tol).any()):
+        print(f"MISMATCH {what}: max err {float(err.max()):.4g}, {int((err > tol).sum())}/{err.numel()} off")
+        sys.exit(1)
+
+
+def fuzz_gemm(r):
+    M = r.choice([r.randint(1, 700), r.randint(700, 6000)])
+    N = r.choice([r.randint(1, 600) * 8, r.randint(1, 40) * 256, r.randint(8, 80) * 128])
+    Kd = r.randint(1, 40) * 64
+    a, b = rnd((M, Kd), 0.5), rnd((N, Kd), 0.1)
+    want = a.float() @ b.float().t()
+    mode = r.randint(0, 3)
+    tol = 0.02 * math.sqrt(Kd) * 0.05 + 0.02
+    if mode == 0:
+        close(K.gemm_nt(a, b), want, tol, 1e-2, f"gemm {M}x{N}x{Kd}")
+    elif mode == 1:
+        bias = rnd((N,))
+        close(K.gemm_nt(a, b, bias=bias, act=K.SPACER_ACT_SILU), torch.nn.functional.silu(want + bias.float()), tol, 1e-2,
+              f"gemm bias+silu {M}x{N}x{Kd}")
+    elif mode == 2:
+        res = rnd((M, N), dtype=torch.float32)
+        close(K.gemm_nt(a, b, residual=res, out_dtype=torch.float32), want + res, tol, 1e-2, f"gemm f32+res {M}x{N}x{Kd}")
+    else:
+        c = rnd((M, N), dtype=torch.float32)
+        c0 = c.clone()
+        K.gemm_nt(a, b, out=c, residual=c, out_dtype=torch.float32, split_k=bool(r.randint(0, 1)))
+        close(c, want + c0, tol, 1e-2, f"gemm accumulate {M}x{N}x{Kd}")
+
+
+def fuzz_swiglu(r):
+    M, I, Kd = r.randint(1, 6000), r.randint(1, 40) * 128, r.randint(1, 30) * 64
+    a, w = rnd((M, Kd), 0.5), rnd((2 * I, Kd), 0.08)
+    bias = rnd((2 * I,), 0.2) if r.randint(0, 1) else None
+    act, gu = K.gemm_swiglu(a, w, bias=bias, keep_gu=True)
+    gu_ref = K.gemm_nt(a, w, bias=bias, split_k=False)
+    if not torch.equal(gu, gu_ref) or not torch.equal(act, K.swiglu_fwd(gu_ref)):
+        print(f"MISMATCH gemm_swiglu {M}x{I}x{Kd} (fused={K._lib.load().spacer_gemm_swiglu_fused(M, I, Kd)})")
+        sys.exit(1)
+
+
+def fuzz_attention(r):
+    D, Hq, Hkv = r.choice([(128, 4, 2), (128, 7, 1), (80, 3, 3)])
+    causal = D == 128
+    segs, at = [], 0
+    if causal and r.randint(0, 1):
+        P = r.randint(1, 300)
+        segs.append((0, P, 0, 0)); at = P
+        for _ in range(r.randint(1, 5)):
+            L = r.randint(1, 200)
+            segs.append((at, L, 0, P)); at += L
+    else:
+        for _ in range(r.randint(1, 5)):
+            L = r.randint(1, 330)
+            segs.append((at, L, 0, 0)); at += L
+    T = at
+    qkv = rnd((T, (Hq + 2 * Hkv) * D), 0.7)
+    q, k, v = qkv[:, :Hq * D], qkv[:, Hq * D:(Hq + Hkv) * D], qkv[:, (Hq + Hkv) * D:]
+    sd = K.make_segments(segs, dev)
+    mq = max(s[1] for s in segs)
+    o, lse = K.attn_fwd(q, k, v, sd, mq, Hq, Hkv, D, causal, D ** -0.5)
+    mask = dense_mask(segs, T, causal)
+    qr, kr, vr = (t.float().detach().clone().requires_grad_(True) for t in (q, k, v))
+    want = attn_ref(qr, kr, vr, mask, Hq, Hkv, D, D ** -0.5)
+    close(o, want, 2e-2, 2e-2, f"attn fwd {segs}")
+    do = rnd((T, Hq * D), 0.5)
+    want.backward(do.float())
+    dqkv = torch.zeros_like(qkv)
+    dq = dqkv[:, :Hq * D]
+    dk, dv = torch.zeros(T, Hkv * D, device=dev), torch.zeros(T, Hkv * D, device=dev)
+    K.attn_bwd(q, k, v, o, do, lse, sd, mq, Hq, Hkv, D, causal, D ** -0.5, dq=dq, dk32=dk, dv32=dv)
+    close(dq, qr.grad, 3e-2, 3e-2, f"attn dq {segs}")
+    close(dk, kr.grad, 3e-2 * math.sqrt(max(1, len(segs))), 3e-2, f"attn dk {segs}")
+    close(dv, vr.grad, 3e-2 * math.sqrt(max(1, len(segs))), 3e-2, f"attn dv {segs}")
+
+
+def fuzz_decode_attention(r):
+    D, Hkv = 128, r.choice([1, 2, 4])
+    rep = r.choice([1, 2, 4, 7])
+    Hq = Hkv * rep
+    Kn = r.randint(2, max(2, 64 // rep)) if rep * 2 <= 64 else 2
+    Kn = min(Kn, 64 // rep)
+    nP = r.randint(1, 4)
+    B = nP * Kn
+    Pmax, Cmax = r.randint(1, 400), r.randint(1, 300)
+    q = rnd((B, Hq * D), 0.7)
+    pk, pv = rnd((nP, Pmax, Hkv, D), 0.7), rnd((nP, Pmax, Hkv, D), 0.7)
+    tk, tv = rnd((B, Cmax, Hkv, D), 0.7), rnd((B, Cmax, Hkv, D), 0.7)
+    plen = torch.tensor([r.randint(1, Pmax) for _ in range(nP)], dtype=torch.int32, device=dev)
+    pof = (torch.arange(B, device=dev) // Kn).int()
+    tl = r.randint(0, Cmax - 1)
+    tld = torch.tensor([tl], dtype=torch.int32, device=dev)
+    o = K.attn_decode_shared(q, pk, pv, plen, pof, tk, tv, tld, Kn, Hq, Hkv, D, D ** -0.5)
+    o2 = K.attn_decode(q, pk, pv, plen, pof, tk, tv, tld, Hq, Hkv, D, D ** -0.5)
+    for b in range(B):
+        P = int(plen[pof[b]])
+        kk = torch.cat([pk[pof[b], :P], tk[b, :tl + 1]]).float().repeat_interleave(rep, 1)
+        vv = torch.cat([pv[pof[b], :P], tv[b, :tl + 1]]).float().repeat_interleave(rep, 1)
+        s = torch.einsum("hd,lhd->hl", q[b].float().view(Hq, D), kk) * D ** -0.5
+        want = torch.einsum("hl,lhd->hd", torch.softmax(s, -1), vv).reshape(-1)
+        close(o[b], want, 2e-2, 2e-2, f"decode attn shared nP={nP} Kn={Kn} rep={rep} Hkv={Hkv} P={P} tl={tl}")
+        close(o2[b], want, 2e-2, 2e-2, f"decode attn plain nP={nP} Kn={Kn} rep={rep} Hkv={Hkv} P={P} tl={tl}")
+
+
+def fuzz_skinny(r):
+    M = r.randint(1, 128)
+    N, Kd = r.randint(1, 300) * 16, r.randint(1, 24) * 256
+    a, b = rnd((M, Kd), 0.5), rnd((N, Kd), 0.05)
+    c0 = rnd((M, N), dtype=torch.float32)
+    c = c0.clone()
+    K.gemm_skinny_packed_acc(a, K.pack_weight_frag(b), c, N)
+    close(c, c0 + a.float() @ b.float().t(), 5e-3, 3e-3, f"skinny packed {M}x{N}x{Kd}")
+    if M <= 128 and N % 64 == 0:
+        I = N // 2
+        y = K.gemm_skinny_swiglu(a, K.pack_weight_frag_swiglu(b), I)
+        gu = a.float() @ b.float().t()
+        close(y, torch.nn.functional.silu(gu[:, :I]) * gu[:, I:], 2e-2, 1e-2, f"skinny swiglu {M}x{I}x{Kd}")
+
+
+def fuzz_norm(r):
+    rows, cols = r.randint(1, 700), r.choice([256, 1280, 1536, 2048, 3584, 5120])
+    f32 = bool(r.randint(0, 1))
+    x = rnd((rows, cols), 2.0, torch.float32 if f32 else BF)
+    w = rnd((cols,)) + 1
+    rstd = torch.empty(rows, device=dev)
+    y = K.rmsnorm_fwd(x, w, 1e-6, rstd=rstd)
+    xr = x.float().clone().requires_grad_(True); wr = w.float().clone().requires_grad_(True)
+    want = xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-6) * wr
+    close(y, want, 3e-2, 2e-2, f"rmsnorm fwd {rows}x{cols}")
+    dy = rnd((rows, cols))
+    want.backward(dy.float())
+    dx = torch.zeros_like(x); dw = torch.zeros(cols, device=dev)
+    K.rmsnorm_bwd(x, w, dy, rstd, dx, dw)
+    close(dx, xr.grad, 3e-2, 3e-2, f"rmsnorm dx {rows}x{cols} f32={f32}")
+    close(dw, wr.grad, 3e-2 * math.sqrt(rows), 2e-2, f"rmsnorm dw {rows}x{cols} f32={f32}")
+
+
+if __name__ == "__main__":
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    r = random.Random(seed)
+    torch.manual_seed(seed)
+    fns = [fuzz_gemm, fuzz_swiglu, fuzz_attention, fuzz_decode_attention, fuzz_skinny, fuzz_norm]
+    counts = {f.__name__: 0 for f in fns}
+    t0 = time.time()
+    while time.time() - t0 < budget:
+        f = r.choice(fns)
+        f(r)
+        counts[f.__name__] += 1
+    torch.cuda.synchronize()
+    print("fuzz ok:", counts)
