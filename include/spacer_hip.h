@@ -119,6 +119,15 @@ int spacer_layernorm_fwd(const void* x, int x_f32, const void* w, const void* b,
 int spacer_layernorm_bwd(const void* x, int x_f32, const void* w, const void* dy, const float* mean,
                          const float* rstd, void* dx, int dx_accumulate, float* dw, float* db, int rows, int cols,
                          spacer_stream_t stream);
+/* Same, with a caller-owned fp32 scratch (16-byte aligned; rows/16 * cols * 4 bytes, twice that for LayerNorm, is always
+ * enough): dw / db are then reduced in two stages without atomics (deterministic, and faster: the atomic flush is a third of
+ * the kernel at 5498 x 3584).  A workspace that is NULL or too small silently selects the atomic form. */
+int spacer_rmsnorm_bwd_ws(const void* x, int x_f32, const void* w, const void* dy, const float* rstd, void* dx,
+                          int dx_accumulate, float* dw, int rows, int cols, void* workspace, long workspace_bytes,
+                          spacer_stream_t stream);
+int spacer_layernorm_bwd_ws(const void* x, int x_f32, const void* w, const void* dy, const float* mean,
+                            const float* rstd, void* dx, int dx_accumulate, float* dw, float* db, int rows, int cols,
+                            void* workspace, long workspace_bytes, spacer_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Rotary embeddings.  cos/sin are fp32 tables [tokens, head_dim] (host builds them from the M-RoPE /

@@ -42,8 +42,10 @@ SIGNATURES = {
     "spacer_transpose_bf16": [_p, _l, _p, _l, _i, _i, _i, _p],
     "spacer_rmsnorm_fwd": [_p, _i, _p, _p, _p, _i, _i, _f, _p],
     "spacer_rmsnorm_bwd": [_p, _i, _p, _p, _p, _p, _i, _p, _i, _i, _p],
+    "spacer_rmsnorm_bwd_ws": [_p, _i, _p, _p, _p, _p, _i, _p, _i, _i, _p, _l, _p],
     "spacer_layernorm_fwd": [_p, _i, _p, _p, _p, _p, _p, _i, _i, _f, _p],
     "spacer_layernorm_bwd": [_p, _i, _p, _p, _p, _p, _p, _i, _p, _p, _i, _i, _p],
+    "spacer_layernorm_bwd_ws": [_p, _i, _p, _p, _p, _p, _p, _i, _p, _p, _i, _i, _p, _l, _p],
     "spacer_rope_inplace": [_p, _l, _p, _p, _i, _i, _i, _i, _p],
     "spacer_attn_fwd": [_p, _p, _p, _p, _p, _l, _l, _l, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p],
     "spacer_attn_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _l, _l, _l, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p],

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(NT) void norm_bwd_kernel(const void* __restrict__ x
                                                       const bf16_t* __restrict__ dy, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, void* __restrict__ dx,
                                                       int dx_acc, float* __restrict__ dw, float* __restrict__ db,
-                                                      int rows, int cols, int rpb) {
+                                                      int rows, int cols, int rpb, float* __restrict__ part) {
     __shared__ float red[32];
     float dwp[IT][4], dbp[IT][4], wv[IT][4];
 #pragma unroll
@@ -169,6 +169,11 @@ __global__ __launch_bounds__(NT) void norm_bwd_kernel(const void* __restrict__ x
     for (int it = 0; it < IT; ++it) {
         const int c = (it * NT + threadIdx.x) * 4;
         if (c < cols) {
+            if (part) {          // two-stage form: this block's partial row (dw | db) in the workspace, summed by norm_dw_reduce_kernel
+                *(float4*)(part + (long)blockIdx.x * cols + c) = make_float4(dwp[it][0], dwp[it][1], dwp[it][2], dwp[it][3]);
+                if (LAYER) *(float4*)(part + ((long)gridDim.x + blockIdx.x) * cols + c) = make_float4(dbp[it][0], dbp[it][1], dbp[it][2], dbp[it][3]);
+                continue;
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (dw) atomicAdd(dw + c + e, dwp[it][e]);
@@ -182,12 +187,12 @@ __global__ __launch_bounds__(NT) void norm_bwd_kernel(const void* __restrict__ x
 // is 5 KiB -- a 256-thread block spends its time in the two block-wide reductions (4 barriers per row, rows strictly one after
 // the other: 80-128 us for 4160 x 1280); here the reductions are wave shuffles, the 4 waves of a block walk 4 rows at once
 // (next row's loads in flight), and the per-wave dw / db partials meet in LDS before the one atomic per column per block.
-constexpr int WROWS = 32;     // rows per block (8 per wave)
+constexpr int WROWS = 16;     // rows per block (4 per wave); with the two-stage dw reduction more, smaller blocks win (32 is better under atomics)
 template <bool XF32, bool LAYER, int WG>
 __global__ __launch_bounds__(NT) void norm_bwd_wave_kernel(const void* __restrict__ x, const bf16_t* __restrict__ w,
                                                            const bf16_t* __restrict__ dy, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, void* __restrict__ dx, int dx_acc,
-                                                           float* __restrict__ dw, float* __restrict__ db, int rows, int cols) {
+                                                           float* __restrict__ dw, float* __restrict__ db, int rows, int cols, float* __restrict__ gpart) {
     __shared__ float part[2][3][64 * 4 * WG];           // waves 1..3 park their dw (and db) partials here
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float dwp[WG][4], dbp[WG][4], wv[WG][4];
@@ -266,17 +271,42 @@ __global__ __launch_bounds__(NT) void norm_bwd_wave_kernel(const void* __restric
         for (int it = 0; it < WG; ++it) {
             const int c = (it * 64 + lane) * 4;
             if (c < cols) {
+                float a[4], b[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float a = dwp[it][e], b = dbp[it][e];
+                    a[e] = dwp[it][e]; b[e] = dbp[it][e];
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) { a += part[0][k][c + e]; if (LAYER) b += part[1][k][c + e]; }
-                    if (dw) atomicAdd(dw + c + e, a);
-                    if (LAYER && db) atomicAdd(db + c + e, b);
+                    for (int k = 0; k < 3; ++k) { a[e] += part[0][k][c + e]; if (LAYER) b[e] += part[1][k][c + e]; }
+                }
+                if (gpart) {
+                    *(float4*)(gpart + (long)blockIdx.x * cols + c) = make_float4(a[0], a[1], a[2], a[3]);
+                    if (LAYER) *(float4*)(gpart + ((long)gridDim.x + blockIdx.x) * cols + c) = make_float4(b[0], b[1], b[2], b[3]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (dw) atomicAdd(dw + c + e, a[e]);
+                        if (LAYER && db) atomicAdd(db + c + e, b[e]);
+                    }
                 }
             }
         }
     }
+}
+
+// second stage of the two-stage dw / db reduction: dw[c] += sum over the blocks' partial rows (coalesced across c)
+__global__ __launch_bounds__(NT) void norm_dw_reduce_kernel(const float* __restrict__ part, int nblocks, int cols, float* __restrict__ dw,
+                                                            float* __restrict__ db) {
+    const int c = blockIdx.x * NT + threadIdx.x;
+    if (c >= cols) return;
+    const float* p = part + (blockIdx.y ? (long)nblocks * cols : 0) + c;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = 0;
+    for (; b + 4 <= nblocks; b += 4) {
+        s0 += p[(long)b * cols]; s1 += p[(long)(b + 1) * cols]; s2 += p[(long)(b + 2) * cols]; s3 += p[(long)(b + 3) * cols];
+    }
+    for (; b < nblocks; ++b) s0 += p[(long)b * cols];
+    float* out = blockIdx.y ? db : dw;
+    if (out) out[c] += (s0 + s1) + (s2 + s3);
 }
 
 int check_shape(const char* who, int rows, int cols) {
@@ -316,43 +346,55 @@ extern "C" int spacer_layernorm_fwd(const void* x, int x_f32, const void* w, con
     return SPACER_OK;
 }
 
-extern "C" int spacer_rmsnorm_bwd(const void* x, int x_f32, const void* w, const void* dy, const float* rstd, void* dx,
-                                  int dx_accumulate, float* dw, int rows, int cols, spacer_stream_t stream) {
-    if (int rc = check_shape("rmsnorm_bwd", rows, cols)) return rc;
-    const int rpb = rows_per_block(), grid = cdiv(rows, rpb);
+// Shared launcher of the backward kernels.  workspace (optional, fp32 scratch of >= blocks * cols * (LAYER ? 2 : 1) floats): the
+// blocks leave their dw / db partial rows there and a second small kernel sums them into dw / db -- no atomics (their flush
+// costs ~33 us of a 5498 x 3584 launch: 1.2 M fp32 atomics at the ~37 G/s the L2 atomic units retire).  NULL: atomics.
+template <bool LAYER>
+static int launch_norm_bwd(const char* who, const void* x, int x_f32, const void* w, const void* dy, const float* mean, const float* rstd,
+                           void* dx, int dx_accumulate, float* dw, float* db, int rows, int cols, void* workspace, long workspace_bytes,
+                           spacer_stream_t stream) {
+    if (int rc = check_shape(who, rows, cols)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const bool narrow = cols <= 64 * 4 * 6;
+    const int rpb = rows_per_block(), grid = narrow ? cdiv(rows, WROWS) : cdiv(rows, rpb);
+    const long need = (long)grid * cols * (LAYER ? 2 : 1) * (long)sizeof(float);
+    float* part = (workspace && workspace_bytes >= need && ((uintptr_t)workspace % 16) == 0 && (dw || db)) ? (float*)workspace : nullptr;
 #define BWD(F32, IT)                                                                                                     \
-    hipLaunchKernelGGL((norm_bwd_kernel<F32, false, IT>), dim3(grid), dim3(NT), 0, (hipStream_t)stream, x, (const bf16_t*)w, \
-                       (const bf16_t*)dy, nullptr, rstd, dx, dx_accumulate, dw, nullptr, rows, cols, rpb)
+    hipLaunchKernelGGL((norm_bwd_kernel<F32, LAYER, IT>), dim3(grid), dim3(NT), 0, s, x, (const bf16_t*)w, (const bf16_t*)dy, mean, \
+                       rstd, dx, dx_accumulate, dw, db, rows, cols, rpb, part)
     const int it = cols <= NT * 4 * 2 ? 2 : cols <= NT * 4 * 4 ? 4 : MAXIT;
-    if (cols <= 64 * 4 * 6) {
-        if (x_f32) hipLaunchKernelGGL((norm_bwd_wave_kernel<true, false, 6>), dim3(cdiv(rows, WROWS)), dim3(NT), 0, (hipStream_t)stream, x,
-                                      (const bf16_t*)w, (const bf16_t*)dy, nullptr, rstd, dx, dx_accumulate, dw, nullptr, rows, cols);
-        else hipLaunchKernelGGL((norm_bwd_wave_kernel<false, false, 6>), dim3(cdiv(rows, WROWS)), dim3(NT), 0, (hipStream_t)stream, x,
-                                (const bf16_t*)w, (const bf16_t*)dy, nullptr, rstd, dx, dx_accumulate, dw, nullptr, rows, cols);
+    if (narrow) {
+        if (x_f32) hipLaunchKernelGGL((norm_bwd_wave_kernel<true, LAYER, 6>), dim3(grid), dim3(NT), 0, s, x, (const bf16_t*)w,
+                                      (const bf16_t*)dy, mean, rstd, dx, dx_accumulate, dw, db, rows, cols, part);
+        else hipLaunchKernelGGL((norm_bwd_wave_kernel<false, LAYER, 6>), dim3(grid), dim3(NT), 0, s, x, (const bf16_t*)w,
+                                (const bf16_t*)dy, mean, rstd, dx, dx_accumulate, dw, db, rows, cols, part);
     } else if (x_f32) { if (it == 2) BWD(true, 2); else if (it == 4) BWD(true, 4); else BWD(true, MAXIT); }
     else { if (it == 2) BWD(false, 2); else if (it == 4) BWD(false, 4); else BWD(false, MAXIT); }
 #undef BWD
+    if (part) hipLaunchKernelGGL(norm_dw_reduce_kernel, dim3(cdiv(cols, NT), LAYER ? 2 : 1), dim3(NT), 0, s, part, grid, cols, dw, db);
     SP_CHECK_LAUNCH();
     return SPACER_OK;
+}
+
+extern "C" int spacer_rmsnorm_bwd(const void* x, int x_f32, const void* w, const void* dy, const float* rstd, void* dx,
+                                  int dx_accumulate, float* dw, int rows, int cols, spacer_stream_t stream) {
+    return launch_norm_bwd<false>("rmsnorm_bwd", x, x_f32, w, dy, nullptr, rstd, dx, dx_accumulate, dw, nullptr, rows, cols, nullptr, 0, stream);
+}
+extern "C" int spacer_rmsnorm_bwd_ws(const void* x, int x_f32, const void* w, const void* dy, const float* rstd, void* dx,
+                                     int dx_accumulate, float* dw, int rows, int cols, void* workspace, long workspace_bytes,
+                                     spacer_stream_t stream) {
+    return launch_norm_bwd<false>("rmsnorm_bwd", x, x_f32, w, dy, nullptr, rstd, dx, dx_accumulate, dw, nullptr, rows, cols, workspace,
+                                  workspace_bytes, stream);
 }
 
 extern "C" int spacer_layernorm_bwd(const void* x, int x_f32, const void* w, const void* dy, const float* mean,
                                     const float* rstd, void* dx, int dx_accumulate, float* dw, float* db, int rows,
                                     int cols, spacer_stream_t stream) {
-    if (int rc = check_shape("layernorm_bwd", rows, cols)) return rc;
-    const int rpb = rows_per_block(), grid = cdiv(rows, rpb);
-#define BWD(F32, IT)                                                                                                     \
-    hipLaunchKernelGGL((norm_bwd_kernel<F32, true, IT>), dim3(grid), dim3(NT), 0, (hipStream_t)stream, x, (const bf16_t*)w,  \
-                       (const bf16_t*)dy, mean, rstd, dx, dx_accumulate, dw, db, rows, cols, rpb)
-    const int it = cols <= NT * 4 * 2 ? 2 : cols <= NT * 4 * 4 ? 4 : MAXIT;
-    if (cols <= 64 * 4 * 6) {
-        if (x_f32) hipLaunchKernelGGL((norm_bwd_wave_kernel<true, true, 6>), dim3(cdiv(rows, WROWS)), dim3(NT), 0, (hipStream_t)stream, x,
-                                      (const bf16_t*)w, (const bf16_t*)dy, mean, rstd, dx, dx_accumulate, dw, db, rows, cols);
-        else hipLaunchKernelGGL((norm_bwd_wave_kernel<false, true, 6>), dim3(cdiv(rows, WROWS)), dim3(NT), 0, (hipStream_t)stream, x,
-                                (const bf16_t*)w, (const bf16_t*)dy, mean, rstd, dx, dx_accumulate, dw, db, rows, cols);
-    } else if (x_f32) { if (it == 2) BWD(true, 2); else if (it == 4) BWD(true, 4); else BWD(true, MAXIT); }
-    else { if (it == 2) BWD(false, 2); else if (it == 4) BWD(false, 4); else BWD(false, MAXIT); }
-#undef BWD
-    SP_CHECK_LAUNCH();
-    return SPACER_OK;
+    return launch_norm_bwd<true>("layernorm_bwd", x, x_f32, w, dy, mean, rstd, dx, dx_accumulate, dw, db, rows, cols, nullptr, 0, stream);
+}
+extern "C" int spacer_layernorm_bwd_ws(const void* x, int x_f32, const void* w, const void* dy, const float* mean,
+                                       const float* rstd, void* dx, int dx_accumulate, float* dw, float* db, int rows,
+                                       int cols, void* workspace, long workspace_bytes, spacer_stream_t stream) {
+    return launch_norm_bwd<true>("layernorm_bwd", x, x_f32, w, dy, mean, rstd, dx, dx_accumulate, dw, db, rows, cols, workspace,
+                                 workspace_bytes, stream);
 }

@@ -233,8 +233,9 @@ def rmsnorm_fwd(x, w, eps, *, rstd=None, out=None):
 def rmsnorm_bwd(x, w, dy, rstd, dx, dw, *, accumulate=True):
     rows, cols = x.shape
     assert dx.dtype == x.dtype and dw.dtype == torch.float32
-    check(_lib.load().spacer_rmsnorm_bwd(_ptr(x), int(x.dtype == torch.float32), _ptr(w), _ptr(dy), _ptr(rstd), _ptr(dx),
-                                         int(accumulate), _ptr(dw), rows, cols, _stream()), "rmsnorm_bwd")
+    ws = _gemm_workspace(x.device)          # two-stage dw reduction (no atomics); launches on one stream share the scratch
+    check(_lib.load().spacer_rmsnorm_bwd_ws(_ptr(x), int(x.dtype == torch.float32), _ptr(w), _ptr(dy), _ptr(rstd), _ptr(dx),
+                                            int(accumulate), _ptr(dw), rows, cols, _ptr(ws), ws.numel() * 4, _stream()), "rmsnorm_bwd")
     return dx
 
 
@@ -249,9 +250,10 @@ def layernorm_fwd(x, w, b, eps=1e-6, *, mean=None, rstd=None, out=None):
 
 def layernorm_bwd(x, w, dy, mean, rstd, dx, dw, db, *, accumulate=True):
     rows, cols = x.shape
-    check(_lib.load().spacer_layernorm_bwd(_ptr(x), int(x.dtype == torch.float32), _ptr(w), _ptr(dy), _ptr(mean), _ptr(rstd),
-                                           _ptr(dx), int(accumulate), _ptr(dw), _ptr(db), rows, cols, _stream()),
-          "layernorm_bwd")
+    ws = _gemm_workspace(x.device)
+    check(_lib.load().spacer_layernorm_bwd_ws(_ptr(x), int(x.dtype == torch.float32), _ptr(w), _ptr(dy), _ptr(mean), _ptr(rstd),
+                                              _ptr(dx), int(accumulate), _ptr(dw), _ptr(db), rows, cols, _ptr(ws), ws.numel() * 4,
+                                              _stream()), "layernorm_bwd")
     return dx
 
 
