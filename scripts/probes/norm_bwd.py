@@ -36,3 +36,11 @@ e0.record()
 for _ in range(20): K.layernorm_bwd(x, w, dy, mean, rstd, dx, dw, db)
 e1.record(); torch.cuda.synchronize()
 print(f"  layernorm_bwd {rows}x{cols}: {e0.elapsed_time(e1) / 20 * 1e3:7.1f} us")
+for rows, cols in [(4160, 1280), (5498, 4608), (4160, 5120)]:
+    dyb = torch.randn(rows, cols, device=dev).bfloat16(); dbb = torch.zeros(cols, device=dev)
+    for _ in range(3): K.bias_grad_(dyb, dbb)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(20): K.bias_grad_(dyb, dbb)
+    e1.record(); torch.cuda.synchronize()
+    print(f"  bias_grad {rows}x{cols}: {e0.elapsed_time(e1) / 20 * 1e3:7.1f} us")
