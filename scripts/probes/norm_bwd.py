@@ -44,3 +44,12 @@ for rows, cols in [(4160, 1280), (5498, 4608), (4160, 5120)]:
     for _ in range(20): K.bias_grad_(dyb, dbb)
     e1.record(); torch.cuda.synchronize()
     print(f"  bias_grad {rows}x{cols}: {e0.elapsed_time(e1) / 20 * 1e3:7.1f} us")
+rows, cols = 4160, 1280
+x = torch.randn(rows, cols, device=dev); w = torch.randn(cols, device=dev).bfloat16(); b = torch.randn(cols, device=dev).bfloat16()
+mean = torch.empty(rows, device=dev); rstd = torch.empty(rows, device=dev); y = torch.empty(rows, cols, device=dev, dtype=torch.bfloat16)
+for _ in range(3): K.layernorm_fwd(x, w, b, 1e-6, mean=mean, rstd=rstd, out=y)
+torch.cuda.synchronize()
+e0.record()
+for _ in range(20): K.layernorm_fwd(x, w, b, 1e-6, mean=mean, rstd=rstd, out=y)
+e1.record(); torch.cuda.synchronize()
+print(f"  layernorm_fwd {rows}x{cols}: {e0.elapsed_time(e1) / 20 * 1e3:7.1f} us")
