@@ -81,8 +81,14 @@ class RolloutEngine:
         starts = [0]
         for P in plen[:-1]:
             starts.append(starts[-1] + P)
-        pk = torch.zeros(L, nP, Pmax, Hkv, D, device=self.dev, dtype=BF16)
-        pv = torch.zeros_like(pk)
+        pk = torch.empty(L, nP, Pmax, Hkv, D, device=self.dev, dtype=BF16)
+        pv = torch.empty_like(pk)
+        # packed row of every (prompt, position) slot of the prompt KV cache; slots past a prompt's length are never read
+        # (the attention kernels stop at plen) and take row 0
+        gidx = torch.zeros(nP, Pmax, dtype=torch.int32)
+        for pi, (s0, P) in enumerate(zip(starts, plen)):
+            gidx[pi, :P] = torch.arange(s0, s0 + P, dtype=torch.int32)
+        gidx = gidx.reshape(-1).to(self.dev)
         with_video = [p for p in prompts if p.pix is not None]
         video = None
         if with_video:
@@ -98,10 +104,9 @@ class RolloutEngine:
         cos, sin = POS.mrope_tables(torch.cat(pos_list, 1), cfg, self.dev)
         segs = K.make_segments([(s0, P, 0, 0) for s0, P in zip(starts, plen)], self.dev)
 
-        def sink(layer, k, v):
-            for pi, (s0, P) in enumerate(zip(starts, plen)):
-                pk[layer, pi, :P].view(P, Hkv * D).copy_(k[s0:s0 + P])
-                pv[layer, pi, :P].view(P, Hkv * D).copy_(v[s0:s0 + P])
+        def sink(layer, k, v):          # one row gather per tensor per layer (was one device copy per prompt)
+            K.gather_rows(k, gidx, out=pk[layer].view(nP * Pmax, Hkv * D))
+            K.gather_rows(v, gidx, out=pv[layer].view(nP * Pmax, Hkv * D))
 
         x = e.llm_forward(x0, cos, sin, segs, Pmax, kv_sink=sink)
         last = torch.tensor([s0 + P - 1 for s0, P in zip(starts, plen)], dtype=torch.int64, device=self.dev)
