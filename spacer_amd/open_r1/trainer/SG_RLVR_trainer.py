@@ -359,6 +359,9 @@ class SGRLVRTrainer:
         while self.global_step < self.total_steps:
             idx = shard_indices(n_rows, self.rank, self.world, a.data_seed if a.data_seed is not None else a.seed, epoch)
             starts = list(range(0, len(idx) - acc + 1, acc))
+            if not starts:
+                raise ValueError(f"{len(idx)} samples per rank cannot fill one optimizer step of {acc} micro-batches "
+                                 "(per_device_train_batch_size x gradient_accumulation_steps)")
 
             def submit(s0: int):
                 return [pool.submit(self._prepare, [self.train_dataset[idx[s0 + j]]], prep_seed(epoch, s0 + j)) for j in range(acc)]
