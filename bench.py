@@ -2,6 +2,7 @@
 """Headline benchmark: GRPO samples/sec (K=8 rollouts), Qwen2-VL-7B, 16-frame video, on N MI355X.
 
     python bench.py --gpus 1 --steps 2 --warmup 1
+    python bench.py --gpus N ...          # N > 1 without a launcher: re-executes itself under torch.distributed.run, N ranks
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -13,7 +14,9 @@ Nothing is skipped or cached inside the timed region.  Weak scaling: every rank 
 Prints ONE JSON line on rank 0 (see the driver contract in the task statement) with two extra objects:
   roofline      bf16 MFMA roofline of the dominant kernel (gemm_bf16_nt_256h_kernel), measured live with HIP events on
                 the launch stream over the timed region: sum(2*M*N*K) / sum(duration)
-  cpu_baseline  the fp32 oracle (oracle/qwen2vl_fp32.py, kind "port") timed on the host cores on a bounded sample
+  cpu_baseline  the whole step for one prompt group restated on the host (oracle/cpu_path.py, kind "port": ViT + prefill +
+                KV-cache decode + reference / policy scoring + autograd backward) timed on a bounded sample of the workload
+  variants      (N = 1) the same workload with the shipped script's --temporal true, and free-running (EOS allowed, 1024 new tokens)
 """
 from __future__ import annotations
 
@@ -43,14 +46,9 @@ DECODE_WEIGHT_GB = {"Qwen2-VL-7B": 14.14, "Qwen2.5-VL-7B": 14.14}               
 ALGO_TF_PER_SAMPLE = {"cfg3": 53.1, "cfg4": 53.1}   # SURVEY 8(d), temporal branch off
 
 
-def cpu_baseline(cfg, seconds_budget: float = 12.0):
-    """Oracle timed on the host: one decoder layer + one ViT block of the benchmark's shapes over a small token
-    batch; FLOP rate extrapolated to the algorithmic FLOPs of one sample."""
+def cpu_gemm_rate(cfg, seconds_budget: float = 4.0):
+    """fp32 GEMM-dominated rate of the host: forwards of ONE decoder layer of the benchmark's width over 1024 tokens."""
     from oracle import qwen2vl_fp32 as O
-    # measured on the MI355X box's host (256 hardware threads): fp32 torch GEMMs peak at 16-32 threads (~1.1 TFLOP/s)
-    # and collapse when all 256 are used (15 GFLOP/s), so the baseline uses 32 threads and says so in "cores"
-    threads = min(32, os.cpu_count() or 1)
-    torch.set_num_threads(threads)
     one = O.make_config(hidden=cfg.hidden, layers=1, heads=cfg.heads, kv_heads=cfg.kv_heads, intermediate=cfg.intermediate,
                         vocab=1024, vit_dim=cfg.vit_dim, vit_depth=1, vit_heads=cfg.vit_heads, vit_mlp=cfg.vit_mlp,
                         head_dim=cfg.head_dim)
@@ -67,8 +65,62 @@ def cpu_baseline(cfg, seconds_budget: float = 12.0):
             O.llm_forward(w, one, x, pos, return_hidden=True)
             n += 1
         dt = time.perf_counter() - t0
-    rate = per_layer * n / dt / 1e12      # TFLOP/s on the host
-    return rate, threads, f"{n} fp32 forwards of one {cfg.hidden}-wide decoder layer over {T} tokens ({dt:.1f} s)"
+    return per_layer * n / dt / 1e12
+
+
+def cpu_baseline(cfg, workload):
+    """The reference path's CPU stand-in (SURVEY 8(d) "CPU baseline"): ONE prompt group through the WHOLE step on the host
+    (oracle/cpu_path.py: ViT + prefill, KV-cache decode, reference + policy scoring with the prompt shared, GRPO loss,
+    autograd backward; fp32 torch) on a BOUNDED sample of the workload: the model's real widths with the depth cut to 2
+    decoder layers + 2 vision blocks and an 8192-row vocabulary, the workload's real frames / prompt length, K = 2 rollouts
+    of 8 tokens.  Every phase is then scaled to the full depth, K and C by its own cost law (stated in "extrapolation")."""
+    from oracle import cpu_path as CP
+    from oracle import qwen2vl_fp32 as O
+    preset, F, Hpx, Wpx, n_text, Kgen, C, groups = workload
+    # fp32 torch GEMMs on this host peak at 16-32 threads and collapse when all 256 hardware threads are used
+    threads = min(32, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    Ls, Vs, Ks, Cs, vocab_s = 2, 2, 2, 8, 8192
+    oc = O.make_config(hidden=cfg.hidden, layers=Ls, heads=cfg.heads, kv_heads=cfg.kv_heads, intermediate=cfg.intermediate,
+                       vocab=vocab_s, vit_dim=cfg.vit_dim, vit_depth=Vs, vit_heads=cfg.vit_heads, vit_mlp=cfg.vit_mlp,
+                       head_dim=cfg.head_dim, tie_embeddings=cfg.tie_embeddings, video_token_id=vocab_s - 1, image_token_id=vocab_s - 2)
+    if cfg.vit_kind != "qwen2":
+        return None
+    w_ref = O.random_weights(oc, seed=1234)
+    g = torch.Generator().manual_seed(1000)
+    frames = torch.randint(0, 256, (F, 3, Hpx, Wpx), generator=g, dtype=torch.uint8)
+    rows, grid = O.patchify_frames(frames, oc)
+    nv = grid[0] * grid[1] * grid[2] // 4
+    prompt = torch.cat([torch.tensor([vocab_s - 4]), torch.full((nv,), oc["video_token_id"]), torch.tensor([vocab_s - 3]),
+                        torch.randint(5, vocab_s - 8, (n_text,), generator=g)])
+    w = {k: v.clone().requires_grad_(True) for k, v in w_ref.items()}
+    out = CP.grpo_group_step(w, w_ref, oc, prompt, rows, [tuple(grid)], num_generations=Ks, max_new_tokens=Cs, eos_token_id=7, seed=1)
+    sec = out["seconds"]
+    P = prompt.numel()
+    # scale each phase from the sample (Ls layers, Vs blocks, Ks x Cs tokens) to the workload (full depth, K x C tokens):
+    #   vit+prefill: ViT part ~ depth, prefill ~ layers (split by their FLOPs);  decode: per token-step time (memory-bound weight
+    #   streaming, batch-independent up to K=8) x layers x C;  scoring / backward: ~ layers x tokens (P + K*C) (+ ViT ~ depth)
+    Lr, Vr = cfg.layers / Ls, cfg.vit_depth / Vs
+    vit_f = 2.0 * grid[0] * grid[1] * grid[2] * (12 * cfg.vit_dim ** 2 + 2 * 0) * Vs      # rough split only
+    pre_f = 2.0 * P * (cfg.hidden * cfg.qkv_dim + cfg.heads * cfg.head_dim * cfg.hidden + 3 * cfg.hidden * cfg.intermediate) * Ls
+    fv = vit_f / (vit_f + pre_f)
+    tok_s, tok_r = P + Ks * Cs, P + Kgen * C
+    full = {
+        "vit+prefill": sec["vit+prefill"] * (fv * Vr + (1 - fv) * Lr),
+        "decode": sec["decode"] / max(1, Cs - 1) * Lr * (C - 1),
+        "ref scoring": sec["ref scoring"] * (fv * Vr + (1 - fv) * Lr * tok_r / tok_s),
+        "policy scoring": sec["policy scoring"] * (fv * Vr + (1 - fv) * Lr * tok_r / tok_s),
+        "loss+backward": sec["loss+backward"] * (fv * Vr + (1 - fv) * Lr * tok_r / tok_s),
+    }
+    t_group = sum(full.values())
+    return {"value": Kgen / t_group, "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"one prompt group through oracle/cpu_path.py at the model's widths, {Ls} decoder layers + {Vs} vision blocks, "
+                      f"vocab {vocab_s}, {F} frames {Hpx}x{Wpx}, P={P}, K={Ks}, C={Cs}: {out['total_seconds']:.1f} s measured",
+            "measured_phase_seconds": {k: round(v, 3) for k, v in sec.items()},
+            "measured_decode_tokens_per_s_at_sample_depth": round(Ks * (Cs - 1) / sec["decode"], 2),
+            "extrapolation": f"phases scaled to {cfg.layers} layers / {cfg.vit_depth} vision blocks, K={Kgen}, C={C}: "
+                             + ", ".join(f"{k} {v:.0f} s" for k, v in full.items()) + f" = {t_group:.0f} s per group",
+            "cpu_gemm_rate_gflops": round(1e3 * cpu_gemm_rate(cfg), 1)}
 
 
 def pmc_traffic(workload: str):
@@ -95,15 +147,33 @@ def main():
     ap.add_argument("--completion-len", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--grad-comm", choices=("fp32", "bf16"), default="fp32",
-                    help="wire format of the gradient all-reduce (N > 1): fp32 values, or bf16 as DeepSpeed's bf16 mode sends them")
+    ap.add_argument("--grad-comm", choices=("fp32", "bf16"), default="bf16",
+                    help="wire format of the gradient all-reduce (N > 1): bf16 as the reference's DeepSpeed bf16 mode sends them, or fp32")
+    ap.add_argument("--no-overlap", action="store_true", help="exchange gradients after the last backward instead of during it")
+    ap.add_argument("--no-variants", action="store_true", help="skip the extra --temporal / free-running measurements (N = 1)")
     ap.add_argument("--phase-times", action="store_true", help="print per-phase wall times (adds synchronisations)")
     ap.add_argument("--gemm-shapes", action="store_true", help="also print the GEMM time broken down by (M,N,K) to stderr")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher -- one process per GPU under torch.distributed.run (RCCL)
+        import socket
+        import subprocess
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus:
+            sys.exit(f"bench.py --gpus {args.gpus}: only {n_dev} GPU(s) visible")
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.run(cmd, env=env).returncode)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py --gpus {args.gpus} was launched with WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pg = None
@@ -111,7 +181,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
         pg = dist.group.WORLD
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+        world = dist.get_world_size()            # the RCCL world actually formed
 
     from spacer_amd import kernels as K
     from spacer_amd.grpo import GRPOEngine, GRPOHyper, group_advantages, length_bonus, temporal_bonus
@@ -124,7 +194,8 @@ def main():
     groups = args.groups or groups
     C = args.completion_len or C
     cfg = PRESETS[preset]
-    hyper = GRPOHyper(num_generations=Kgen, temporal=False, len_control=True, total_steps=1000, grad_comm_bf16=args.grad_comm == "bf16")
+    hyper = GRPOHyper(num_generations=Kgen, temporal=False, len_control=True, total_steps=1000, grad_comm_bf16=args.grad_comm == "bf16",
+                      overlap_comm=not args.no_overlap)
     params = FlatParams.empty(cfg, dev)
     random_init_(params, seed=1234)
     ge = GRPOEngine(cfg, params, hyper, process_group=pg)
@@ -140,11 +211,11 @@ def main():
             return time.perf_counter()
         return t0
 
-    def step(step_idx):
+    def step(step_idx, temporal=args.temporal, sp=sp):
         t0 = time.perf_counter()
         prompts = [make_prompt(cfg, rank * groups + g, F, Hpx, Wpx, n_text, dev, frames_u8=frames[g])[0] for g in range(groups)]
         scomp = None
-        if args.temporal:                         # the shuffled twin: same text, temporally permuted frames
+        if temporal:                              # the shuffled twin: same text, temporally permuted frames
             sprompts = []
             for g in range(groups):
                 perm = torch.randperm(F, generator=torch.Generator().manual_seed(77 + step_idx * 1009 + rank * groups + g)).to(dev)
@@ -162,9 +233,10 @@ def main():
             rpf = synthetic_rewards(step_idx, rank * groups + g, Kgen)
             srpf = synthetic_rewards(step_idx + 100003, rank * groups + g, Kgen // 2) if scomp is not None else None
             rewards, _ = temporal_bonus(rpf, srpf, scomp is not None, True)
-            rewards = length_bonus(rewards, rpf, torch.full((Kgen,), C), hyper.len_control)
+            rewards = length_bonus(rewards, rpf, torch.full((Kgen,), cg.shape[1]), hyper.len_control)
             adv, _ = group_advantages(rewards, Kgen)
-            ge.score_and_backward(prompts[g], cg, adv.to(dev), grad_scale=1.0 / groups)
+            # the rank's last backward of the step hands finished layer ranges to the data-parallel reducer (overlap_comm)
+            ge.score_and_backward(prompts[g], cg, adv.to(dev), grad_scale=1.0 / groups, last_group=g == groups - 1)
         t0 = tick("score+backward", t0)
         ge.reduce_gradients()
         ge.optimizer_step(world)
@@ -195,6 +267,31 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     prof = K.PROFILER.summary()
+    main_stats = dict(roll_stats)
+    variants = {}
+    if world == 1 and not args.no_variants and not args.temporal and args.workload in ("cfg3", "cfg2", "tiny"):
+        # the same workload as the shipped script runs it (run_SpaceR_SG_RLVR.sh:29 --temporal true) and free-running
+        # (EOS allowed, --max_completion_length 1024, :33): reported beside the headline, never as it
+        from dataclasses import replace
+        for name, kw in (("temporal", dict(temporal=True)),
+                         ("free_running", dict(sp=replace(sp, max_new_tokens=2 * C if args.workload == "tiny" else 1024, suppress_eos=False)))):
+            try:
+                roll_stats.clear()
+                step(10_000, **kw)
+                torch.cuda.synchronize()
+                t_v = time.perf_counter()
+                n_v = 2
+                for i in range(n_v):
+                    step(10_001 + i, **kw)
+                torch.cuda.synchronize()
+                dt_v = (time.perf_counter() - t_v) / n_v
+                variants[name] = {"samples_per_s": round(groups * Kgen / dt_v, 3), "ms_per_step": round(1e3 * dt_v, 1), "steps": n_v,
+                                  "max_new_tokens": kw["sp"].max_new_tokens if "sp" in kw else C}
+            except Exception as exc:                                   # e.g. out of memory on a smaller part: report, do not die
+                variants[name] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+                torch.cuda.empty_cache()
+        roll_stats.clear()
+        roll_stats.update(main_stats)
     if args.gemm_shapes and rank == 0:
         shapes = sorted(((v["seconds"], k, v) for k, v in prof.items() if k.startswith("gemm[")), reverse=True)
         for sec, k, v in shapes[:24]:
@@ -216,7 +313,9 @@ def main():
             "config": {"workload": f"{args.workload}: {preset} random-init bf16, {F} frames {Hpx}x{Wpx}, {n_text} text tokens, "
                                    f"K={Kgen}, C={C} (EOS suppressed), {groups} prompt groups/GPU, full step "
                                    f"(rollout+ref/policy scoring+backward+AdamW)",
-                       "global_batch": groups * Kgen * world, "parallelism": f"dp{world}", "decode_graph": not args.no_graph, "grad_comm": args.grad_comm},
+                       "global_batch": groups * Kgen * world, "parallelism": f"dp{world}", "decode_graph": not args.no_graph,
+                       "grad_comm": args.grad_comm, "overlap_comm": not args.no_overlap, "rccl_world": world,
+                       "devices": [torch.cuda.get_device_name(local)] if world == 1 else f"{world} x {torch.cuda.get_device_name(local)}"},
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_256h_kernel", "achieved": round(gemm["tflops"], 2),
                          "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gemm["tflops"] / MFMA_PEAK_TFLOPS, 4),
                          "traffic": pmc_traffic(args.workload), "launches": gemm["launches"],
@@ -246,12 +345,10 @@ def main():
             out["step_algorithmic_tflops"] = round(ALGO_TF_PER_SAMPLE[args.workload] * value / world, 2)
         if args.phase_times:
             out["phase_seconds_per_step"] = {k: round(v / args.steps, 3) for k, v in phase.items()}
+        if variants:
+            out["variants"] = variants
         if not args.no_cpu_baseline and world == 1:
-            rate, cores, sample = cpu_baseline(cfg)
-            tf_sample = ALGO_TF_PER_SAMPLE.get(args.workload)
-            out["cpu_baseline"] = {"value": (rate / tf_sample) if tf_sample else None, "unit": "samples/s", "cores": cores,
-                                   "kind": "port", "sample": sample + f"; host rate {rate * 1e3:.1f} GFLOP/s"
-                                   + (f" extrapolated to {tf_sample} TFLOP/sample" if tf_sample else "")}
+            out["cpu_baseline"] = cpu_baseline(cfg, (preset, F, Hpx, Wpx, n_text, Kgen, C, groups))
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -21,11 +21,15 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import qwen2vl_fp32 as O  # noqa: E402
 
-OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "tiny_model.npz")
+# ``--tied`` writes tiny_tied_model.npz: the same miniature with tie_word_embeddings=True, the Qwen2-VL-2B arrangement
+# (lm_head IS the embedding table: BASELINE.json configs[0]/[1] are 2B models)
+TIED = "--tied" in sys.argv
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                   "tiny_tied_model.npz" if TIED else "tiny_model.npz")
 
 CFG = O.make_config(hidden=256, layers=2, heads=2, kv_heads=1, intermediate=512, vocab=1024,
                     vit_dim=320, vit_depth=2, vit_heads=4, vit_mlp=1280, head_dim=128,
-                    video_token_id=1001, image_token_id=1000, tie_embeddings=False)
+                    video_token_id=1001, image_token_id=1000, tie_embeddings=TIED)
 VISION_START, VISION_END = 1002, 1003
 
 
@@ -35,15 +39,17 @@ def hf_model():
         text_config=dict(hidden_size=256, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1,
                          intermediate_size=512, vocab_size=1024, rms_norm_eps=1e-6,
                          rope_parameters=dict(rope_theta=1e6, rope_type="default", mrope_section=[16, 24, 24]),
-                         max_position_embeddings=4096, tie_word_embeddings=False),
+                         max_position_embeddings=4096, tie_word_embeddings=TIED),
         vision_config=dict(depth=2, embed_dim=320, hidden_size=256, num_heads=4, mlp_ratio=4, patch_size=14,
                            spatial_merge_size=2, temporal_patch_size=2, in_channels=3),
         image_token_id=1000, video_token_id=1001, vision_start_token_id=1002, vision_end_token_id=1003,
-        tie_word_embeddings=False,
+        tie_word_embeddings=TIED,
     )
     cfg._attn_implementation = "eager"
-    torch.manual_seed(7)
+    torch.manual_seed(8 if TIED else 7)
     m = Qwen2VLForConditionalGeneration(cfg).float().eval()
+    if TIED:
+        assert m.lm_head.weight.data_ptr() == m.model.language_model.embed_tokens.weight.data_ptr(), "HF did not tie the weights"
     # HF init leaves biases at zero / norms at one; perturb so every term is exercised.
     g = torch.Generator().manual_seed(11)
     with torch.no_grad():
@@ -68,6 +74,8 @@ def to_ckpt_names(sd):
         if k2 == "visual.patch_embed.proj.weight":
             v = v.reshape(v.shape[0], -1)
         out[k2] = v.detach().clone()
+    if TIED:
+        out.pop("lm_head.weight", None)          # tied checkpoints carry the embedding table only
     return out
 
 

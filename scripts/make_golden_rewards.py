@@ -172,11 +172,26 @@ def main():
             mx = max(min(vp.VIDEO_MAX_PIXELS, tot / n * vp.FRAME_FACTOR), int(mn * 1.05))
             mx = min(ele.get("max_pixels", mx), mx)
             budget.append({"nframes": n, "ele": ele, "max_pixels": mx})
+    # ---- image inputs: the reference's own fetch_image (:99-142) on seeded images -> output size + sha256 of the RGB bytes
+    import hashlib
+    import numpy as np
+    from PIL import Image
+    images = []
+    for seed, (h, w), mode, ele in [(0, (100, 150), "RGB", {}), (1, (480, 640), "RGB", {}), (2, (37, 901), "RGB", {}),
+                                    (3, (64, 64), "RGBA", {}), (4, (200, 300), "L", {}), (5, (300, 200), "RGB", {"max_pixels": 50176}),
+                                    (6, (90, 120), "RGB", {"resized_height": 280, "resized_width": 420}),
+                                    (7, (1200, 1600), "RGB", {}), (8, (20, 30), "RGB", {"min_pixels": 3136})]:
+        ch = {"RGB": 3, "RGBA": 4, "L": 1}[mode]
+        arr = np.random.RandomState(seed).randint(0, 256, (h, w, ch), dtype=np.uint8)
+        img = Image.fromarray(arr.squeeze(), mode)
+        out = vp.fetch_image({"image": img, **ele})
+        images.append({"seed": seed, "h": h, "w": w, "mode": mode, "ele": ele, "size": list(out.size),
+                       "sha256": hashlib.sha256(np.asarray(out).tobytes()).hexdigest()})
     with open(os.path.join(OUT, "vision_tables.json"), "w") as f:
         json.dump({"constants": {k: getattr(vp, k) for k in ("VIDEO_MIN_PIXELS", "VIDEO_MAX_PIXELS", "FPS", "FPS_MIN_FRAMES",
                                                               "FPS_MAX_FRAMES", "FRAME_FACTOR", "VIDEO_TOTAL_PIXELS")},
-                   "smart_resize": resize, "smart_nframes": nfr, "budget": budget}, f, indent=0)
-    print(f"vision_tables.json: {len(resize)} resize rows, {len(nfr)} nframes rows, {len(budget)} budget rows")
+                   "smart_resize": resize, "smart_nframes": nfr, "budget": budget, "fetch_image": images}, f, indent=0)
+    print(f"vision_tables.json: {len(resize)} resize rows, {len(nfr)} nframes rows, {len(budget)} budget rows, {len(images)} image rows")
 
 
 if __name__ == "__main__":

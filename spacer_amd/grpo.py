@@ -38,7 +38,10 @@ class GRPOHyper:
     lr_scheduler_type: str = "cosine"  # (:23)
     total_steps: int = 1000
     warmup_steps: int = 0
-    grad_comm_bf16: bool = False      # gradient all-reduce on a bf16 wire (DeepSpeed bf16's communication dtype); fp32 when False
+    # gradient all-reduce on a bf16 wire: the communication dtype of the reference's DeepSpeed bf16 configuration
+    # (local_scripts/zero3.json:14-33 "bf16": {"enabled": "auto"}); fp32 values on the wire when False
+    grad_comm_bf16: bool = True
+    overlap_comm: bool = True         # zero3.json:26 "overlap_comm": true -- reduce layer ranges while the backward still runs
 
 
 # ------------------------------------------------------------------------------------- reward shaping (host)
@@ -112,6 +115,104 @@ def allreduce_flat_(flat: torch.Tensor, pg, bucket_elems: int = 1 << 28, wire_dt
     return flat
 
 
+class GradReducer:
+    """Bucketed data-parallel gradient exchange OVERLAPPED with the backward pass (the reference's contract:
+    local_scripts/zero3.json:26 ``overlap_comm``; DeepSpeed reduces gradient buckets as autograd produces them).
+
+    The flat gradient buffer is in layer order and the backward of the rank's LAST prompt group finalises it from the
+    end (lm_head, decoder layers 27..0, embedding, merger, vision blocks 31..0, patch embedding).  The engine reports each
+    finished parameter range (``ready``); ranges are merged into buckets of >= ``bucket_elems`` and every full bucket is
+    handed to RCCL at once on a side stream: the collective of layer i runs under the GEMMs of layers i-1, i-2, ...  On
+    MI355X the 8 GPUs are joined by point-to-point xGMI links, so a collective is per-link bound -- buckets are big
+    (>= 128 Mi elements: a 7B decoder layer, 233 M parameters, goes out as ONE message the moment its backward ends) and few.  ``finish`` drains what is left and makes the compute stream
+    wait for the side stream.  wire_dtype = bf16 halves the bytes: a bucket is rounded to bf16 on the compute stream, summed
+    by the collective and widened back into the fp32 buffer."""
+
+    def __init__(self, flat: torch.Tensor, specs, pg, *, wire_dtype: Optional[torch.dtype] = None, bucket_elems: int = 1 << 27):
+        self.flat, self.pg, self.wire_dtype, self.bucket_elems = flat, pg, wire_dtype, bucket_elems
+        self.ranges = {}
+        starts = [s.offset for s in specs] + [flat.numel()]
+        end = {s.name: starts[i + 1] for i, s in enumerate(specs)}       # up to the next tensor: alignment padding included
+        for s in specs:                                     # parameter-name prefix -> [lo, hi)
+            for pre in {s.name, s.name.rsplit(".", 1)[0] + "." if "." in s.name else s.name}:
+                lo, hi = self.ranges.get(pre, (s.offset, end[s.name]))
+                self.ranges[pre] = (min(lo, s.offset), max(hi, end[s.name]))
+        self.cuda = flat.is_cuda
+        self.side = torch.cuda.Stream(device=flat.device) if self.cuda else None
+        self.reset()
+
+    def reset(self) -> None:
+        self.pending: List[Tuple[int, int]] = []          # finished, not yet sent
+        self.inflight = []                                  # (lo, hi, wire or None, work)
+        self.sent = 0
+
+    def _send(self, lo: int, hi: int) -> None:
+        import torch.distributed as dist
+        view = self.flat[lo:hi]
+        wire = view.to(self.wire_dtype) if self.wire_dtype not in (None, view.dtype) else None
+        buf = wire if wire is not None else view
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(ev)
+                work = dist.all_reduce(buf, group=self.pg, async_op=True)
+        else:
+            work = dist.all_reduce(buf, group=self.pg, async_op=True)
+        self.inflight.append((lo, hi, wire, work))
+        self.sent += hi - lo
+
+    def _flush(self, force: bool) -> None:
+        """Merge adjacent finished ranges; send every merged run that reached the bucket size (all of them when forced)."""
+        self.pending.sort()
+        merged: List[List[int]] = []
+        for lo, hi in self.pending:
+            if merged and lo <= merged[-1][1]:
+                merged[-1][1] = max(merged[-1][1], hi)
+            else:
+                merged.append([lo, hi])
+        self.pending = []
+        for lo, hi in merged:
+            if force or hi - lo >= self.bucket_elems:
+                for a in range(lo, hi, 4 * self.bucket_elems):
+                    self._send(a, min(hi, a + 4 * self.bucket_elems))
+            else:
+                self.pending.append((lo, hi))
+
+    def ready(self, prefix: str) -> None:
+        """The gradient of every parameter whose name starts with ``prefix`` (a layer prefix such as "llm.12." or a full
+        name) is final on the current stream."""
+        self.pending.append(self.ranges[prefix])
+        self._flush(False)
+
+    def finish(self) -> None:
+        """Send what has not been sent (everything, if no ``ready`` call was made), wait, widen bf16 wires back."""
+        covered = sorted([(lo, hi) for lo, hi, _, _ in self.inflight] + self.pending)
+        pos, gaps = 0, []
+        for lo, hi in covered:
+            if lo > pos:
+                gaps.append((pos, lo))
+            pos = max(pos, hi)
+        if pos < self.flat.numel():
+            gaps.append((pos, self.flat.numel()))
+        self.pending += gaps
+        self._flush(True)
+        for lo, hi, wire, work in self.inflight:
+            if self.cuda:
+                with torch.cuda.stream(self.side):
+                    work.wait()
+                    if wire is not None:
+                        self.flat[lo:hi].copy_(wire)
+            else:
+                work.wait()
+                if wire is not None:
+                    self.flat[lo:hi].copy_(wire)
+        if self.cuda:
+            torch.cuda.current_stream().wait_stream(self.side)
+        assert self.sent == self.flat.numel(), (self.sent, self.flat.numel())
+        self.reset()
+
+
 # ------------------------------------------------------------------------------------- the step engine
 class GRPOEngine:
     """Owns policy + frozen reference weights, fp32 master / Adam state / gradients, and runs the step phases."""
@@ -133,15 +234,20 @@ class GRPOEngine:
         self.step_count = 0
         self.pg = process_group
         self._sumsq = torch.zeros(1, device=self.dev, dtype=F32)
+        self.reducer = None
+        if process_group is not None:
+            self.reducer = GradReducer(self.G.flat, self.G.specs, process_group,
+                                       wire_dtype=torch.bfloat16 if hyper.grad_comm_bf16 else None)
 
     # -------------------------------------------------------------- phases
     def rollout(self, prompts: List[PromptInput], sp: SamplingParams, stats: Optional[dict] = None) -> torch.Tensor:
         return self.roll.generate(prompts, self.h.num_generations, sp, stats=stats)
 
     def score_and_backward(self, prompt: PromptInput, completion_ids: torch.Tensor, advantages: torch.Tensor,
-                           grad_scale: float = 1.0, *, era_rule: bool = False) -> Dict[str, torch.Tensor]:
+                           grad_scale: float = 1.0, *, era_rule: bool = False, last_group: bool = False) -> Dict[str, torch.Tensor]:
         """One prompt group: masks, reference + policy log-probs, loss, backward into self.G.  ``advantages`` fp32 [K]
-        (device).  grad_scale folds 1/num_groups (gradient accumulation mean)."""
+        (device).  grad_scale folds 1/num_groups (gradient accumulation mean).  ``last_group`` = this is the rank's last
+        backward before the optimizer step: finished layer ranges go to the data-parallel reducer while it runs."""
         cfg = self.cfg
         mask, lengths = K.completion_mask(completion_ids, cfg.eos_token_id)
         with torch.no_grad():
@@ -151,11 +257,12 @@ class GRPOEngine:
             loss, kl, dlogp = K.grpo_loss(lp, ref_lp, advantages, mask, self.h.beta)
             if grad_scale != 1.0:
                 dlogp.mul_(grad_scale)
-            self.engine.backward_group(tape, dlogp, self.G)
+            hook = self.reducer.ready if (last_group and self.reducer is not None and self.h.overlap_comm) else None
+            self.engine.backward_group(tape, dlogp, self.G, on_ready=hook)
         return dict(loss=loss, kl=kl, logps=lp, ref_logps=ref_lp, mask=mask, lengths=lengths)
 
     def sft_forward_backward(self, ids: torch.Tensor, pix, grids, label_mask: torch.Tensor, *, grad_scale: float = 1.0,
-                             second_per_grid_ts=None) -> float:
+                             second_per_grid_ts=None, last_group: bool = False) -> float:
         """Supervised objective of open_r1/sft.py on the same kernels: mean cross-entropy of ids[1:] over the positions whose
         label is kept (``label_mask`` bool/0-1 [S], True where labels != -100: the reference masks pad and visual tokens,
         sft.py:170-181), gradients accumulated into G scaled by grad_scale.  Returns the loss."""
@@ -164,14 +271,16 @@ class GRPOEngine:
         m = label_mask.reshape(-1)[1:].to(self.dev, torch.float32)
         n = float(m.sum().clamp_min(1.0))
         loss = float(-(logp * m).sum() / n)
-        self.engine.backward_group(tape, (-(m / n) * grad_scale).view(1, -1), self.G)
+        hook = self.reducer.ready if (last_group and self.reducer is not None and self.h.overlap_comm) else None
+        self.engine.backward_group(tape, (-(m / n) * grad_scale).view(1, -1), self.G, on_ready=hook)
         return loss
 
     def reduce_gradients(self) -> None:
-        """Data-parallel exchange: SUM all-reduce of the flat fp32 gradient over RCCL in large buckets (xGMI is
-        per-link bound: few, big collectives).  The mean is folded into the optimizer's grad_scale."""
-        if self.pg is not None:
-            allreduce_flat_(self.G.flat, self.pg, wire_dtype=torch.bfloat16 if self.h.grad_comm_bf16 else None)
+        """Data-parallel exchange: SUM all-reduce of the flat gradient over RCCL in large buckets (xGMI is per-link
+        bound: few, big collectives).  Ranges already handed over during the last backward (``last_group=True``) are only
+        waited for; the rest is sent now.  The mean is folded into the optimizer's grad_scale."""
+        if self.reducer is not None:
+            self.reducer.finish()
 
     def optimizer_step(self, world_size: int = 1) -> float:
         """Global-norm clip (max_grad_norm) + AdamW on fp32 master, bf16 policy refreshed in the same kernel."""

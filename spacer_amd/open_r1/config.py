@@ -28,6 +28,11 @@ class GRPOScriptArguments:                     # SG-RLVR.py:27-56
     temporal: Optional[bool] = False
     len_control: Optional[bool] = True
     map_annotation: str = "annotation/cognitive_map.jsonl"      # path the reference hard-codes (:291)
+    # M-RoPE text position after a vision span: True = the rule of the transformers 4.49-dev build the reference pins
+    # (r1-v/setup.py:64): max(all vision positions) + 1; False = transformers 5.x: start + max(h, w) / merge.  They differ
+    # when the temporal extent exceeds the spatial one (Qwen2.5-VL videos: 16 frames, tokens_per_second 2 -> t up to s + 14
+    # against 11..14 merged rows / columns), so checkpoints must be trained with the rule their consumers use.
+    mrope_era_rule: Optional[bool] = True
 
 
 @dataclass

@@ -90,8 +90,11 @@ def train(model_path: str, rows: List[Dict[str, Any]], processor, *, output_dir:
     load_state_dict(params, read_checkpoint(model_path))
     world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
     rank = torch.distributed.get_rank(process_group) if process_group is not None else 0
-    mine = rows[rank::world]
-    steps = max(1, len(mine) * epochs // grad_accum)
+    # equal-length, padded shards (DistributedSampler semantics, the GRPO trainer's shard_indices): every rank takes the
+    # same number of optimizer steps and derives the same linear schedule from the GLOBAL row count
+    from .trainer.SG_RLVR_trainer import shard_indices
+    mine = [rows[i] for i in shard_indices(len(rows), rank, world, seed=0, epoch=0, shuffle=False)]
+    steps = max(1, (len(mine) // grad_accum) * epochs)
     hyper = GRPOHyper(learning_rate=learning_rate, weight_decay=weight_decay, max_grad_norm=max_grad_norm, total_steps=steps,
                       lr_scheduler_type="linear")
     eng = GRPOEngine(cfg, params, hyper, ref=params, process_group=process_group)     # no frozen reference model in SFT
@@ -102,7 +105,8 @@ def train(model_path: str, rows: List[Dict[str, Any]], processor, *, output_dir:
             for j in range(grad_accum):
                 ids, pix, grids, keep, sec = collate(make_conversation(mine[s + j]) if "messages" not in mine[s + j] else mine[s + j],
                                                      processor, cfg, device)
-                loss += eng.sft_forward_backward(ids, pix, grids, keep, grad_scale=1.0 / grad_accum, second_per_grid_ts=sec) / grad_accum
+                loss += eng.sft_forward_backward(ids, pix, grids, keep, grad_scale=1.0 / grad_accum, second_per_grid_ts=sec,
+                                                 last_group=j == grad_accum - 1) / grad_accum
             eng.reduce_gradients()
             lr = eng.optimizer_step(world)
             step += 1
@@ -133,7 +137,9 @@ def main(argv=None) -> None:
         rows = json.load(f) if a.dataset_name.endswith(".json") else [json.loads(l) for l in f if l.strip()]
     pg = None
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        torch.distributed.init_process_group("nccl")
+        dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(dev)                       # before the RCCL communicator is created
+        torch.distributed.init_process_group("nccl", device_id=dev)
         pg = torch.distributed.group.WORLD
     train(a.model_name_or_path, rows, processor, output_dir=a.output_dir, learning_rate=a.learning_rate, epochs=a.num_train_epochs,
           grad_accum=a.gradient_accumulation_steps, max_grad_norm=a.max_grad_norm, weight_decay=a.weight_decay, process_group=pg)

@@ -194,6 +194,7 @@ class SGRLVRTrainer:
         self.temporal = bool(self.script_args.temporal)
         self.len_control = bool(self.script_args.len_control)
         self.beta = args.beta
+        self.era_rule = bool(getattr(self.script_args, "mrope_era_rule", True))
         self.train_dataset, self.eval_dataset = train_dataset, eval_dataset
         n_rows = len(train_dataset) if train_dataset is not None else 0
         per_step = max(1, self.world * args.per_device_train_batch_size * args.gradient_accumulation_steps)
@@ -281,7 +282,7 @@ class SGRLVRTrainer:
         not a second decode loop.  Returns per sample dict(prompt, completion_ids [G, C], shuffled_ids [G/2, C] or None)."""
         G = self.num_generations
         sp = SamplingParams(max_new_tokens=self.max_completion_length, top_k=self.args.top_k, top_p=0.95, temperature=1.0,
-                            seed=self._sample_seed + 7919 * self.global_step)
+                            seed=self._sample_seed + 7919 * self.global_step, era_rule=self.era_rule)
         prompts, slots = [], []
         for prep in preps:
             slots.append((len(prompts), prep["sproc"] is not None))
@@ -296,7 +297,7 @@ class SGRLVRTrainer:
         return out
 
     def compute_loss(self, model, inputs, return_outputs=False, num_items_in_batch=None, *, grad_scale: float = 1.0,
-                     prepared: Optional[dict] = None, rolled: Optional[dict] = None):
+                     prepared: Optional[dict] = None, rolled: Optional[dict] = None, last_micro_batch: bool = False):
         if return_outputs:
             raise ValueError("The GRPOTrainer does not support returning outputs")
         eng, G = self.engine, self.num_generations
@@ -318,7 +319,9 @@ class SGRLVRTrainer:
         lengths = torch.where(is_eos.any(1), is_eos.int().argmax(1) + 1, torch.full((G,), completion_ids.shape[1]))
         rewards = length_bonus(rewards, rewards_per_func, lengths, self.len_control)
         adv, std = group_advantages(rewards, G)
-        res = eng.score_and_backward(prompt, completion_ids, adv.to(self.device), grad_scale=grad_scale)
+        # last_micro_batch: finished layer ranges of this backward go to the data-parallel reducer while it still runs
+        res = eng.score_and_backward(prompt, completion_ids, adv.to(self.device), grad_scale=grad_scale, era_rule=self.era_rule,
+                                     last_group=last_micro_batch)
 
         packed = pack_metrics(lengths, rewards_per_func, rewards, temporal_reward, std, float(res["kl"]))
         if self.pg is not None:
@@ -350,8 +353,13 @@ class SGRLVRTrainer:
             self._load_checkpoint(resume_from_checkpoint)
         n_rows = len(self.train_dataset)
         acc = max(1, a.gradient_accumulation_steps * a.per_device_train_batch_size)
-        epoch, t_last = 0, time.time()
+        t_last = time.time()
         pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="spacer-prefetch")
+        # resume (HF Trainer semantics): the optimizer steps already taken are skipped, not replayed -- epoch and position in
+        # the epoch's permutation follow from global_step
+        per_rank = (n_rows + self.world - 1) // self.world
+        steps_per_epoch = max(1, (per_rank - acc) // acc + 1) if per_rank >= acc else 1
+        epoch, skip = divmod(self.global_step, steps_per_epoch)
 
         def prep_seed(ep: int, pos: int) -> int:
             return self._sample_seed + 104729 * (ep * 1000003 + pos)
@@ -362,6 +370,7 @@ class SGRLVRTrainer:
             if not starts:
                 raise ValueError(f"{len(idx)} samples per rank cannot fill one optimizer step of {acc} micro-batches "
                                  "(per_device_train_batch_size x gradient_accumulation_steps)")
+            starts, skip = starts[skip:], 0
 
             def submit(s0: int):
                 return [pool.submit(self._prepare, [self.train_dataset[idx[s0 + j]]], prep_seed(epoch, s0 + j)) for j in range(acc)]
@@ -377,7 +386,7 @@ class SGRLVRTrainer:
                 loss = 0.0
                 for j in range(acc):
                     loss += float(self.compute_loss(None, [self.train_dataset[idx[s + j]]], grad_scale=1.0 / acc, prepared=preps[j],
-                                                    rolled=rolled[j])) / acc
+                                                    rolled=rolled[j], last_micro_batch=j == acc - 1)) / acc
                     rolled[j] = None
                 self.engine.reduce_gradients()
                 lr = self.engine.optimizer_step(self.world)
@@ -405,6 +414,12 @@ class SGRLVRTrainer:
         write_checkpoint(output_dir, self.engine.policy, source_dir=self.model_id if os.path.isdir(str(self.model_id)) else None,
                          processor=self.processing_class,
                          extra_state={"global_step": self.global_step, "model_id": self.model_id, "notes": self._log_lines})
+        if not self.args.save_only_model:
+            # --save_only_model false: what HF Trainer adds for an exact resume -- fp32 master weights (the sub-bf16 part of
+            # the accumulated lr 1e-6 updates) and the Adam moments
+            e = self.engine
+            torch.save({"master": e.master.flat.cpu(), "m": e.m.cpu(), "v": e.v.cpu(), "step_count": e.step_count},
+                       os.path.join(output_dir, "optimizer.pt"))
 
     def _load_checkpoint(self, path: str) -> None:
         load_state_dict(self.engine.policy, read_checkpoint(path))
@@ -414,3 +429,11 @@ class SGRLVRTrainer:
             with open(st) as f:
                 self.global_step = int(json.load(f).get("global_step", 0))
             self.engine.step_count = self.global_step
+        opt = os.path.join(path, "optimizer.pt")
+        if os.path.exists(opt):
+            st = torch.load(opt, map_location="cpu")
+            e = self.engine
+            e.master.flat.copy_(st["master"]); e.m.copy_(st["m"]); e.v.copy_(st["v"])
+            e.step_count = int(st["step_count"])
+        self.engine.engine.invalidate_cache()
+        self.engine.roll.invalidate()

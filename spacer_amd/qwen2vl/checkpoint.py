@@ -119,10 +119,35 @@ def write_checkpoint(output_dir: str, params: FlatParams, *, source_dir: Optiona
             json.dump(extra_state, f)
 
 
+def _weight_files(path: str):
+    """The weight shards of an HF-layout directory: the files the ``*.index.json`` names when there is one, else
+    ``model*.safetensors``, else ``pytorch_model*.bin`` -- safetensors preferred when both exist; ``training_args.bin``,
+    ``optimizer.pt``, ``scheduler.pt``, ``rng_state*.pth`` (HF Trainer outputs) are never weight files."""
+    names = sorted(os.listdir(path))
+    for index in ("model.safetensors.index.json", "pytorch_model.bin.index.json"):
+        if index in names:
+            with open(os.path.join(path, index)) as f:
+                return sorted({os.path.join(path, v) for v in json.load(f)["weight_map"].values()})
+    st = [n for n in names if n.endswith(".safetensors") and (n.startswith("model") or n == "adapter_model.safetensors")]
+    if not st:
+        st = [n for n in names if n.endswith(".safetensors")]
+    if st:
+        return [os.path.join(path, n) for n in st]
+    return [os.path.join(path, n) for n in names if n.startswith("pytorch_model") and n.endswith(".bin")]
+
+
 def read_checkpoint(path: str) -> Dict[str, torch.Tensor]:
-    """A directory (or file) of safetensors / .bin shards in the original names (transformers 5.x prefixes accepted)."""
-    files = [path] if os.path.isfile(path) else sorted(os.path.join(path, f) for f in os.listdir(path)
-                                                       if f.endswith(".safetensors") or f.endswith(".bin"))
+    """A directory (or file) of safetensors / .bin shards in the original names (transformers 5.x prefixes accepted).  A hub id
+    such as the launch script's ``Qwen/Qwen2.5-VL-7B-Instruct`` is resolved through the local huggingface_hub cache."""
+    if not os.path.exists(path):
+        try:
+            from huggingface_hub import snapshot_download
+            path = snapshot_download(path, local_files_only=bool(os.environ.get("HF_HUB_OFFLINE", "")),
+                                     allow_patterns=["*.safetensors", "*.json", "*.bin"])
+        except Exception as e:           # noqa: BLE001
+            raise FileNotFoundError(f"{path!r} is neither a local checkpoint directory nor a hub snapshot that could be "
+                                    f"resolved ({type(e).__name__}: {e})") from e
+    files = [path] if os.path.isfile(path) else _weight_files(path)
     if not files:
         raise FileNotFoundError(f"no checkpoint shards under {path}")
     sd: Dict[str, torch.Tensor] = {}
@@ -131,7 +156,7 @@ def read_checkpoint(path: str) -> Dict[str, torch.Tensor]:
             from safetensors.torch import load_file
             part = load_file(f)
         else:
-            part = torch.load(f, map_location="cpu")
+            part = torch.load(f, map_location="cpu", weights_only=True)
         for k, v in part.items():
             k = k.replace("model.language_model.", "model.").replace("model.visual.", "visual.")
             sd[k] = v

@@ -86,6 +86,11 @@ TINY = Qwen2VLConfig(hidden=256, layers=2, heads=2, kv_heads=1, intermediate=512
                      vit_depth=2, vit_heads=4, vit_mlp=1280, image_token_id=1000, video_token_id=1001,
                      vision_start_id=1002, vision_end_id=1003, eos_token_id=7, pad_token_id=0)
 
+# the same miniature with lm_head tied to the embedding table (the Qwen2-VL-2B arrangement); fixture tiny_tied_model.npz
+TINY_TIED = Qwen2VLConfig(hidden=256, layers=2, heads=2, kv_heads=1, intermediate=512, vocab=1024, vit_dim=320,
+                          vit_depth=2, vit_heads=4, vit_mlp=1280, image_token_id=1000, video_token_id=1001,
+                          vision_start_id=1002, vision_end_id=1003, eos_token_id=7, pad_token_id=0, tie_embeddings=True)
+
 # Qwen2.5-VL in miniature: 4 vision blocks (1 and 3 full attention), 56-px windows = 2x2 merge units, ragged SwiGLU width
 TINY25 = Qwen2VLConfig(hidden=256, layers=2, heads=2, kv_heads=1, intermediate=512, vocab=1024, vit_dim=320,
                        vit_depth=4, vit_heads=4, vit_mlp=420, image_token_id=1000, video_token_id=1001,
@@ -93,7 +98,7 @@ TINY25 = Qwen2VLConfig(hidden=256, layers=2, heads=2, kv_heads=1, intermediate=5
                        vit_kind="qwen2_5", vit_window=56, vit_fullatt=(1, 3))
 
 PRESETS = {"Qwen2.5-VL-7B": QWEN2_5_VL_7B, "Qwen2.5-VL-3B": QWEN2_5_VL_3B, "Qwen2-VL-7B": QWEN2_VL_7B, "Qwen2-VL-2B": QWEN2_VL_2B,
-           "tiny25": TINY25, "tiny": TINY}
+           "tiny25": TINY25, "tiny_tied": TINY_TIED, "tiny": TINY}
 
 
 def preset_for(model_id: str) -> Qwen2VLConfig:

@@ -102,10 +102,12 @@ class Qwen2VLEngine:
                         segs=segs, max_q=max_q)
         return out
 
-    def vit_backward(self, tape: dict, d_out: torch.Tensor, G: FlatParams) -> None:
-        """d_out bf16 [Nv, hidden] = gradient of the merged video embeds; accumulates into G (fp32)."""
+    def vit_backward(self, tape: dict, d_out: torch.Tensor, G: FlatParams, on_ready=None) -> None:
+        """d_out bf16 [Nv, hidden] = gradient of the merged video embeds; accumulates into G (fp32).  ``on_ready(prefix)``
+        is called when the gradients of a parameter group are final (data-parallel overlap, grpo.GradReducer)."""
+        ready = on_ready or (lambda prefix: None)
         if self.cfg.vit_kind == "qwen2_5":
-            return self._vit25_backward(tape, d_out, G)
+            return self._vit25_backward(tape, d_out, G, ready)
         cfg, W = self.cfg, self.W
         D, Hh, hd = cfg.vit_dim, cfg.vit_heads, cfg.vit_head_dim
         Np = tape["pix"].shape[0]
@@ -120,6 +122,7 @@ class Qwen2VLEngine:
         dx = self._empty(Np, D)
         K.layernorm_bwd(tape["x_last"], W["merger.ln_w"], d_hm4.view(Np, D), tape["mean"], tape["rstd"], dx,
                         G["merger.ln_w"], G["merger.ln_b"], accumulate=False)
+        ready("merger.")
         for i in reversed(range(cfg.vit_depth)):
             p = f"vit.{i}."
             t = tape["blocks"][i]
@@ -144,7 +147,9 @@ class Qwen2VLEngine:
             self._dw(G[p + "qkv_w"], d_qkv, t["h"]); K.bias_grad_(d_qkv, G[p + "qkv_b"])
             K.layernorm_bwd(t["x_in"], W[p + "n1_w"], d_h, t["mean1"], t["rstd1"], dx, G[p + "n1_w"], G[p + "n1_b"])
             tape["blocks"][i] = None
+            ready(p)
         self._dw(G["vit.patch_w"], K.cast_bf16(dx), tape["pix"])
+        ready("vit.patch_w")
 
     # ------------------------------------------------------------------ Qwen2.5-VL vision tower
     def _vit25_forward(self, pix: torch.Tensor, grids, tape: Optional[dict] = None):
@@ -198,7 +203,7 @@ class Qwen2VLEngine:
                         unit_perm=unit_dev.int())
         return out
 
-    def _vit25_backward(self, tape: dict, d_out: torch.Tensor, G: FlatParams) -> None:
+    def _vit25_backward(self, tape: dict, d_out: torch.Tensor, G: FlatParams, ready) -> None:
         cfg, W = self.cfg, self.W
         D, Hh, hd = cfg.vit_dim, cfg.vit_heads, cfg.vit_head_dim
         Np = tape["pix"].shape[0]
@@ -212,6 +217,7 @@ class Qwen2VLEngine:
         self._dw(G["merger.m0_w"], d_m1, tape["hm4"]); K.bias_grad_(d_m1, G["merger.m0_b"])
         dx = self._empty(Np, D)
         K.rmsnorm_bwd(tape["x_last"], W["merger.ln_w"], d_hm4.view(Np, D), tape["rstd"], dx, G["merger.ln_w"], accumulate=False)
+        ready("merger.")
         for i in reversed(range(cfg.vit_depth)):
             p = f"vit.{i}."
             t = tape["blocks"][i]
@@ -236,7 +242,9 @@ class Qwen2VLEngine:
             self._dw(G[p + "qkv_w"], d_qkv, t["h"]); K.bias_grad_(d_qkv, G[p + "qkv_b"])
             K.rmsnorm_bwd(t["x_in"], W[p + "n1_w"], d_h, t["rstd1"], dx, G[p + "n1_w"])
             tape["blocks"][i] = None
+            ready(p)
         self._dw(G["vit.patch_w"], K.cast_bf16(dx), tape["pix"])
+        ready("vit.patch_w")
 
     # ================================================================== language model
     def llm_forward(self, x: torch.Tensor, cos, sin, segs, max_q: int, *, tape: Optional[list] = None, kv_sink=None):
@@ -266,9 +274,10 @@ class Qwen2VLEngine:
             x = x_out
         return x
 
-    def llm_backward(self, tape: list, dx: torch.Tensor, G: FlatParams, cos, sin, segs, max_q: int) -> torch.Tensor:
+    def llm_backward(self, tape: list, dx: torch.Tensor, G: FlatParams, cos, sin, segs, max_q: int, on_ready=None) -> torch.Tensor:
         """dx fp32 [T, hidden] = grad of the pre-final-norm stream (updated in place); returns d(embeddings)."""
         cfg, W = self.cfg, self.W
+        ready = on_ready or (lambda prefix: None)
         Hq, Hkv, D = cfg.heads, cfg.kv_heads, cfg.head_dim
         T = dx.shape[0]
         qd, kd = Hq * D, Hkv * D
@@ -297,6 +306,7 @@ class Qwen2VLEngine:
             self._dw(G[p + "qkv_w"], d_qkv, t["h"]); K.bias_grad_(d_qkv, G[p + "qkv_b"])
             K.rmsnorm_bwd(t["x_in"], W[p + "ln1_w"], d_h, t["rstd1"], dx, G[p + "ln1_w"])
             tape[i] = None
+            ready(p)
         return dx
 
     # ================================================================== embeddings
@@ -382,9 +392,12 @@ class Qwen2VLEngine:
                         has_video=video is not None)
         return logp
 
-    def backward_group(self, tape: dict, dlogp: torch.Tensor, G: FlatParams) -> None:
-        """Back-propagates d loss / d logp (fp32 [K, C]) through lm_head, the LLM, the embeddings and the ViT."""
+    def backward_group(self, tape: dict, dlogp: torch.Tensor, G: FlatParams, on_ready=None) -> None:
+        """Back-propagates d loss / d logp (fp32 [K, C]) through lm_head, the LLM, the embeddings and the ViT.
+        ``on_ready(prefix)``: see vit_backward."""
         cfg, W = self.cfg, self.W
+        ready = on_ready or (lambda prefix: None)
+        tied = cfg.tie_embeddings
         T, H = tape["T"], cfg.hidden
         dlogits = K.logprob_bwd(tape["logits"], tape["targets"], tape["lse"], dlogp.reshape(-1).contiguous())
         tape["logits"] = None
@@ -396,11 +409,15 @@ class Qwen2VLEngine:
         d_hn = K.cast_bf16(d_hn32)
         dx = d_hn32                                                     # reuse the buffer for the stream gradient
         K.rmsnorm_bwd(tape["x_final"], W["llm.norm_w"], d_hn, tape["rstd_f"], dx, G["llm.norm_w"], accumulate=False)
-        dx = self.llm_backward(tape["llm"], dx, G, tape["cos"], tape["sin"], tape["segs"], tape["max_q"])
+        ready("llm.norm_w")
+        if not tied:
+            ready("llm.lm_head")
+        dx = self.llm_backward(tape["llm"], dx, G, tape["cos"], tape["sin"], tape["segs"], tape["max_q"], on_ready)
         d_video = None
         if tape["has_video"]:
             nv = int((tape["vrow"] >= 0).sum())
             d_video = self._zeros(nv, H)
         K.embed_bwd(tape["ids"], tape["vrow"], dx, G["llm.embed"], d_video)
+        ready("llm.embed")
         if d_video is not None:
-            self.vit_backward(tape["vit"], K.cast_bf16(d_video), G)
+            self.vit_backward(tape["vit"], K.cast_bf16(d_video), G, on_ready)

@@ -19,8 +19,21 @@ class FakeProcessor:
                  add_special_tokens=False):
         assert len(text) == 1
         marker = "<|vision_start|><|video_pad|><|vision_end|>"
+        imarker = "<|vision_start|><|image_pad|><|vision_end|>"
         out = {}
         ids = []
+        if imarker in text[0]:            # an image row: one still frame, duplicated over the temporal patch like HF's image processor
+            import numpy as np
+            head, tail = text[0].split(imarker)
+            frame = torch.from_numpy(np.asarray(images[0]).copy()).permute(2, 0, 1).unsqueeze(0)
+            rows, grid = O.patchify_frames(frame, self.ocfg)
+            nv = grid[0] * grid[1] * grid[2] // (self.cfg.merge ** 2)
+            ids = [self._tok(w) for w in head.split()] + [self.cfg.vision_start_id] + [self.cfg.image_token_id] * nv \
+                + [self.cfg.vision_end_id] + [self._tok(w) for w in tail.split()]
+            out["pixel_values"], out["image_grid_thw"] = rows, torch.tensor([list(grid)])
+            out["input_ids"] = torch.tensor([ids])
+            out["attention_mask"] = torch.ones_like(out["input_ids"])
+            return out
         parts = text[0].split(marker)
         for i, part in enumerate(parts):
             ids += [self._tok(w) for w in part.split()]

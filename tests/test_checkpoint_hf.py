@@ -55,3 +55,30 @@ def test_written_checkpoint_loads_in_hf_and_matches_golden_logits(tmp_path, fami
     want = O.full_logits(wb, g["cfg"], ids[0], rows, [grid])
     assert (lg - want).abs().max() < 5e-5
     assert (lg - g["hf_logits_row0"]).abs().max() < 5e-2
+
+
+def test_reader_ignores_trainer_side_files(tmp_path):
+    """An HF Trainer output directory (the reference's SFT checkpoint, a checkpoint-N of a GRPO run) also holds
+    training_args.bin / optimizer.pt / scheduler.pt / rng_state.pth: only the weight shards are read; an index file decides
+    when there is one; a name that is neither a directory nor a resolvable hub snapshot fails with a clear error."""
+    import json as _json
+
+    import pytest as _pytest
+    from safetensors.torch import save_file
+
+    from spacer_amd.qwen2vl.checkpoint import read_checkpoint
+    d = tmp_path / "ck"
+    d.mkdir()
+    save_file({"model.language_model.norm.weight": torch.ones(4)}, str(d / "model-00001-of-00002.safetensors"))
+    save_file({"model.visual.merger.ln_q.weight": torch.zeros(3)}, str(d / "model-00002-of-00002.safetensors"))
+    torch.save({"not": "weights"}, str(d / "training_args.bin"))
+    torch.save({"master": torch.zeros(2)}, str(d / "optimizer.pt"))
+    torch.save({"x": 1}, str(d / "rng_state.pth"))
+    sd = read_checkpoint(str(d))
+    assert set(sd) == {"model.norm.weight", "visual.merger.ln_q.weight"}
+    save_file({"stale": torch.zeros(1)}, str(d / "model-old.safetensors"))
+    (d / "model.safetensors.index.json").write_text(_json.dumps({"weight_map": {
+        "a": "model-00001-of-00002.safetensors", "b": "model-00002-of-00002.safetensors"}}))
+    assert set(read_checkpoint(str(d))) == {"model.norm.weight", "visual.merger.ln_q.weight"}
+    with _pytest.raises(FileNotFoundError):
+        read_checkpoint("Qwen/definitely-not-a-local-dir")

@@ -1,8 +1,12 @@
-"""GPU parity of the whole forward / backward path against the fp32 CPU oracle on the golden tiny model
-(real head sizes: LLM 128, ViT 80).  Both sides use the SAME bf16-rounded weights; the oracle computes in fp32,
-the engine in bf16 activations + fp32 residual stream, so the tolerances below are bf16-activation budgets:
-  ViT output 3e-2 abs, per-token log-probs 1e-3 abs on the 2-layer model (north_star budget), parameter
-  gradients 4% of each tensor's max + small abs floor."""
+"""GPU parity of the whole forward / backward path against the fp32 CPU oracle on the golden tiny models
+(real head sizes: LLM 128, ViT 80; "tiny" = untied lm_head as Qwen2-VL-7B, "tiny_tied" = lm_head tied to the embedding
+table as Qwen2-VL-2B).  Both sides use the SAME bf16-rounded weights; the oracle computes in fp32, the engine with bf16
+MFMA operands, fp32 accumulation, an fp32 residual stream and fp32 logits.  Tolerances:
+  * per-token log-probs (SG_RLVR_trainer.py:353-366): the north-star's 1e-3 is below what ANY bf16-operand pipeline can
+    reach (per-operator budget from oracle/qwen2vl_engine_emul.py -- rms 0.8e-3 / max 2.5e-3 on this
+    2-layer model, rms 9e-3 at 28 layers).  What is asserted: the engine sits AT that floor -- rms error over 256 tokens
+    <= 1.3x the CPU emulation's rms error, max error <= 5e-3 -- and is far inside the reference's own bf16-eager error;
+  * ViT output 3e-2 abs; parameter gradients 4 % of each tensor's max + small abs floor."""
 import pytest
 import torch
 
@@ -11,14 +15,19 @@ pytestmark = pytest.mark.gpu
 from golden_util import load_tiny                      # noqa: E402
 from oracle import qwen2vl_fp32 as O                   # noqa: E402
 from spacer_amd import kernels as K                    # noqa: E402
-from spacer_amd.qwen2vl.config import TINY             # noqa: E402
+from spacer_amd.qwen2vl.config import TINY as TINY_UNTIED, TINY_TIED    # noqa: E402
 from spacer_amd.qwen2vl.engine import Qwen2VLEngine    # noqa: E402
 from spacer_amd.qwen2vl.weights import FlatParams, export_state_dict, load_state_dict  # noqa: E402
 
 
-@pytest.fixture(scope="module")
-def setup(dev):
-    g = load_tiny()
+TINY = TINY_UNTIED     # shapes shared by both fixtures (they differ in tie_embeddings only)
+
+
+@pytest.fixture(scope="module", params=["tiny", "tiny_tied"])
+def setup(dev, request):
+    tied = request.param == "tiny_tied"
+    g = load_tiny("tiny_tied_model.npz" if tied else "tiny_model.npz")
+    TINY = TINY_TIED if tied else TINY_UNTIED
     params = FlatParams.empty(TINY, dev)
     load_state_dict(params, g["w"])
     wb = {k: v.float().cpu() for k, v in export_state_dict(params).items()}      # bf16-rounded weights, fp32 container
@@ -27,11 +36,11 @@ def setup(dev):
     pix, grid = K.patchify(g["frames"].to(dev), kpad=TINY.patch_kpad)
     rows, grid_o = O.patchify_frames(g["frames"], g["cfg"])
     assert tuple(grid) == tuple(grid_o) == g["grid"]
-    return dict(g=g, params=params, wb=wb, eng=eng, pix=pix, rows=rows.to(torch.bfloat16).float(), grid=tuple(grid))
+    return dict(g=g, params=params, wb=wb, eng=eng, pix=pix, rows=rows.to(torch.bfloat16).float(), grid=tuple(grid), cfg=TINY)
 
 
 def test_config_matches_fixture(setup):
-    a, b = TINY.as_oracle_dict(), setup["g"]["cfg"]
+    a, b = setup["cfg"].as_oracle_dict(), setup["g"]["cfg"]
     for k in b:
         assert a[k] == b[k] or tuple(a[k]) == tuple(b[k]), k
 
@@ -50,7 +59,7 @@ def test_logps_match_oracle(setup):
     lp = s["eng"].score_group(g["prompt"].to(dev), g["completions"].to(dev), s["pix"], [s["grid"]])
     want = O.completion_logps(s["wb"], g["cfg"], g["prompt"], g["completions"], s["rows"], [s["grid"]])
     err = (lp.cpu() - want).abs().max()
-    assert err < 8e-3, f"log-prob max abs err {err}"   # bf16 activations; see DESIGN.md "numerics"
+    assert err < 5e-3, f"log-prob max abs err {err}"   # bf16-operand floor of this model: DESIGN.md section 4
     # the reference's own bf16 eager numerics (every op output rounded to bf16, bf16 residual stream and logits),
     # emulated on the CPU: this engine must be at least as close to the fp32 truth as the reference path is
     from oracle import qwen2vl_bf16_emul as E
@@ -59,11 +68,31 @@ def test_logps_match_oracle(setup):
     err_pair = (lp.cpu() - ref_bf16).abs().max()
     print(f"max |logp - fp32 oracle|: engine {float(err):.2e}, reference-style bf16 eager {float(err_ref):.2e}; "
           f"engine vs bf16 eager {float(err_pair):.2e}")
-    assert err <= err_ref + 1e-3
+    assert err <= 0.5 * err_ref
     # text-only prompt (no video) goes through the same path
     lp2 = s["eng"].score_group(g["prompt"][-9:].to(dev), g["completions"].to(dev), None, None)
     want2 = O.completion_logps(s["wb"], g["cfg"], g["prompt"][-9:], g["completions"], None, None)
-    assert (lp2.cpu() - want2).abs().max() < 8e-3
+    assert (lp2.cpu() - want2).abs().max() < 5e-3
+
+
+def test_logps_sit_at_the_bf16_operand_floor(setup):
+    """256 completion tokens (8 rollouts x 32): the engine's error against the fp32 oracle vs the error of the CPU emulation
+    of its own rounding points (oracle/qwen2vl_engine_emul.py).  A kernel that loses more than its operand rounding
+    (a bf16 accumulator, a bf16 residual, a low-precision exp) shows up as rms(engine) > rms(emulation)."""
+    from oracle import qwen2vl_engine_emul as E
+    s, g = setup, setup["g"]
+    dev = s["pix"].device
+    comps = torch.randint(5, 990, (8, 32), generator=torch.Generator().manual_seed(21))
+    want = O.completion_logps(s["wb"], g["cfg"], g["prompt"], comps, s["rows"], [s["grid"]])
+    emu = E.completion_logps(s["wb"], g["cfg"], g["prompt"], comps, s["rows"], [s["grid"]])
+    lp = s["eng"].score_group(g["prompt"].to(dev), comps.to(dev), s["pix"], [s["grid"]]).cpu()
+    rms = lambda d: float(d.pow(2).mean().sqrt())                                         # noqa: E731
+    e_eng, e_emu = lp - want, emu - want
+    print(f"log-prob error vs fp32 oracle over {comps.numel()} tokens: engine rms {rms(e_eng):.2e} max {float(e_eng.abs().max()):.2e}; "
+          f"emulated rounding points rms {rms(e_emu):.2e} max {float(e_emu.abs().max()):.2e}; engine vs emulation rms {rms(lp - emu):.2e}")
+    assert rms(e_eng) <= 1.3 * rms(e_emu) + 1e-4
+    assert float(e_eng.abs().max()) <= 5e-3
+    assert rms(e_eng) <= 1.5e-3
 
 
 def test_backward_matches_oracle_autograd(setup):
@@ -83,6 +112,7 @@ def test_backward_matches_oracle_autograd(setup):
     eng.backward_group(tape, dlogp.to(dev), G)
     got = export_state_dict(G)
     got["visual.patch_embed.proj.weight"] = got["visual.patch_embed.proj.weight"].reshape(TINY.vit_dim, -1)
+    assert ("lm_head.weight" in wr) != s["cfg"].tie_embeddings       # tied: the table's gradient sums both of its uses
     worst = []
     for name, ref in wr.items():
         gr = ref.grad if ref.grad is not None else torch.zeros_like(ref)
@@ -115,7 +145,7 @@ def test_sft_loss_and_gradients_match_oracle(setup):
     m = keep[1:].float()
     loss_o = -(lp * m).sum() / m.sum()
     loss_o.backward()
-    ge = GRPOEngine(TINY, s["params"], GRPOHyper(), ref=s["params"])
+    ge = GRPOEngine(s["cfg"], s["params"], GRPOHyper(), ref=s["params"])
     loss = ge.sft_forward_backward(ids.to(dev), s["pix"], [s["grid"]], keep)
     assert abs(loss - float(loss_o.detach())) < 5e-3, (loss, float(loss_o.detach()))
     got = export_state_dict(ge.G)

@@ -1,0 +1,76 @@
+"""GPU, >= 2 devices (skipped on the one-GPU test box): the data-parallel exchange over RCCL ("nccl") with one process per GPU --
+``allreduce_flat_`` and the overlapped ``GradReducer`` on device tensors (fp32 and bf16 wire), and one tiny two-rank GRPO step
+whose replicas must end bit-identical (same reduced gradient, same AdamW)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from golden_util import load_tiny
+    from spacer_amd import kernels as K
+    from spacer_amd.grpo import GradReducer, GRPOEngine, GRPOHyper, allreduce_flat_, group_advantages
+    from spacer_amd.qwen2vl.config import TINY
+    from spacer_amd.qwen2vl.weights import FlatParams, load_state_dict, param_specs, total_numel
+    from spacer_amd.rollout import PromptInput, SamplingParams
+    dev = torch.device("cuda", rank)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    pg = dist.group.WORLD
+    specs = param_specs(TINY)
+    n = total_numel(specs)
+    contrib = [torch.randn(n, generator=torch.Generator().manual_seed(50 + r)) for r in range(world)]
+    ok = True
+    for wire in (None, torch.bfloat16):
+        want = sum(c.to(wire).float() if wire is not None else c for c in contrib)
+        tol = dict(atol=3e-2, rtol=2e-2) if wire is not None else dict(atol=1e-5, rtol=1e-5)
+        flat = contrib[rank].to(dev)
+        allreduce_flat_(flat, pg, bucket_elems=100_000, wire_dtype=wire)
+        ok = ok and torch.allclose(flat.cpu(), want, **tol)
+        flat = contrib[rank].to(dev)
+        red = GradReducer(flat, specs, pg, wire_dtype=wire, bucket_elems=100_000)
+        red.ready("llm.norm_w"); red.ready("llm.lm_head")
+        for i in reversed(range(TINY.layers)):
+            red.ready(f"llm.{i}.")
+        ok = ok and red.sent > 0
+        red.finish()
+        torch.cuda.synchronize()
+        ok = ok and torch.allclose(flat.cpu(), want, **tol)
+    # one data-parallel GRPO step on the tiny model: different prompts' completions per rank, identical replicas afterwards
+    g = load_tiny()
+    params = FlatParams.empty(TINY, dev)
+    load_state_dict(params, g["w"])
+    ge = GRPOEngine(TINY, params, GRPOHyper(num_generations=3, learning_rate=1e-3), process_group=pg)
+    pix, grid = K.patchify(g["frames"].to(dev), kpad=TINY.patch_kpad)
+    prompt = PromptInput(g["prompt"].to(dev), pix, [tuple(grid)])
+    comp = ge.rollout([prompt], SamplingParams(max_new_tokens=8, seed=1 + rank))
+    adv, _ = group_advantages(torch.tensor([2.0, 0.0, 1.0]), 3)
+    ge.score_and_backward(prompt, comp, adv.to(dev), last_group=True)
+    ge.reduce_gradients()
+    ge.optimizer_step(world)
+    torch.cuda.synchronize()
+    mine = ge.policy.flat.float().cpu()
+    both = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather_object(both, mine)
+    ok = ok and all(torch.equal(both[0], b) for b in both) and not torch.equal(mine, ge.ref.flat.float().cpu())
+    ret[rank] = ok
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs (RCCL over xGMI)")
+def test_rccl_gradient_exchange_two_gpus():
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert ret[0] and ret[1]

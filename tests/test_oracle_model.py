@@ -25,6 +25,39 @@ def test_logits_and_logps_match_hf():
     assert (lp - g["hf_logps"]).abs().max() < 5e-5
 
 
+def test_tied_embedding_fixture_matches_hf():
+    """tie_word_embeddings=True (the Qwen2-VL-2B arrangement, BASELINE configs[0]/[1]): lm_head is the embedding table."""
+    g = load_tiny("tiny_tied_model.npz")
+    assert g["cfg"]["tie_embeddings"] and "lm_head.weight" not in g["w"]
+    rows, grid = O.patchify_frames(g["frames"], g["cfg"])
+    ids = torch.cat([g["prompt"], g["completions"][0]])
+    lg = O.full_logits(g["w"], g["cfg"], ids, rows, [grid])
+    assert (lg - g["hf_logits_row0"]).abs().max() < 5e-5
+    lp = O.completion_logps(g["w"], g["cfg"], g["prompt"], g["completions"], rows, [grid])
+    assert (lp - g["hf_logps"]).abs().max() < 5e-5
+
+
+def test_engine_emulator_is_the_oracle_without_rounding_and_budget_is_additive():
+    """oracle/qwen2vl_engine_emul.py (the engine's bf16 rounding points on the CPU): with no class rounding it IS the
+    oracle; with every class as a hi+lo pair it is within 1e-5; with every class rounding it sits at the bf16-operand floor
+     -- above the north-star's 1e-3 even on this 2-layer model."""
+    from oracle import qwen2vl_engine_emul as E
+    g = load_tiny()
+    rows, grid = O.patchify_frames(g["frames"], g["cfg"])
+    w = {k: v.to(torch.bfloat16).float() for k, v in g["w"].items()}
+    rows = rows.to(torch.bfloat16).float()
+    gen = torch.Generator().manual_seed(0)
+    comps = torch.randint(5, 990, (8, 16), generator=gen)
+    want = O.completion_logps(w, g["cfg"], g["prompt"], comps, rows, [grid])
+    none = E.completion_logps(w, g["cfg"], g["prompt"], comps, rows, [grid], points=())
+    assert (none - want).abs().max() < 2e-6
+    pairs = E.completion_logps(w, g["cfg"], g["prompt"], comps, rows, [grid], split=E.ALL_POINTS)
+    assert (pairs - want).abs().max() < 1e-5
+    full = E.completion_logps(w, g["cfg"], g["prompt"], comps, rows, [grid])
+    rms = float((full - want).pow(2).mean().sqrt())
+    assert 2e-4 < rms < 2e-3, rms
+
+
 def test_mrope_positions_match_hf_and_era_rule():
     g = load_tiny()
     ids = torch.cat([g["prompt"], g["completions"][0]]).tolist()

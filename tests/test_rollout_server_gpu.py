@@ -1,7 +1,8 @@
 """GPU: the dedicated-rollout-rank topology end to end on the tiny model -- a training rank running
 ``Qwen2VLGRPOVLLMTrainerModified`` and a rollout rank running the HIP RolloutEngine behind ``RolloutServer`` (two processes;
-both on cuda:0 and talking over gloo here because the test box has one GPU -- the wire code is the same for RCCL, which only
-skips the host staging).  Bar: the remote rollouts are the ones a local RolloutEngine samples from the same weights and seed,
+on a box with >= 2 GPUs each rank takes its own GPU and the job talks over RCCL ("nccl": grouped point-to-point weight push,
+device tensors on the wire); on a one-GPU box both ranks share cuda:0 and talk over gloo, the same protocol staged through host
+memory).  Bar: the remote rollouts are the ones a local RolloutEngine samples from the same weights and seed,
 so step 1 of the remote trainer reproduces step 1 of ``SGRLVRTrainer`` exactly (rewards, lengths, loss)."""
 import json
 import os
@@ -35,9 +36,14 @@ def _worker(rank, world, port, tmp, ret):
     from spacer_amd.qwen2vl.config import TINY
     from spacer_amd.qwen2vl.weights import FlatParams, load_state_dict
     from spacer_amd.rollout_server import make_topology
-    dev = torch.device("cuda", 0)
+    multi = torch.cuda.device_count() >= world
+    dev = torch.device("cuda", rank if multi else 0)
     torch.cuda.set_device(dev)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if multi:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    ret["backend"] = dist.get_backend()
     topo = make_topology()
     if topo.is_server:
         ret["served"] = run_rollout_rank(TINY, topo, dev)

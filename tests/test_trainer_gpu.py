@@ -92,3 +92,81 @@ def test_accumulation_micro_batches_roll_out_together(dev, tmp_path):
     assert sorted((s["n"], s["video_path"]) for s in SEEN) == [(2, False)] * 4 + [(4, True)] * 4
     logs = [json.loads(line) for line in open(os.path.join(str(tmp_path), "trainer_log.jsonl"))]
     assert len(logs) == 2 and all(lg["kl"] >= 0 for lg in logs)
+
+
+def _video_rows(n, seed0=20):
+    rows = []
+    for i in range(n):
+        frames = torch.randint(0, 256, (6, 3, 56, 84), generator=torch.Generator().manual_seed(seed0 + i), dtype=torch.uint8)
+        rows.append(dict(prompt=[{"role": "user", "content": [{"type": "video"}, {"type": "text", "text": f"clip {i} ?"}]}],
+                         path=frames, data_type="video", problem_type="multiple choice", solution="<answer>A</answer>",
+                         problem_id=i, options=["A. x", "B. y"], data_source="other"))
+    return rows
+
+
+def test_image_rows_train(dev, tmp_path):
+    """``data_type == "image"`` rows (SG-RLVR.py:319-352, TR:396-414): the image goes through fetch_image (PIL, as the
+    reference), the prompt carries <|image_pad|> placeholders + image_grid_thw, T-GRPO is skipped (temporal_rewards 0.5)."""
+    from PIL import Image
+    g = load_tiny()
+    params = FlatParams.empty(TINY, dev)
+    load_state_dict(params, g["w"])
+    rows = []
+    for i in range(2):
+        arr = torch.randint(0, 256, (60, 90, 3), generator=torch.Generator().manual_seed(40 + i), dtype=torch.uint8).numpy()
+        rows.append(dict(prompt=[{"role": "user", "content": [{"type": "image"}, {"type": "text", "text": f"what is in image {i} ?"}]}],
+                         path=Image.fromarray(arr), data_type="image", problem_type="multiple choice", solution="<answer>A</answer>",
+                         problem_id=i, options=["A. x", "B. y"], data_source="other"))
+    args = GRPOConfig(output_dir=str(tmp_path), max_completion_length=6, num_generations=4, learning_rate=1e-4, max_steps=2,
+                      logging_steps=1, save_steps=0, seed=3)
+    trainer = SGRLVRTrainer(model=params, reward_funcs=[accuracy_reward, format_reward], args=args,
+                            script_args=GRPOScriptArguments(temporal=True, len_control=True), train_dataset=rows,
+                            processing_class=FakeProcessor(TINY), device=dev)
+    prep = trainer._prepare([rows[0]])
+    assert prep["sproc"] is None and not prep["has_video"] and "pixel_values" in prep["proc"]
+    pi = trainer._prompt_input(prep["proc"])
+    assert int((pi.ids == TINY.image_token_id).sum()) == pi.grids[0][1] * pi.grids[0][2] // 4 and pi.grids[0][0] == 1
+    SEEN.clear()
+    assert trainer.train()["global_step"] == 2
+    assert {(s["n"], s["video_path"]) for s in SEEN} == {(4, True)}              # no shuffled twin for images
+    logs = [json.loads(line) for line in open(os.path.join(str(tmp_path), "trainer_log.jsonl"))]
+    assert all(lg["temporal_rewards"] == 0.5 and lg["kl"] >= 0 and lg["loss"] == lg["loss"] for lg in logs)
+
+
+def test_resume_skips_consumed_steps_and_restores_optimizer(dev, tmp_path, monkeypatch):
+    """--resume_from_checkpoint (SG-RLVR.py:377-381, HF Trainer semantics): the run continues AFTER the samples already
+    consumed (no replay from position 0), and with --save_only_model false the fp32 master weights and Adam moments come back,
+    so a resumed run reproduces the uninterrupted one."""
+    monkeypatch.setenv("SPACER_SKINNY_BLOCKS", "1")          # decode GEMMs without split-K atomics: reproducible rollouts
+    g = load_tiny()
+    rows = _video_rows(3)
+    common = dict(reward_funcs=[accuracy_reward, format_reward], script_args=GRPOScriptArguments(temporal=False, len_control=True),
+                  train_dataset=rows, processing_class=FakeProcessor(TINY), device=dev)
+
+    def fresh():
+        p = FlatParams.empty(TINY, dev)
+        load_state_dict(p, g["w"])
+        return p
+
+    def cfg(out, steps):
+        return GRPOConfig(output_dir=out, max_completion_length=6, num_generations=4, learning_rate=1e-3, max_steps=steps,
+                          logging_steps=1, save_steps=2, save_only_model=False, seed=9, use_decode_graph=False)
+
+    order = []
+    full = SGRLVRTrainer(model=fresh(), args=cfg(str(tmp_path / "full"), 3), **common)
+    inner = full._prepare
+    full._prepare = lambda inputs, seed=0: (order.append(inputs[0]["problem_id"]), inner(inputs, seed))[1]
+    full.train()
+    ck = str(tmp_path / "full" / "checkpoint-2")
+    assert os.path.exists(os.path.join(ck, "optimizer.pt"))
+    seen = []
+    res = SGRLVRTrainer(model=fresh(), args=cfg(str(tmp_path / "resumed"), 3), model_config=TINY, **common)
+    inner2 = res._prepare
+    res._prepare = lambda inputs, seed=0: (seen.append(inputs[0]["problem_id"]), inner2(inputs, seed))[1]
+    assert res.train(resume_from_checkpoint=ck)["global_step"] == 3
+    assert seen == order[2:3], (seen, order)                       # only the third sample of the epoch's permutation is trained
+    assert res.engine.step_count == 3
+    # same sample, same rollout seed, restored master + moments -> the same weights up to backward-atomics rounding
+    a, b = full.engine.policy.flat.float(), res.engine.policy.flat.float()
+    assert float((a - b).abs().max()) <= 2e-3 * float(a.abs().max())
+    assert float((full.engine.m - res.engine.m).abs().max()) <= 1e-2 * float(full.engine.m.abs().max()) + 1e-8

@@ -160,3 +160,47 @@ def test_data_parallel_exchange_world2():
         assert abs(m["completion_length"] - 25.5) < 1e-6 and abs(m["kl"] - 0.375) < 1e-6
         assert abs(m["rewards/accuracy_reward"] - 0.95) < 1e-6 and m["rewards/format_reward"] == 1.0
         assert m["temporal_rewards"] == 0.5 and abs(m["reward"] - (1.0 + 2.9) / 2) < 1e-6
+
+
+def _reducer_worker(rank, world, port, ret):
+    """GradReducer (grpo.py) on gloo/CPU tensors: ranges reported in BACKWARD order (end of the flat buffer first, as the
+    engine's hooks do) are bucketed and sent while "backward" continues; finish() covers what was never reported."""
+    from spacer_amd.grpo import GradReducer
+    from spacer_amd.qwen2vl.config import TINY_TIED
+    from spacer_amd.qwen2vl.weights import param_specs, total_numel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    specs = param_specs(TINY_TIED)
+    n = total_numel(specs)
+    ok = True
+    for wire in (None, torch.bfloat16):
+        flat = torch.randn(n, generator=torch.Generator().manual_seed(7 + rank))
+        contributions = [torch.randn(n, generator=torch.Generator().manual_seed(7 + r)) for r in range(world)]
+        red = GradReducer(flat, specs, dist.group.WORLD, wire_dtype=wire, bucket_elems=200_000)
+        sent_before_finish = 0
+        red.ready("llm.norm_w")
+        for i in reversed(range(TINY_TIED.layers)):
+            red.ready(f"llm.{i}.")
+        sent_before_finish = red.sent                              # buckets already on the wire "during backward"
+        red.ready("llm.embed"); red.ready("merger.")
+        for i in reversed(range(TINY_TIED.vit_depth)):
+            red.ready(f"vit.{i}.")
+        # vit.patch_w deliberately NOT reported: finish() must still cover it
+        red.finish()
+        want = sum(c.to(wire).float() if wire is not None else c for c in contributions)
+        tol = dict(atol=3e-2, rtol=2e-2) if wire is not None else dict(atol=1e-6, rtol=1e-6)
+        ok = ok and torch.allclose(flat, want, **tol) and sent_before_finish > 0
+        # second step with NO ready() calls at all (overlap off): one finish() reduces everything
+        flat2 = contributions[rank].clone()
+        red2 = GradReducer(flat2, specs, dist.group.WORLD, wire_dtype=wire, bucket_elems=200_000)
+        red2.finish()
+        ok = ok and torch.allclose(flat2, want, **tol)
+    ret[rank] = ok
+    dist.destroy_process_group()
+
+
+def test_overlapped_gradient_reducer_world2():
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_reducer_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret[0] and ret[1]
