@@ -267,7 +267,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     prof = K.PROFILER.summary()
-    main_stats = dict(roll_stats)
+    main_stats, main_phase = dict(roll_stats), dict(phase)
+    hbm_peak_gb = round(torch.cuda.max_memory_allocated() / 1e9, 1)       # of 288 GB: replicas, no ZeRO, no recompute
     variants = {}
     if world == 1 and not args.no_variants and not args.temporal and args.workload in ("cfg3", "cfg2", "tiny"):
         # the same workload as the shipped script runs it (run_SpaceR_SG_RLVR.sh:29 --temporal true) and free-running
@@ -292,6 +293,8 @@ def main():
                 torch.cuda.empty_cache()
         roll_stats.clear()
         roll_stats.update(main_stats)
+        phase.clear()
+        phase.update(main_phase)
     if args.gemm_shapes and rank == 0:
         shapes = sorted(((v["seconds"], k, v) for k, v in prof.items() if k.startswith("gemm[")), reverse=True)
         for sec, k, v in shapes[:24]:
@@ -325,7 +328,7 @@ def main():
             "kernels": {k: {"tflops": round(v["tflops"], 2), "launches": v["launches"], "seconds": round(v["seconds"], 4)}
                         for k, v in prof.items()},
         }
-        out["hbm_peak_gb"] = round(torch.cuda.max_memory_allocated() / 1e9, 1)      # of 288 GB: replicas, no ZeRO, no recompute
+        out["hbm_peak_gb"] = hbm_peak_gb
         if roll_stats.get("events"):
             # the north-star's "fused rollout forward": ViT + LLM prefill of every prompt (MFMA-bound), and the decode loop
             # (HBM-bound: packed weights + KV), each from HIP events on the launch stream inside the timed region

@@ -60,6 +60,16 @@ typedef struct spacer_gemm_epilogue {
 int spacer_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
                         const spacer_gemm_epilogue* epi, spacer_stream_t stream);
 
+/* The same GEMM with operands read in place from CONTRACTION-MAJOR arrays: trans_a -> A(m,k) = A[k*lda + m] (a [K, M] row-major
+ * array), trans_b -> B(n,k) = B[k*ldb + n] ([K, N]).  What loss.backward() needs for every nn.Linear of the model the reference
+ * trains (SG_RLVR_trainer.py:357 forward, HF Trainer.training_step backward):
+ *     dX[T,in] = dY[T,out] . W[out,in]            trans_a = 0, trans_b = 1   (M = T,   N = in, K = out)
+ *     dW[out,in] += dY[T,out]^T . X[T,in]         trans_a = 1, trans_b = 1   (M = out, N = in, K = T, any K >= 1: a ragged
+ *                                                                             last K tile is masked in the kernel)
+ * trans_a needs M % 8 == 0, trans_b needs N % 8 == 0; (trans_a = 1, trans_b = 0) is not instantiated.  Always the 256 tile. */
+int spacer_gemm_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K, int trans_a,
+                     int trans_b, const spacer_gemm_epilogue* epi, spacer_stream_t stream);
+
 long spacer_gemm_workspace_bytes(void);
 
 /* SwiGLU MLP input half in one launch (HF Qwen2MLP.forward: act_fn(gate_proj(x)) * up_proj(x), modeling_qwen2_vl.py Qwen2MLP;
@@ -233,6 +243,24 @@ int spacer_embed_bwd(const int64_t* ids, const int* video_row_of_token, const fl
  * ---------------------------------------------------------------------------------------------- */
 int spacer_patchify(const uint8_t* frames, void* out, int F, int Hpx, int Wpx, int patch, int tpatch, int merge,
                     int Kpad, spacer_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Video front end before patchify (qwen_vl_utils/vision_process.py, reached through TR:406 process_vision_info):
+ *   spacer_gather_frames_u8      out[f] = src[idx[f]]: the uniform frame sampling of :252 (idx = linspace().round()) on
+ *                                decoded frames already in HBM; frame_bytes % 16 == 0, 16-byte aligned buffers.
+ *   spacer_resize_bicubic_aa_u8  :310-315 `resize(video, [h, w], BICUBIC, antialias=True)` on uint8 [planes = F*3, H, W]
+ *                                -> uint8 [planes, h, w]: torch's separable antialiased bicubic (horizontal pass, fp32
+ *                                intermediate, vertical pass), rounded half-to-even to the uint8 grid and clamped, as
+ *                                torchvision's tensor resize does for uint8 input.  Window / weight tables per axis
+ *                                (xmin, xsize int32 [w]; wx fp32 [w, taps_x]; same for y) are the caller's
+ *                                (vision_process.aa_tables restates aten's _compute_indices_weights_aa);
+ *                                workspace = spacer_resize_workspace_bytes(planes, H, w) bytes of fp32 scratch.
+ * ---------------------------------------------------------------------------------------------- */
+int spacer_gather_frames_u8(const uint8_t* src, const int* idx, uint8_t* out, int n, long frame_bytes, spacer_stream_t stream);
+long spacer_resize_workspace_bytes(int planes, int H, int w);
+int spacer_resize_bicubic_aa_u8(const uint8_t* src, uint8_t* dst, int planes, int H, int W, int h, int w, const int* xmin,
+                                const int* xsize, const float* wx, int taps_x, const int* ymin, const int* ysize,
+                                const float* wy, int taps_y, float* workspace, spacer_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Per-token log-probs (TR:353-366) from fp32 logits rows: logp[r] = logits[r, tgt[r]] - logsumexp(logits[r,:]).

@@ -33,6 +33,7 @@ _p, _i, _l, _f, _u64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint64
 # name -> argtypes; every entry returns int.  Kept in the order of include/spacer_hip.h.
 SIGNATURES = {
     "spacer_gemm_bf16_nt": [_p, _l, _p, _l, _p, _l, _i, _i, _i, C.POINTER(GemmEpilogue), _p],
+    "spacer_gemm_bf16": [_p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _i, C.POINTER(GemmEpilogue), _p],
     "spacer_gemm_skinny_bf16": [_p, _l, _p, _l, _p, _l, _i, _i, _i, C.POINTER(GemmEpilogue), _p],
     "spacer_pack_weight_frag": [_p, _l, _p, _i, _i, _p],
     "spacer_gemm_skinny_packed_bf16": [_p, _l, _p, _p, _l, _i, _i, _i, _p],
@@ -73,10 +74,12 @@ SIGNATURES = {
     "spacer_decode_qkv_finish": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "spacer_swiglu_f32_fwd": [_p, _p, _i, _i, _p],
     "spacer_gemm_swiglu_bf16": [_p, _l, _p, _l, _p, _p, _l, _p, _l, _i, _i, _i, _p],
+    "spacer_resize_bicubic_aa_u8": [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _i, _p, _p],
+    "spacer_gather_frames_u8": [_p, _p, _p, _i, _l, _p],
     "spacer_sumsq_f32": [_p, _l, _p, _p],
     "spacer_adamw_step": [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _f, _p, _f, _f, _p],
 }
-OTHER_SYMBOLS = ["spacer_last_error", "spacer_version", "spacer_sample_workspace_bytes", "spacer_attn_decode_workspace_bytes", "spacer_gemm_tile", "spacer_gemm_workspace_bytes", "spacer_gemm_swiglu_fused"]
+OTHER_SYMBOLS = ["spacer_last_error", "spacer_version", "spacer_sample_workspace_bytes", "spacer_attn_decode_workspace_bytes", "spacer_gemm_tile", "spacer_gemm_workspace_bytes", "spacer_gemm_swiglu_fused", "spacer_resize_workspace_bytes"]
 
 _lib = None
 
@@ -105,6 +108,8 @@ def load() -> C.CDLL:
     lib.spacer_gemm_swiglu_fused.restype = _i
     lib.spacer_gemm_workspace_bytes.argtypes = []
     lib.spacer_gemm_workspace_bytes.restype = C.c_long
+    lib.spacer_resize_workspace_bytes.argtypes = [_i, _i, _i]
+    lib.spacer_resize_workspace_bytes.restype = C.c_long
     lib.spacer_attn_decode_workspace_bytes.argtypes = [_i, _i]
     lib.spacer_attn_decode_workspace_bytes.restype = C.c_long
     _lib = lib

@@ -1,8 +1,9 @@
-// bf16 GEMM for gfx950:  C[M,N] = epilogue( A[M,K] . B[N,K]^T )   (both operands K-contiguous)
+// bf16 GEMM for gfx950:  C[M,N] = epilogue( sum_k A(m,k) B(n,k) )
 //
-// This is the one matmul shape the whole hot path is expressed in (every nn.Linear of the ViT / LLM the
-// reference trainer drives is y = x W^T with W stored [out,in]); backward GEMMs reuse it through the
-// transpose kernel (dX = dY . (W^T)^T, dW = dY^T . (X^T)^T).
+// Every nn.Linear of the ViT / LLM the reference trainer drives is y = x W^T with W stored [out,in]: both operands
+// contraction-contiguous ("NT", spacer_gemm_bf16_nt).  The backward GEMMs contract over the OTHER dim of the stored arrays
+// (dX = dY . W over `out`, dW = dY^T . X over tokens); the 256 tile reads such operands in place (trans_a / trans_b of
+// spacer_gemm_bf16: contraction-major LDS images + transposing LDS reads, gemm_halftile.h) -- no transpose pass, no W^T copies.
 //
 // Design (MI355X_MICROARCH / cdna_hip_programming T1/T2/T3):
 //   * two kernels picked by problem size (spacer_gemm_tile):
@@ -297,11 +298,14 @@ extern "C" long spacer_gemm_workspace_bytes(void) { return WS_MAX_SLABS * WS_SLA
 
 extern "C" int spacer_gemm_tile(int M, int N, int K, int have_workspace) { return choose_tile(M, N, K, have_workspace != 0); }
 
-extern "C" int spacer_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M,
-                                   int N, int K, const spacer_gemm_epilogue* epi, spacer_stream_t stream) {
+static int launch_gemm(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K, bool ta, bool tb,
+                       const spacer_gemm_epilogue* epi, spacer_stream_t stream) {
     SP_REQUIRE(A && B && C, SPACER_EINVAL, "gemm: null operand");
     SP_REQUIRE(M > 0 && N > 0 && K > 0, SPACER_EINVAL, "gemm: empty shape M=%d N=%d K=%d", M, N, K);
-    SP_REQUIRE(K % BK == 0, SPACER_EINVAL, "gemm: K=%d must be a multiple of %d (pad the contraction dim)", K, BK);
+    SP_REQUIRE(!ta || tb, SPACER_EINVAL, "gemm: trans_a without trans_b is not instantiated (no caller on the hot path)");
+    SP_REQUIRE(ta || K % BK == 0, SPACER_EINVAL, "gemm: K=%d must be a multiple of %d (pad the contraction dim)", K, BK);
+    SP_REQUIRE(!ta || (M % 8 == 0 && M >= 8), SPACER_EINVAL, "gemm: trans_a needs M %% 8 == 0 (M=%d)", M);
+    SP_REQUIRE(!tb || (N % 8 == 0 && N >= 8), SPACER_EINVAL, "gemm: trans_b needs N %% 8 == 0 (N=%d)", N);
     SP_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, SPACER_EINVAL, "gemm: lda/ldb must be multiples of 8 elements");
     SP_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, SPACER_EINVAL, "gemm: A/B must be 16-byte aligned");
     GemmArgs g;
@@ -319,21 +323,28 @@ extern "C" int spacer_gemm_bf16_nt(const void* A, long lda, const void* B, long 
     SP_REQUIRE(((uintptr_t)C % (4 * esz)) == 0, SPACER_EINVAL, "gemm: C misaligned");
     const bool have_ws = epi && epi->workspace && epi->workspace_bytes >= spacer_gemm_workspace_bytes();
     SP_REQUIRE(!(epi && epi->workspace) || ((uintptr_t)epi->workspace % 16) == 0, SPACER_EINVAL, "gemm: workspace misaligned");
-    const bool big = choose_tile(M, N, K, have_ws) == 256;
+    // the contraction-major operand forms exist on the 256 tile only
+    const bool big = tb || choose_tile(M, N, K, have_ws) == 256;
     hipStream_t s = (hipStream_t)stream;
     if (big) {
         constexpr int LDS = 8 * 128 * BK * 2;
         static const int once = hipFuncSetAttribute((const void*)gemm_bf16_nt_256h_kernel<true>,
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS)
+                              + hipFuncSetAttribute((const void*)gemm_bf16_nt_256h_kernel<true, false, true>,
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS)
+                              + hipFuncSetAttribute((const void*)gemm_bf16_nt_256h_kernel<true, true, true>,
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         (void)once;
         g.tiles_m = cdiv(M, 256); g.tiles_n = cdiv(N, 256);
         const long tiles = (long)g.tiles_m * g.tiles_n;
         static const char* nosplit = getenv("SPACER_GEMM_NOSPLIT");
-        tail_plan(tiles, K / BK, have_ws && !nosplit, &g.full_tiles, &g.splits);
+        tail_plan(tiles, cdiv(K, BK), have_ws && !nosplit, &g.full_tiles, &g.splits);
         g.slabs = have_ws ? (float*)epi->workspace : nullptr;
         const long tail_tiles = tiles - g.full_tiles;
-        hipLaunchKernelGGL((gemm_bf16_nt_256h_kernel<true>), dim3((unsigned)(g.full_tiles + tail_tiles * g.splits)), dim3(512),
-                           LDS, s, g);
+        const dim3 grid((unsigned)(g.full_tiles + tail_tiles * g.splits));
+        if (ta) hipLaunchKernelGGL((gemm_bf16_nt_256h_kernel<true, true, true>), grid, dim3(512), LDS, s, g);
+        else if (tb) hipLaunchKernelGGL((gemm_bf16_nt_256h_kernel<true, false, true>), grid, dim3(512), LDS, s, g);
+        else hipLaunchKernelGGL((gemm_bf16_nt_256h_kernel<true>), grid, dim3(512), LDS, s, g);
         if (g.splits > 1) hipLaunchKernelGGL(gemm_tail_reduce_kernel, dim3((unsigned)(tail_tiles * 32)), dim3(512), 0, s, g);
     } else {
         constexpr int LDS = 2 * (128 * BK * 2 + 128 * BK * 2);
@@ -342,6 +353,16 @@ extern "C" int spacer_gemm_bf16_nt(const void* A, long lda, const void* B, long 
     }
     SP_CHECK_LAUNCH();
     return SPACER_OK;
+}
+
+extern "C" int spacer_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M,
+                                   int N, int K, const spacer_gemm_epilogue* epi, spacer_stream_t stream) {
+    return launch_gemm(A, lda, B, ldb, C, ldc, M, N, K, false, false, epi, stream);
+}
+
+extern "C" int spacer_gemm_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
+                                int trans_a, int trans_b, const spacer_gemm_epilogue* epi, spacer_stream_t stream) {
+    return launch_gemm(A, lda, B, ldb, C, ldc, M, N, K, trans_a != 0, trans_b != 0, epi, stream);
 }
 
 // act[M, I] (bf16) = silu(A . Wgate^T + bgate) * (A . Wup^T + bup) with W = [gate rows | up rows] ([2I, K]), in ONE launch on the

@@ -20,6 +20,20 @@
 //     SIMD alternate between the LDS segment and the MFMA segment, so the matrix pipe always has a wave feeding it.
 //   * K tiles past the end are staged from the last real tile (redundant, never read) so the in-flight count is the
 //     same in every phase; the queue is drained once, before the epilogue.
+//
+// Operand layouts (TA / TB).  C[m][n] = sum_k A(m,k) B(n,k).  The default (false) is "contraction-contiguous":
+// A(m,k) = A[m*lda + k].  TA = true reads A stored CONTRACTION-MAJOR, A(m,k) = A[k*lda + m] (an [K, M] row-major array),
+// likewise TB; this is what the backward GEMMs need without a transpose pass:
+//     dX[T, in]  = dY[T, out] . W[out, in]           A = dY (plain),   B(n = in, k = out) = W[k][n]     -> TB
+//     dW[out,in] = dY[T, out]^T . X[T, in]           A(m = out, k = t) = dY[k][m], B(n = in, k = t) = X[k][n] -> TA, TB
+// A contraction-major half-tile image is [64 k-rows][128 columns] (256-byte rows, same 16 KiB): the DMA writes 4 k-rows
+// per 1 KiB piece, and the MFMA operand fragments are gathered with gfx950's transposing LDS read (ds_read_b64_tr_b16: a
+// 16-lane group fetches a [4 k-rows][16 columns] block, lane i receives column i of the 4 rows; two reads fill the 8
+// contraction slots k = kk*32 + (lane>>4)*8 + 0..7 of a 16x16x32 operand, the same slot order as the plain image, so the two
+// layouts mix freely).  Bank swizzle of that image: the 32-byte column pair index ^= (row & 3) | ((row >> 3) & 1) << 2 -- the 8
+// rows a 32-lane group touches in one read ({r..r+3} and {r+8..r+11}) land on 8 distinct 32-byte bank groups.
+// A ragged contraction length (dW: K = tokens) is handled in the kernel: rows >= K are fetched from row K-1 (in bounds)
+// and the A fragments of the last K tile are masked to zero slot by slot.
 #include <type_traits>
 
 // pid (position in the launch's tile order) -> tile coordinates: groups of 4 tile-rows walked column by column, so the
@@ -33,7 +47,10 @@ __device__ __forceinline__ void tile_of_256(int pid, const GemmArgs& g, int& tm,
     tn = (pid % per_group) / gsz;
 }
 
-template <bool BALANCED>
+typedef __attribute__((ext_vector_type(4))) short gemm_s16x4;
+typedef __attribute__((ext_vector_type(8))) short gemm_s16x8;
+
+template <bool BALANCED, bool TA = false, bool TB = false>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
     constexpr int BM = 256, BN = 256;
     constexpr int HALF = 128 * BK * 2;                 // one half-tile image
@@ -46,7 +63,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
     // ---- block -> (tile, K range).  Blocks [0, full_tiles) own whole tiles (bijective XCD remap); the remaining
     // tiles (the last, partially filled round of the 256 CUs) are each cut into `splits` K ranges, so the tail of the
     // launch also fills the chip.  splits == 1 -> full_tiles == all tiles and there is no tail.
-    int pid, split = 0, kt0 = 0, ntl = g.K / BK;
+    int pid, split = 0, kt0 = 0, ntl = (g.K + BK - 1) / BK;
     bool tail = false;
     {
         const int b = blockIdx.x;
@@ -58,7 +75,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
             pid = g.full_tiles + u / g.splits;
             split = u % g.splits;
             tail = true;
-            const int nt_all = g.K / BK;
+            const int nt_all = (g.K + BK - 1) / BK;
             kt0 = (int)((long)split * nt_all / g.splits);
             ntl = (int)((long)(split + 1) * nt_all / g.splits) - kt0;
         }
@@ -67,22 +84,41 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
     tile_of_256(pid, g, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
-    // ---- DMA sources: this wave owns pieces (wave*2 + i), i = 0..1, of every half-tile image (8 rows x 128 B each)
+    // ---- DMA sources: this wave owns pieces (wave*2 + i), i = 0..1, of every half-tile image.
+    // plain image: piece = 8 rows x 128 B;  contraction-major image: piece = 4 k-rows x 256 B
     unsigned offA[2][2], offB[2][2];                   // [half][piece] element offsets of this lane's 16-byte chunk
+    int krT[2];                                        // contraction-major: k-row (inside the K tile) of piece i
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int hr = (wave * 2 + i) * 8 + (lane >> 3);                 // image row
+            const int hr = (wave * 2 + i) * 8 + (lane >> 3);                 // plain image row
             const int chunk = (lane & 7) ^ ((hr >> 1) & 7);                  // logical 16-B chunk this lane fetches
-            int ra = m0 + (hr >> 6) * 128 + h * 64 + (hr & 63);
-            const int lcol = (hr >> 5) * 64 + h * 32 + (hr & 31);            // tile column this B row produces
-            int rb = n0 + lcol;
-            if (g.swiglu_inter) rb = (lcol < 128 ? 0 : g.swiglu_inter - 128) + tn * 128 + lcol;
-            ra = ra < g.M ? ra : g.M - 1;
-            rb = rb < g.N ? rb : g.N - 1;
-            offA[h][i] = (unsigned)((long)ra * g.lda + chunk * 8);
-            offB[h][i] = (unsigned)((long)rb * g.ldb + chunk * 8);
+            const int kr = (wave * 2 + i) * 4 + (lane >> 4);                 // contraction-major image row
+            const int pc = lane & 15;                                        // physical 16-B chunk in the 256-byte row
+            const int lc = ((((pc >> 1) ^ ((kr & 3) | (((kr >> 3) & 1) << 2))) << 1) | (pc & 1));   // logical chunk (8 columns)
+            if (TA) {
+                int m = m0 + (lc >> 3) * 128 + h * 64 + (lc & 7) * 8;         // first of 8 consecutive tile rows
+                m = m + 8 <= g.M ? m : g.M - 8;
+                offA[h][i] = (unsigned)m;
+                krT[i] = kr;
+            } else {
+                int ra = m0 + (hr >> 6) * 128 + h * 64 + (hr & 63);
+                ra = ra < g.M ? ra : g.M - 1;
+                offA[h][i] = (unsigned)((long)ra * g.lda + chunk * 8);
+            }
+            if (TB) {
+                int n = n0 + (lc >> 2) * 64 + h * 32 + (lc & 3) * 8;          // first of 8 consecutive tile columns
+                n = n + 8 <= g.N ? n : g.N - 8;
+                offB[h][i] = (unsigned)n;
+                krT[i] = kr;
+            } else {
+                const int lcol = (hr >> 5) * 64 + h * 32 + (hr & 31);        // tile column this B row produces
+                int rb = n0 + lcol;
+                if (g.swiglu_inter) rb = (lcol < 128 ? 0 : g.swiglu_inter - 128) + tn * 128 + lcol;
+                rb = rb < g.N ? rb : g.N - 1;
+                offB[h][i] = (unsigned)((long)rb * g.ldb + chunk * 8);
+            }
         }
     const int nt = ntl;                                 // K tiles of THIS block: global tiles kt0 .. kt0+nt-1
     auto stage = [&](int par, int which, int t) {
@@ -90,7 +126,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
         char* dst = smem + (par * 4 + which) * HALF + wave * 2048;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const bf16_t* src = (which < 2) ? g.A + offA[which & 1][i] + k0 : g.B + offB[which & 1][i] + k0;
+            const bf16_t* src;
+            if (which < 2) {
+                if (TA) src = g.A + (long)min(k0 + krT[i], g.K - 1) * g.lda + offA[which & 1][i];
+                else src = g.A + offA[which & 1][i] + k0;
+            } else {
+                if (TB) src = g.B + (long)min(k0 + krT[i], g.K - 1) * g.ldb + offB[which & 1][i];
+                else src = g.B + offB[which & 1][i] + k0;
+            }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
         }
@@ -101,8 +144,46 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
     const int fo0 = (lane & 15) * 128 + (((lane >> 4) ^ fsw) << 4);          // kk = 0
     const int fo1 = fo0 ^ 64;                                                // kk = 1: chunk + 4
     const int aoff = wr * 64 * 128, boff = wc * 32 * 128;
-    auto fragA = [&](const char* img, int i, int kk) { return *(const bf16x8*)(img + aoff + i * 2048 + (kk ? fo1 : fo0)); };
-    auto fragB = [&](const char* img, int j, int kk) { return *(const bf16x8*)(img + boff + j * 2048 + (kk ? fo1 : fo0)); };
+    // contraction-major image: lane i of a 16-lane group supplies the address of k-row kk*32 + g*8 + (i>>2) [+4 for the
+    // second read], columns cb + 4*(i&3) .. +3 (8 bytes), and receives column cb + i of the four rows.  The swizzle term
+    // (row & 3) | ((row >> 3) & 1) << 2 of those rows does not depend on kk or on the +4, so it is a per-lane constant and a
+    // fragment's address is  img + [lane part] + ((block ^ hx) << 5) + kk*8192 (+1024), block = 16-column block of the image.
+    const int tq = (lane & 15) >> 2, tg = lane >> 4;
+    const int hx = tq | ((tg & 1) << 2);
+    const int tlane = (tg * 8 + tq) * 256 + (lane & 3) * 8;
+    int toA[4], toB[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) toA[i] = tlane + (((wr * 4 + i) ^ hx) << 5);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) toB[j] = tlane + (((wc * 2 + j) ^ hx) << 5);
+    auto frag_t16 = [&](const char* p) -> bf16x8 {
+        const gemm_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) gemm_s16x4*)p);
+        const gemm_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) gemm_s16x4*)(p + 1024));
+        const gemm_s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, both);
+    };
+    auto fragA = [&](const char* img, int i, int kk) -> bf16x8 {
+        if (TA) return frag_t16(img + toA[i] + kk * 8192);
+        return *(const bf16x8*)(img + aoff + i * 2048 + (kk ? fo1 : fo0));
+    };
+    auto fragB = [&](const char* img, int j, int kk) -> bf16x8 {
+        if (TB) return frag_t16(img + toB[j] + kk * 8192);
+        return *(const bf16x8*)(img + boff + j * 2048 + (kk ? fo1 : fo0));
+    };
+    // ragged contraction length (TA only): slot s of lane group tg in k-step kk is contraction row kk*32 + tg*8 + s of the
+    // tile; in the last K tile rows >= krem are zeroed in the A fragments (B rows there are finite duplicates of row K-1)
+    const int krem = g.K - (kt0 + nt - 1) * BK;                              // valid k-rows of this block's last tile (1..64)
+    auto mask_a = [&](bf16x8& v, int kk) {
+        const int base = kk * 32 + tg * 8;
+        uint4 u = __builtin_bit_cast(uint4, v);
+        unsigned* w = (unsigned*)&u;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const unsigned lo_ok = base + 2 * d < krem ? 0x0000ffffu : 0u, hi_ok = base + 2 * d + 1 < krem ? 0xffff0000u : 0u;
+            w[d] &= (lo_ok | hi_ok);
+        }
+        v = __builtin_bit_cast(bf16x8, u);
+    };
 
     f32x4 acc[8][4];
 #pragma unroll
@@ -146,6 +227,12 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
                 for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) a[i][kk] = fragA(img + A_LO * HALF, i, kk);
+                if (TA && krem < BK && t == nt - 1) {
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) mask_a(a[i][kk], kk);
+                }
             } else if (p == 1) {
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk)
@@ -156,6 +243,12 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
                 for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) a[i][kk] = fragA(img + A_HI * HALF, i, kk);
+                if (TA && krem < BK && t == nt - 1) {
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) mask_a(a[i][kk], kk);
+                }
             } else if (BALANCED) {                                           // next tile's B-lo (waited for in phase 2)
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk)

@@ -125,6 +125,37 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = N
     return out
 
 
+def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, trans_b: bool = False, out: Optional[torch.Tensor] = None,
+         residual=None, out_dtype=BF16, alpha: float = 1.0) -> torch.Tensor:
+    """out[M,N] = alpha * sum_k A(m,k) B(n,k) + residual with operands read IN PLACE from contraction-major arrays:
+    trans_a -> ``a`` is [K, M] (A(m,k) = a[k, m]), trans_b -> ``b`` is [K, N].  The backward GEMMs of every linear layer:
+        dX = gemm(dY, W, trans_b=True)                    [T, out] x [out, in] -> [T, in]
+        dW = gemm(dY, X, trans_a=True, trans_b=True)      [T, out], [T, in]    -> [out, in]   (K = T, ragged is fine)
+    No transposes, no W^T copies.  Runs on the 256 tile (spacer_gemm_bf16)."""
+    if not trans_a and not trans_b:
+        return gemm_nt(a, b, out=out, residual=residual, out_dtype=out_dtype, alpha=alpha)
+    Kc = a.shape[0] if trans_a else a.shape[1]
+    M = a.shape[1] if trans_a else a.shape[0]
+    N = b.shape[1] if trans_b else b.shape[0]
+    assert (b.shape[0] if trans_b else b.shape[1]) == Kc and a.dtype == BF16 and b.dtype == BF16
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=out_dtype)
+    assert out.dtype in (BF16, torch.float32) and (residual is None or residual.dtype == out.dtype)
+    epi = GemmEpilogue(None, _ptr(residual), _rowmajor(residual) if residual is not None else 0,
+                       1 if out.dtype == torch.float32 else 0, SPACER_ACT_NONE, alpha)
+    ws = _gemm_workspace(a.device)
+    epi.workspace, epi.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    t0 = PROFILER.begin()
+    check(_lib.load().spacer_gemm_bf16(_ptr(a), _rowmajor(a), _ptr(b), _rowmajor(b), _ptr(out), _rowmajor(out), M, N, Kc,
+                                       int(trans_a), int(trans_b), C.byref(epi), _stream()), "gemm_bf16")
+    if t0 is not None:
+        PROFILER.end("gemm_bf16_nt_256h_kernel", t0, 2.0 * M * N * Kc, 2.0 * (M * Kc + N * Kc) + out.element_size() * M * N)
+        if PROFILER.by_shape:
+            s0, e0 = PROFILER.records[-1][1], PROFILER.records[-1][2]
+            PROFILER.records.append((f"gemm{'T' if trans_a else 'N'}{'T' if trans_b else 'N'}[{M}x{N}x{Kc}]", s0, e0, 2.0 * M * N * Kc, 0.0))
+    return out
+
+
 def gemm_swiglu(a: torch.Tensor, w_gu: torch.Tensor, *, bias=None, keep_gu: bool = True):
     """SwiGLU input half of an MLP: returns (act [M, I] bf16, gu [M, 2I] bf16 or None) with
     act = silu(a @ Wgate^T + b) * (a @ Wup^T + b), w_gu = [gate rows | up rows] ([2I, K]).  One launch (gate|up GEMM with the
@@ -430,6 +461,41 @@ def patchify(frames_u8, patch=14, tpatch=2, merge=2, kpad=1216, *, out=None):
     check(_lib.load().spacer_patchify(_ptr(frames_u8), _ptr(out), F, Hpx, Wpx, patch, tpatch, merge, kpad, _stream()),
           "patchify")
     return out, (gt, gh, gw)
+
+
+_AA_DEV = {}
+
+
+def resize_bicubic_aa(frames_u8: torch.Tensor, hw, tables_x, tables_y, *, out=None) -> torch.Tensor:
+    """uint8 [F, C, H, W] -> uint8 [F, C, h, w], bicubic + antialias with torch's arithmetic (csrc/frontend.hip); the window /
+    weight tables (qwen_vl_utils.vision_process.aa_tables) are uploaded once per (size, device)."""
+    F, Cc, H, W = frames_u8.shape
+    h, w = int(hw[0]), int(hw[1])
+    assert frames_u8.dtype == torch.uint8 and frames_u8.is_contiguous()
+    dev = frames_u8.device
+    key = (dev, H, W, h, w)
+    tb = _AA_DEV.get(key)
+    if tb is None:
+        tb = [t.to(dev) for t in tables_x] + [t.to(dev) for t in tables_y]
+        _AA_DEV[key] = tb
+    xmin, xsize, wx, ymin, ysize, wy = tb
+    if out is None:
+        out = torch.empty(F, Cc, h, w, device=dev, dtype=torch.uint8)
+    ws = torch.empty(F * Cc * H * w, device=dev, dtype=torch.float32)
+    check(_lib.load().spacer_resize_bicubic_aa_u8(_ptr(frames_u8), _ptr(out), F * Cc, H, W, h, w, _ptr(xmin), _ptr(xsize), _ptr(wx),
+                                                  wx.shape[1], _ptr(ymin), _ptr(ysize), _ptr(wy), wy.shape[1], _ptr(ws), _stream()),
+          "resize_bicubic_aa_u8")
+    return out
+
+
+def gather_frames(frames_u8: torch.Tensor, idx32: torch.Tensor, *, out=None) -> torch.Tensor:
+    """out[f] = frames[idx[f]] (uniform frame sampling on the device); frames [T, ...] uint8 contiguous, 16-byte-multiple frames."""
+    n = idx32.shape[0]
+    fb = frames_u8[0].numel()
+    if out is None:
+        out = torch.empty((n,) + tuple(frames_u8.shape[1:]), device=frames_u8.device, dtype=torch.uint8)
+    check(_lib.load().spacer_gather_frames_u8(_ptr(frames_u8), _ptr(idx32), _ptr(out), n, fb, _stream()), "gather_frames_u8")
+    return out
 
 
 # ----------------------------------------------------------------------------------------- loss

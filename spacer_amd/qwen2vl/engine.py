@@ -28,29 +28,22 @@ class Qwen2VLEngine:
         self.cfg = cfg
         self.W = params
         self.dev = params.flat.device
-        self.cache_wT = cache_wT          # True trades +1x weight memory for skipping the per-use transposes
+        self.cache_wT = cache_wT          # kept for callers; unused since the backward GEMMs read W / dY / X in place
         self._wT: Dict[str, torch.Tensor] = {}
 
     # ------------------------------------------------------------------ helpers
     def invalidate_cache(self) -> None:
-        """Call after the optimizer rewrites the bf16 weights: drops the cached W^T copies."""
+        """Call after the optimizer rewrites the bf16 weights (nothing is cached any more: the dX GEMMs read W in place)."""
         self._wT.clear()
 
-    def wT(self, name: str) -> torch.Tensor:
-        """W^T ([in, out], contraction dim = out) for the dX GEMMs; built on first use per optimizer step."""
-        t = self._wT.get(name)
-        if t is None:
-            w = self.W[name]
-            assert w.shape[0] % 64 == 0, f"{name}: output dim must be a multiple of 64 for the dX GEMM"
-            t = K.transpose_pad(w, w.shape[0])
-            if self.cache_wT:
-                self._wT[name] = t
-        return t
+    def _dx(self, dy: torch.Tensor, name: str) -> torch.Tensor:
+        """dX[T, in] = dY[T, out] . W[out, in]: contraction over W's ROW index, read in place (trans_b)."""
+        return K.gemm(dy, self.W[name], trans_b=True)
 
     @staticmethod
     def _dw(gw: torch.Tensor, dy: torch.Tensor, x: torch.Tensor) -> None:
-        """gw[N,K] (fp32) += dy[T,N]^T @ x[T,K]  via two zero-padded transposes and the NT GEMM."""
-        K.gemm_nt(K.transpose_pad(dy), K.transpose_pad(x), out=gw, residual=gw, algo_k=dy.shape[0])
+        """gw[N,K] (fp32) += dy[T,N]^T @ x[T,K]: both operands contraction-major, read in place (trans_a, trans_b)."""
+        K.gemm(dy, x, trans_a=True, trans_b=True, out=gw, residual=gw)
 
     def _zeros(self, *shape, dtype=F32):
         return torch.zeros(*shape, device=self.dev, dtype=dtype)
@@ -114,10 +107,10 @@ class Qwen2VLEngine:
         scale = hd ** -0.5
         cos, sin, segs, max_q = tape["cos"], tape["sin"], tape["segs"], tape["max_q"]
         # merger
-        d_g = K.gemm_nt(d_out, self.wT("merger.m2_w"))
+        d_g = self._dx(d_out, "merger.m2_w")
         self._dw(G["merger.m2_w"], d_out, tape["g"]); K.bias_grad_(d_out, G["merger.m2_b"])
         d_m1 = K.act_bwd(tape["m1"], d_g, K.SPACER_ACT_GELU_ERF)
-        d_hm4 = K.gemm_nt(d_m1, self.wT("merger.m0_w"))
+        d_hm4 = self._dx(d_m1, "merger.m0_w")
         self._dw(G["merger.m0_w"], d_m1, tape["hm4"]); K.bias_grad_(d_m1, G["merger.m0_b"])
         dx = self._empty(Np, D)
         K.layernorm_bwd(tape["x_last"], W["merger.ln_w"], d_hm4.view(Np, D), tape["mean"], tape["rstd"], dx,
@@ -127,14 +120,14 @@ class Qwen2VLEngine:
             p = f"vit.{i}."
             t = tape["blocks"][i]
             dyb = K.cast_bf16(dx)
-            d_a = K.gemm_nt(dyb, self.wT(p + "fc2_w"))
+            d_a = self._dx(dyb, p + "fc2_w")
             self._dw(G[p + "fc2_w"], dyb, t["a"]); K.bias_grad_(dyb, G[p + "fc2_b"])
             d_f1 = K.act_bwd(t["f1"], d_a, K.SPACER_ACT_QUICK_GELU)
-            d_h2 = K.gemm_nt(d_f1, self.wT(p + "fc1_w"))
+            d_h2 = self._dx(d_f1, p + "fc1_w")
             self._dw(G[p + "fc1_w"], d_f1, t["h2"]); K.bias_grad_(d_f1, G[p + "fc1_b"])
             K.layernorm_bwd(t["x_mid"], W[p + "n2_w"], d_h2, t["mean2"], t["rstd2"], dx, G[p + "n2_w"], G[p + "n2_b"])
             dyb = K.cast_bf16(dx)
-            d_o = K.gemm_nt(dyb, self.wT(p + "proj_w"))
+            d_o = self._dx(dyb, p + "proj_w")
             self._dw(G[p + "proj_w"], dyb, t["o"]); K.bias_grad_(dyb, G[p + "proj_b"])
             qkv = t["qkv"]
             d_qkv = torch.empty_like(qkv)
@@ -143,7 +136,7 @@ class Qwen2VLEngine:
                        scale, dq=d_qkv[:, :D], dk32=dk32, dv32=dv32)
             K.cast_bf16_strided(dk32, d_qkv[:, D:2 * D]); K.cast_bf16_strided(dv32, d_qkv[:, 2 * D:])
             K.rope_(d_qkv, cos, sin, 2 * Hh, hd, inverse=True)
-            d_h = K.gemm_nt(d_qkv, self.wT(p + "qkv_w"))
+            d_h = self._dx(d_qkv, p + "qkv_w")
             self._dw(G[p + "qkv_w"], d_qkv, t["h"]); K.bias_grad_(d_qkv, G[p + "qkv_b"])
             K.layernorm_bwd(t["x_in"], W[p + "n1_w"], d_h, t["mean1"], t["rstd1"], dx, G[p + "n1_w"], G[p + "n1_b"])
             tape["blocks"][i] = None
@@ -210,10 +203,10 @@ class Qwen2VLEngine:
         scale = hd ** -0.5
         cos, sin = tape["cos"], tape["sin"]
         d_merged = K.gather_rows(d_out, tape["unit_perm"])                   # out[i] = merged[rev[i]]  =>  d_merged[u] = d_out[perm[u]]
-        d_g = K.gemm_nt(d_merged, self.wT("merger.m2_w"))
+        d_g = self._dx(d_merged, "merger.m2_w")
         self._dw(G["merger.m2_w"], d_merged, tape["g"]); K.bias_grad_(d_merged, G["merger.m2_b"])
         d_m1 = K.act_bwd(tape["m1"], d_g, K.SPACER_ACT_GELU_ERF)
-        d_hm4 = K.gemm_nt(d_m1, self.wT("merger.m0_w"))
+        d_hm4 = self._dx(d_m1, "merger.m0_w")
         self._dw(G["merger.m0_w"], d_m1, tape["hm4"]); K.bias_grad_(d_m1, G["merger.m0_b"])
         dx = self._empty(Np, D)
         K.rmsnorm_bwd(tape["x_last"], W["merger.ln_w"], d_hm4.view(Np, D), tape["rstd"], dx, G["merger.ln_w"], accumulate=False)
@@ -222,14 +215,14 @@ class Qwen2VLEngine:
             p = f"vit.{i}."
             t = tape["blocks"][i]
             dyb = K.cast_bf16(dx)
-            d_a = K.gemm_nt(dyb, self.wT(p + "down_w"))
+            d_a = self._dx(dyb, p + "down_w")
             self._dw(G[p + "down_w"], dyb, t["a"]); K.bias_grad_(dyb, G[p + "down_b"])
             d_gu = K.swiglu_bwd(t["gu"], d_a)
-            d_h2 = K.gemm_nt(d_gu, self.wT(p + "gu_w"))
+            d_h2 = self._dx(d_gu, p + "gu_w")
             self._dw(G[p + "gu_w"], d_gu, t["h2"]); K.bias_grad_(d_gu, G[p + "gu_b"])
             K.rmsnorm_bwd(t["x_mid"], W[p + "n2_w"], d_h2, t["rstd2"], dx, G[p + "n2_w"])
             dyb = K.cast_bf16(dx)
-            d_o = K.gemm_nt(dyb, self.wT(p + "proj_w"))
+            d_o = self._dx(dyb, p + "proj_w")
             self._dw(G[p + "proj_w"], dyb, t["o"]); K.bias_grad_(dyb, G[p + "proj_b"])
             qkv = t["qkv"]
             d_qkv = torch.empty_like(qkv)
@@ -238,7 +231,7 @@ class Qwen2VLEngine:
                        scale, dq=d_qkv[:, :D], dk32=dk32, dv32=dv32)
             K.cast_bf16_strided(dk32, d_qkv[:, D:2 * D]); K.cast_bf16_strided(dv32, d_qkv[:, 2 * D:])
             K.rope_(d_qkv, cos, sin, 2 * Hh, hd, inverse=True)
-            d_h = K.gemm_nt(d_qkv, self.wT(p + "qkv_w"))
+            d_h = self._dx(d_qkv, p + "qkv_w")
             self._dw(G[p + "qkv_w"], d_qkv, t["h"]); K.bias_grad_(d_qkv, G[p + "qkv_b"])
             K.rmsnorm_bwd(t["x_in"], W[p + "n1_w"], d_h, t["rstd1"], dx, G[p + "n1_w"])
             tape["blocks"][i] = None
@@ -286,14 +279,14 @@ class Qwen2VLEngine:
             p = f"llm.{i}."
             t = tape[i]
             dyb = K.cast_bf16(dx)
-            d_a = K.gemm_nt(dyb, self.wT(p + "down_w"))
+            d_a = self._dx(dyb, p + "down_w")
             self._dw(G[p + "down_w"], dyb, t["a"])
             d_gu = K.swiglu_bwd(t["gu"], d_a)
-            d_h2 = K.gemm_nt(d_gu, self.wT(p + "gu_w"))
+            d_h2 = self._dx(d_gu, p + "gu_w")
             self._dw(G[p + "gu_w"], d_gu, t["h2"])
             K.rmsnorm_bwd(t["x_mid"], W[p + "ln2_w"], d_h2, t["rstd2"], dx, G[p + "ln2_w"])
             dyb = K.cast_bf16(dx)
-            d_o = K.gemm_nt(dyb, self.wT(p + "o_w"))
+            d_o = self._dx(dyb, p + "o_w")
             self._dw(G[p + "o_w"], dyb, t["o"])
             qkv = t["qkv"]
             d_qkv = torch.empty_like(qkv)
@@ -302,7 +295,7 @@ class Qwen2VLEngine:
                        True, scale, dq=d_qkv[:, :qd], dk32=dk32, dv32=dv32)
             K.cast_bf16_strided(dk32, d_qkv[:, qd:qd + kd]); K.cast_bf16_strided(dv32, d_qkv[:, qd + kd:])
             K.rope_(d_qkv, cos, sin, Hq + Hkv, D, inverse=True)
-            d_h = K.gemm_nt(d_qkv, self.wT(p + "qkv_w"))
+            d_h = self._dx(d_qkv, p + "qkv_w")
             self._dw(G[p + "qkv_w"], d_qkv, t["h"]); K.bias_grad_(d_qkv, G[p + "qkv_b"])
             K.rmsnorm_bwd(t["x_in"], W[p + "ln1_w"], d_h, t["rstd1"], dx, G[p + "ln1_w"])
             tape[i] = None
@@ -310,12 +303,17 @@ class Qwen2VLEngine:
         return dx
 
     # ================================================================== embeddings
-    def embed(self, ids: torch.Tensor, video: Optional[torch.Tensor]):
-        """ids int64 [T] (device); video bf16 [Nv, hidden] rows replace placeholder tokens in order."""
+    def embed(self, ids: torch.Tensor, video: Optional[torch.Tensor], n_placeholder_scope: Optional[int] = None):
+        """ids int64 [T] (device); video bf16 [Nv, hidden] rows replace placeholder tokens in order.  Only the first
+        ``n_placeholder_scope`` tokens (the prompt) can be placeholders: a SAMPLED completion token that happens to be
+        <|video_pad|> / <|image_pad|> (random-init policies do emit them) is an ordinary token with its own embedding row --
+        HF raises on the count mismatch there and the reference falls back to a text-only forward (TR:526-532)."""
         cfg = self.cfg
         vrow = None
         if video is not None:
             is_vis = (ids == cfg.video_token_id) | (ids == cfg.image_token_id)
+            if n_placeholder_scope is not None:
+                is_vis[n_placeholder_scope:] = False
             vrow = torch.where(is_vis, torch.cumsum(is_vis.int(), 0, dtype=torch.int32) - 1,
                                torch.full_like(ids, -1, dtype=torch.int32)).int().contiguous()
         return K.embed_fwd(ids, self.W["llm.embed"], video, vrow), vrow
@@ -340,7 +338,7 @@ class Qwen2VLEngine:
         vit_tape = {} if tape is not None else None
         video = self.vit_forward(pix, grids, vit_tape) if pix is not None else None
         ids = torch.cat([prompt_ids.reshape(-1), completion_ids.reshape(-1)])
-        x0, vrow = self.embed(ids, video)
+        x0, vrow = self.embed(ids, video, n_placeholder_scope=P)
         pos3, delta = POS.mrope_positions(prompt_ids.tolist(), list(grids or []), cfg, era_rule)
         comp_pos = (P + delta) + torch.arange(C)                       # same for every rollout
         pos_all = torch.cat([pos3] + [comp_pos.view(1, C).expand(3, C)] * Kn, dim=1)
@@ -401,7 +399,7 @@ class Qwen2VLEngine:
         T, H = tape["T"], cfg.hidden
         dlogits = K.logprob_bwd(tape["logits"], tape["targets"], tape["lse"], dlogp.reshape(-1).contiguous())
         tape["logits"] = None
-        d_hsel = K.gemm_nt(dlogits, self.wT("llm.lm_head"))
+        d_hsel = self._dx(dlogits, "llm.lm_head")
         self._dw(G["llm.lm_head"], dlogits, tape["hsel"])
         del dlogits
         d_hn32 = self._zeros(T, H)

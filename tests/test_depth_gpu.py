@@ -5,9 +5,10 @@ completions of 24 tokens.  The fp32 oracle (oracle/qwen2vl_fp32.py) runs the sam
 (forward ~5 s, autograd backward ~10 s) -- this is the quantity SG_RLVR_trainer.py:353-366 produces and the north-star pins.
 
 Tolerances (DESIGN.md section 4 has the per-operator table they come from):
-  * log-probs: the bf16-operand floor at 28 layers is rms 8.7e-3 / max 1.9e-2 (CPU emulation of the engine's rounding points,
-    scripts/logp_error_budget.py 2b); the reference's own bf16-eager numerics give rms 2.7e-2 / max 5.7e-2.  Asserted:
-    rms <= 1.3e-2 and max <= 3.5e-2 (the floor with margin for its token-to-token scatter), i.e. at least 2x inside the reference path.
+  * log-probs: the bf16-operand floor at 28 layers is rms ~1e-2 / max ~2-3e-2 (CPU emulation of the engine's rounding points,
+    oracle/qwen2vl_engine_emul.py; scripts/logp_error_budget.py 2b: 8.7e-3 / 1.9e-2 on its sample); the reference's own
+    bf16-eager numerics give rms 2.7e-2 / max 5.7e-2.  Asserted: the engine's rms error <= 1.5x the emulation's rms error ON THE
+    SAME TOKENS (the emulation runs on the host beside the oracle), and the absolute caps rms <= 2e-2, max <= 5e-2.
     The north-star's 1e-3 needs hi+lo operand pairs on EVERY matmul operand incl. attention (emulated: 5e-5), i.e. 2-3x the
     MFMA work; not built.
   * gradients of selected tensors (first / middle / last decoder layer, the tied embedding table, final norm, first / last
@@ -67,6 +68,11 @@ def test_logps_and_gradients_match_oracle_at_2b_depth(depth):
     (want * dlogp).sum().backward()
     t_oracle = time.time() - t0
     want = want.detach()
+    from oracle import qwen2vl_engine_emul as E
+    with torch.no_grad():
+        emu = E.completion_logps(d["w"], d["ocfg"], pr.ids.cpu(), comps.cpu(), d["rows"], [d["grid"]])
+    e_emu = emu - want
+    rms_emu = float(e_emu.pow(2).mean().sqrt())
     # ---- engine
     G = params.like(torch.float32)
     tape = {}
@@ -75,10 +81,11 @@ def test_logps_and_gradients_match_oracle_at_2b_depth(depth):
     err = lp.cpu() - want
     rms, mx = float(err.pow(2).mean().sqrt()), float(err.abs().max())
     print(f"Qwen2-VL-2B depth: |logp - fp32 oracle| rms {rms:.2e} max {mx:.2e} over {err.numel()} tokens "
-          f"(logp range [{float(want.min()):.2f}, {float(want.max()):.2f}]); oracle fwd+bwd {t_oracle:.1f} s on the host")
+          f"(logp range [{float(want.min()):.2f}, {float(want.max()):.2f}]); emulated rounding points rms {rms_emu:.2e} max "
+          f"{float(e_emu.abs().max()):.2e}; oracle fwd+bwd {t_oracle:.1f} s on the host")
     assert torch.isfinite(lp).all()
-    assert rms <= 1.3e-2, rms
-    assert mx <= 3.5e-2, mx
+    assert rms <= 1.5 * rms_emu + 1e-3, (rms, rms_emu)
+    assert rms <= 2e-2 and mx <= 5e-2, (rms, mx)
     got = export_state_dict(G)
     got["visual.patch_embed.proj.weight"] = got["visual.patch_embed.proj.weight"].reshape(d["cfg"].vit_dim, -1)
     bad = []

@@ -95,6 +95,26 @@ def test_logps_sit_at_the_bf16_operand_floor(setup):
     assert rms(e_eng) <= 1.5e-3
 
 
+def test_sampled_placeholder_ids_are_plain_tokens(setup):
+    """A random-init policy does sample <|video_pad|> / <|image_pad|> as completion tokens.  They are ordinary tokens there
+    (own embedding row; only the prompt's placeholders take ViT rows): forward, backward and the ViT-gradient row count stay
+    consistent, and the log-probs before the injected position are untouched (causality)."""
+    s, g = setup, setup["g"]
+    dev = s["pix"].device
+    cfg = s["cfg"]
+    comps = g["completions"].clone()
+    base = s["eng"].score_group(g["prompt"].to(dev), comps.to(dev), s["pix"], [s["grid"]])
+    comps[1, 3] = cfg.video_token_id
+    comps[2, 0] = cfg.image_token_id
+    tape = {}
+    lp = s["eng"].score_group(g["prompt"].to(dev), comps.to(dev), s["pix"], [s["grid"]], tape=tape)
+    assert torch.isfinite(lp).all()
+    assert torch.equal(lp[0], base[0]) and torch.equal(lp[1, :3], base[1, :3])
+    G = s["params"].like(torch.float32)
+    s["eng"].backward_group(tape, torch.ones_like(lp), G)
+    assert torch.isfinite(G.flat).all() and float(G["vit.patch_w"].abs().max()) > 0
+
+
 def test_backward_matches_oracle_autograd(setup):
     s, g = setup, setup["g"]
     dev = s["pix"].device

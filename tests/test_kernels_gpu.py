@@ -94,6 +94,56 @@ def test_gemm_split_k_tail(dev, M, N, Kd):
     assert_close(g1, g0, 1e-3, 1e-4, "split vs unsplit")
 
 
+@pytest.mark.parametrize("M,N,Kd", [(512, 768, 256), (5498, 3584, 4608), (300, 1280, 3840), (77, 1216, 320), (1040, 256, 5120),
+                                    (4096, 3584, 1024), (1, 512, 64)])
+def test_gemm_trans_b_is_dx(dev, M, N, Kd):
+    """dX = dY . W with W read in place ([out, in] = [K, N], trans_b): same bits as the NT kernel on an explicit W^T copy
+    (same MFMA sequence, same accumulation order), and close to the fp32 product."""
+    dy, w = rnd((M, Kd), dev, 11, 0.5), rnd((Kd, N), dev, 12, 0.1)
+    w[0] += 1.0                                                     # asymmetric: a transposed read would show
+    got = K.gemm(dy, w, trans_b=True)
+    ref = K.gemm_nt(dy, w.t().contiguous())
+    from spacer_amd import _lib
+    if _lib.load().spacer_gemm_tile(M, N, Kd, 1) == 256:           # same tile, same split plan -> the same bits
+        assert torch.equal(got, ref), f"trans_b differs from NT-on-transposed: max {float((got.float() - ref.float()).abs().max())}"
+    else:                                                          # the NT call ran on the 128 tile: fp32 summation order may differ
+        assert_close(got, ref, atol=2e-2, rtol=1e-2, what="dX vs NT (128 tile)")
+    assert_close(got, dy.float() @ w.float(), atol=0.05, rtol=2e-2, what=f"dX {M}x{N}x{Kd}")
+
+
+@pytest.mark.parametrize("T,Nout,Kin", [(256, 512, 768), (5498, 4608, 3584), (4160, 3840, 1280), (333, 256, 1216), (64, 1280, 320),
+                                        (1, 8, 8), (70, 264, 72), (2100, 3584, 1536)])
+def test_gemm_trans_ab_is_dw(dev, T, Nout, Kin):
+    """dW[out, in] += dY[T, out]^T . X[T, in], both operands contraction-major and read in place; T (the contraction length) is
+    ragged -- the kernel masks the last K tile.  Compared with the fp32 product and, bit for bit, with the old route (two
+    zero-padded transposes + the NT kernel)."""
+    dy, x = rnd((T, Nout), dev, 13, 0.5), rnd((T, Kin), dev, 14, 0.5)
+    dy[0] += 1.0
+    acc0 = rnd((Nout, Kin), dev, 15, dtype=torch.float32)
+    got = K.gemm(dy, x, trans_a=True, trans_b=True, out=acc0.clone(), residual=None)
+    want = dy.float().t() @ x.float()
+    assert_close(got, want, atol=0.02 * math.sqrt(T) * 0.3 + 0.02, rtol=1e-2, what=f"dW {Nout}x{Kin}x{T}")
+    # accumulate form (what the engine calls) vs the transpose route
+    acc = acc0.clone()
+    K.gemm(dy, x, trans_a=True, trans_b=True, out=acc, residual=acc)
+    old = acc0.clone()
+    dyt, xt = K.transpose_pad(dy), K.transpose_pad(x)
+    K.gemm_nt(dyt, xt, out=old, residual=old)
+    from spacer_amd import _lib
+    if _lib.load().spacer_gemm_tile(Nout, Kin, dyt.shape[1], 1) == 256 and dyt.shape[1] // 64 == (T + 63) // 64:
+        assert torch.equal(acc, old), f"in-place dW differs from the transpose route: max {float((acc - old).abs().max())}"
+    else:
+        assert_close(acc, old, atol=1e-3, rtol=1e-4, what="dW vs transpose route (128 tile)")
+
+
+def test_gemm_trans_rejects_unsupported(dev):
+    a, b = rnd((64, 128), dev, 1), rnd((64, 100), dev, 2)
+    with pytest.raises(K.SpacerError):
+        K.gemm(a, b, trans_a=True, trans_b=True)          # N = 100 is not a multiple of 8
+    with pytest.raises(K.SpacerError):
+        K.gemm(rnd((128, 100), dev, 3), rnd((100, 64), dev, 4), trans_b=True)   # trans_b alone needs K % 64 == 0
+
+
 def test_gemm_rejects_bad_k(dev):
     a, b = rnd((64, 96), dev, 1), rnd((64, 96), dev, 2)
     with pytest.raises(K.SpacerError):
@@ -413,6 +463,26 @@ def test_patchify_matches_hf_golden(dev):
 
 
 # ----------------------------------------------------------------------------------------------- loss
+@pytest.mark.parametrize("H,W", [(480, 640), (720, 1280), (448, 448), (60, 80), (100, 100)])
+def test_resize_bicubic_antialias_matches_torch(dev, H, W):
+    """GPU front end (QU:310-315): spacer_resize_bicubic_aa_u8 against torch's antialiased bicubic on the CPU + torchvision's uint8
+    rounding (vision_process.resize_frames), at the target size the reference's smart_resize picks for the source.  Integer
+    output: equal except where the fp32 sum lands within round-off of a .5 tie (bounded: < 1e-4 of the pixels, never by more
+    than 1 level); the kernel chain resize -> patchify equals the CPU resize -> oracle patchify on all other rows."""
+    from spacer_amd.qwen_vl_utils import vision_process as VP
+    frames = torch.randint(0, 256, (6, 3, H, W), generator=torch.Generator().manual_seed(H * 7 + W), dtype=torch.uint8)
+    _, hw, _ = VP.plan_video({}, 300, 30, H, W)
+    want = VP.resize_frames(frames, hw)                                   # CPU, float values on the uint8 grid
+    got = VP.resize_frames_gpu(frames.to(dev), hw)
+    assert got.dtype == torch.uint8 and tuple(got.shape) == (6, 3) + tuple(hw)
+    diff = (got.cpu().float() - want).abs()
+    assert float(diff.max()) <= 1.0 and float((diff > 0).float().mean()) < 1e-4, (float(diff.max()), float((diff > 0).float().mean()))
+    # frame sampling gather (QU:252) is exact
+    idx = torch.tensor(VP.frame_indices(6, 4), dtype=torch.int32)
+    if (3 * H * W) % 16 == 0:
+        assert torch.equal(K.gather_frames(frames.to(dev), idx.to(dev)).cpu(), frames[idx.long()])
+
+
 def test_logprob(dev):
     rows, V = 33, 152064 // 16 + 3
     lgp = torch.zeros(rows, (V + 3) // 4 * 4, device=dev)      # row stride must be a multiple of 4 floats
