@@ -43,6 +43,10 @@ struct GemmArgs {
     // act[m, tn*128 + c] = silu(gate) * up into C (bf16 [M, I]); gate|up themselves go to C2 (bf16 [M, 2I]) when it is given.
     int swiglu_inter;
     void* C2; long ldc2;
+    // contraction-major operands with a ragged K: global K tile `k_tail_tile` (the last one) is staged from zero-padded
+    // 64-row copies of the operands' last K % 64 rows (same row strides lda / ldb); -1 = none
+    int k_tail_tile;
+    const bf16_t* A_tail; const bf16_t* B_tail;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -258,10 +262,26 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N == 4) ? 2
 
 #include "gemm_halftile.h"
 
+// dst[64][ld] = rows r0 .. r0+nrows-1 of src (row stride ld, `cols` valid columns), zero-filled below: the K tail tile of a
+// contraction-major operand
+__global__ __launch_bounds__(256) void gemm_tail_rows_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, long ld, int cols,
+                                                             int r0, int nrows) {
+    const int per = cols >> 3;
+    const long total = 64L * per;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / per), c = (int)(i % per) * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r < nrows) v = *(const uint4*)(src + (long)(r0 + r) * ld + c);
+        *(uint4*)(dst + (long)r * ld + c) = v;
+    }
+}
+
 }  // namespace
 
 // ---- launch planning --------------------------------------------------------------------------------------------
 constexpr long WS_SLAB_BYTES = 256L * 256 * 4, WS_MAX_SLABS = 256;
+constexpr long WS_TAIL_ELEMS = 384L * 1024;          // lda + ldb of a ragged-K contraction-major launch (64 rows each, bf16)
+constexpr long WS_TAIL_BYTES = WS_TAIL_ELEMS * 64 * 2;
 
 // Tail split of the 256-tile kernel: the tiles of the last, partially filled round of the 256 CUs are each cut into
 // `splits` K ranges (<= 256 blocks in total, >= 16 K tiles per range: below that the slab round trip costs more than
@@ -294,7 +314,7 @@ static int choose_tile(int M, int N, int K, bool have_ws) {
     return cost256 <= cost128 ? 256 : 128;
 }
 
-extern "C" long spacer_gemm_workspace_bytes(void) { return WS_MAX_SLABS * WS_SLAB_BYTES; }
+extern "C" long spacer_gemm_workspace_bytes(void) { return WS_MAX_SLABS * WS_SLAB_BYTES + WS_TAIL_BYTES; }
 
 extern "C" int spacer_gemm_tile(int M, int N, int K, int have_workspace) { return choose_tile(M, N, K, have_workspace != 0); }
 
@@ -310,6 +330,7 @@ static int launch_gemm(const void* A, long lda, const void* B, long ldb, void* C
     SP_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, SPACER_EINVAL, "gemm: A/B must be 16-byte aligned");
     GemmArgs g;
     g.swiglu_inter = 0; g.C2 = nullptr; g.ldc2 = 0;
+    g.k_tail_tile = -1; g.A_tail = nullptr; g.B_tail = nullptr;
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.bias = epi ? (const bf16_t*)epi->bias : nullptr;
@@ -326,6 +347,18 @@ static int launch_gemm(const void* A, long lda, const void* B, long ldb, void* C
     // the contraction-major operand forms exist on the 256 tile only
     const bool big = tb || choose_tile(M, N, K, have_ws) == 256;
     hipStream_t s = (hipStream_t)stream;
+    if (ta && K % BK != 0) {
+        // ragged contraction length: the last K % 64 rows of both operands go to zero-padded 64-row tail buffers
+        SP_REQUIRE(have_ws, SPACER_EINVAL, "gemm: trans_a with K=%d not a multiple of %d needs the workspace", K, BK);
+        SP_REQUIRE(lda + ldb <= WS_TAIL_ELEMS && M <= lda && N <= ldb, SPACER_EINVAL, "gemm: lda + ldb = %ld exceeds the K-tail workspace (%ld)",
+                   lda + ldb, WS_TAIL_ELEMS);
+        bf16_t* ta_buf = (bf16_t*)((char*)epi->workspace + WS_MAX_SLABS * WS_SLAB_BYTES);
+        bf16_t* tb_buf = ta_buf + 64 * lda;
+        const int r0 = K / BK * BK, nr = K - r0;
+        hipLaunchKernelGGL(gemm_tail_rows_kernel, dim3(cdiv(64L * (M / 8), 256)), dim3(256), 0, s, (const bf16_t*)A, ta_buf, lda, M, r0, nr);
+        hipLaunchKernelGGL(gemm_tail_rows_kernel, dim3(cdiv(64L * (N / 8), 256)), dim3(256), 0, s, (const bf16_t*)B, tb_buf, ldb, N, r0, nr);
+        g.k_tail_tile = K / BK; g.A_tail = ta_buf; g.B_tail = tb_buf;
+    }
     if (big) {
         constexpr int LDS = 8 * 128 * BK * 2;
         static const int once = hipFuncSetAttribute((const void*)gemm_bf16_nt_256h_kernel<true>,
@@ -388,6 +421,7 @@ extern "C" int spacer_gemm_swiglu_bf16(const void* A, long lda, const void* W, l
     g.lda = lda; g.ldb = ldb; g.ldc = ld_act; g.M = M; g.N = 2 * inter; g.K = K;
     g.bias = (const bf16_t*)bias; g.resid = nullptr; g.ldr = 0; g.out_f32 = 0; g.act = SPACER_ACT_NONE; g.alpha = 1.f;
     g.swiglu_inter = inter; g.C2 = gu; g.ldc2 = ld_gu;
+    g.k_tail_tile = -1; g.A_tail = nullptr; g.B_tail = nullptr;
     g.tiles_m = cdiv(M, 256); g.tiles_n = inter / 128;
     g.full_tiles = g.tiles_m * g.tiles_n; g.splits = 1; g.slabs = nullptr;      // no K-split tail: the reduce kernel has no SwiGLU form
     constexpr int LDS = 8 * 128 * BK * 2;

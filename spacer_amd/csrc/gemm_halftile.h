@@ -32,8 +32,9 @@
 // contraction slots k = kk*32 + (lane>>4)*8 + 0..7 of a 16x16x32 operand, the same slot order as the plain image, so the two
 // layouts mix freely).  Bank swizzle of that image: the 32-byte column pair index ^= (row & 3) | ((row >> 3) & 1) << 2 -- the 8
 // rows a 32-lane group touches in one read ({r..r+3} and {r+8..r+11}) land on 8 distinct 32-byte bank groups.
-// A ragged contraction length (dW: K = tokens) is handled in the kernel: rows >= K are fetched from row K-1 (in bounds)
-// and the A fragments of the last K tile are masked to zero slot by slot.
+// A ragged contraction length (dW: K = tokens) costs nothing in the loop: the host copies the last K % 64 rows of both operands
+// into zero-padded 64-row tail buffers (caller's workspace) and the kernel stages that one K tile from them (a scalar
+// base-pointer select per DMA).
 #include <type_traits>
 
 // pid (position in the launch's tile order) -> tile coordinates: groups of 4 tile-rows walked column by column, so the
@@ -85,9 +86,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
     const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- DMA sources: this wave owns pieces (wave*2 + i), i = 0..1, of every half-tile image.
-    // plain image: piece = 8 rows x 128 B;  contraction-major image: piece = 4 k-rows x 256 B
+    // plain image: piece = 8 rows x 128 B;  contraction-major image: piece = 4 k-rows x 256 B.  32-bit element offsets
+    // relative to a per-K-tile scalar base (plain: + k0 elements; contraction-major: + k0 rows).
     unsigned offA[2][2], offB[2][2];                   // [half][piece] element offsets of this lane's 16-byte chunk
-    int krT[2];                                        // contraction-major: k-row (inside the K tile) of piece i
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -100,8 +101,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
             if (TA) {
                 int m = m0 + (lc >> 3) * 128 + h * 64 + (lc & 7) * 8;         // first of 8 consecutive tile rows
                 m = m + 8 <= g.M ? m : g.M - 8;
-                offA[h][i] = (unsigned)m;
-                krT[i] = kr;
+                offA[h][i] = (unsigned)((long)kr * g.lda + m);
             } else {
                 int ra = m0 + (hr >> 6) * 128 + h * 64 + (hr & 63);
                 ra = ra < g.M ? ra : g.M - 1;
@@ -110,8 +110,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
             if (TB) {
                 int n = n0 + (lc >> 2) * 64 + h * 32 + (lc & 3) * 8;          // first of 8 consecutive tile columns
                 n = n + 8 <= g.N ? n : g.N - 8;
-                offB[h][i] = (unsigned)n;
-                krT[i] = kr;
+                offB[h][i] = (unsigned)((long)kr * g.ldb + n);
             } else {
                 const int lcol = (hr >> 5) * 64 + h * 32 + (hr & 31);        // tile column this B row produces
                 int rb = n0 + lcol;
@@ -122,18 +121,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
         }
     const int nt = ntl;                                 // K tiles of THIS block: global tiles kt0 .. kt0+nt-1
     auto stage = [&](int par, int which, int t) {
-        const int k0 = (kt0 + (t < nt ? t : nt - 1)) * BK;
+        const int kt = kt0 + (t < nt ? t : nt - 1);     // global K tile (wave-uniform)
         char* dst = smem + (par * 4 + which) * HALF + wave * 2048;
+        const bf16_t* base;                             // scalar base of this K tile
+        if (which < 2) base = TA ? (kt == g.k_tail_tile ? g.A_tail : g.A + (long)kt * BK * g.lda) : g.A + kt * BK;
+        else base = TB ? (kt == g.k_tail_tile ? g.B_tail : g.B + (long)kt * BK * g.ldb) : g.B + kt * BK;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const bf16_t* src;
-            if (which < 2) {
-                if (TA) src = g.A + (long)min(k0 + krT[i], g.K - 1) * g.lda + offA[which & 1][i];
-                else src = g.A + offA[which & 1][i] + k0;
-            } else {
-                if (TB) src = g.B + (long)min(k0 + krT[i], g.K - 1) * g.ldb + offB[which & 1][i];
-                else src = g.B + offB[which & 1][i] + k0;
-            }
+            const bf16_t* src = base + ((which < 2) ? offA[which & 1][i] : offB[which & 1][i]);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
         }
@@ -156,10 +151,16 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
     for (int i = 0; i < 4; ++i) toA[i] = tlane + (((wr * 4 + i) ^ hx) << 5);
 #pragma unroll
     for (int j = 0; j < 2; ++j) toB[j] = tlane + (((wc * 2 + j) ^ hx) << 5);
+    // Issued as inline asm: the ds_read_tr16 builtin makes hipcc drain the LDS-DMA queue (s_waitcnt vmcnt(0)) in front of
+    // every read -- it cannot tell the read from the in-flight global_load_lds writes of OTHER images -- which serialises the
+    // whole pipeline.  The asm form is invisible to that pass; its completion is covered by the explicit lgkmcnt(0) that
+    // already precedes each MFMA segment (and the sched_barriers around it), the only consumers of these registers.
     auto frag_t16 = [&](const char* p) -> bf16x8 {
-        const gemm_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) gemm_s16x4*)p);
-        const gemm_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) gemm_s16x4*)(p + 1024));
-        const gemm_s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+        u32x2_t lo, hi;
+        const unsigned addr = (unsigned)(uintptr_t)p;
+        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:1024" : "=&v"(lo), "=&v"(hi) : "v"(addr));
+        const uint4 both = make_uint4(lo[0], lo[1], hi[0], hi[1]);
         return __builtin_bit_cast(bf16x8, both);
     };
     auto fragA = [&](const char* img, int i, int kk) -> bf16x8 {
@@ -170,21 +171,6 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
         if (TB) return frag_t16(img + toB[j] + kk * 8192);
         return *(const bf16x8*)(img + boff + j * 2048 + (kk ? fo1 : fo0));
     };
-    // ragged contraction length (TA only): slot s of lane group tg in k-step kk is contraction row kk*32 + tg*8 + s of the
-    // tile; in the last K tile rows >= krem are zeroed in the A fragments (B rows there are finite duplicates of row K-1)
-    const int krem = g.K - (kt0 + nt - 1) * BK;                              // valid k-rows of this block's last tile (1..64)
-    auto mask_a = [&](bf16x8& v, int kk) {
-        const int base = kk * 32 + tg * 8;
-        uint4 u = __builtin_bit_cast(uint4, v);
-        unsigned* w = (unsigned*)&u;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            const unsigned lo_ok = base + 2 * d < krem ? 0x0000ffffu : 0u, hi_ok = base + 2 * d + 1 < krem ? 0xffff0000u : 0u;
-            w[d] &= (lo_ok | hi_ok);
-        }
-        v = __builtin_bit_cast(bf16x8, u);
-    };
-
     f32x4 acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -227,12 +213,6 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
                 for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) a[i][kk] = fragA(img + A_LO * HALF, i, kk);
-                if (TA && krem < BK && t == nt - 1) {
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) mask_a(a[i][kk], kk);
-                }
             } else if (p == 1) {
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk)
@@ -243,12 +223,6 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
                 for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) a[i][kk] = fragA(img + A_HI * HALF, i, kk);
-                if (TA && krem < BK && t == nt - 1) {
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) mask_a(a[i][kk], kk);
-                }
             } else if (BALANCED) {                                           // next tile's B-lo (waited for in phase 2)
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk)

@@ -149,10 +149,13 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, trans_b: bo
     check(_lib.load().spacer_gemm_bf16(_ptr(a), _rowmajor(a), _ptr(b), _rowmajor(b), _ptr(out), _rowmajor(out), M, N, Kc,
                                        int(trans_a), int(trans_b), C.byref(epi), _stream()), "gemm_bf16")
     if t0 is not None:
-        PROFILER.end("gemm_bf16_nt_256h_kernel", t0, 2.0 * M * N * Kc, 2.0 * (M * Kc + N * Kc) + out.element_size() * M * N)
+        # rocprof names the three instantiations <BALANCED, TA, TB>: <true, false, false> is the forward (NT) one
+        name = "gemm_bf16_nt_256h_kernel<true, true, true>" if trans_a else "gemm_bf16_nt_256h_kernel<true, false, true>"
+        rmw = out.element_size() * M * N if residual is not None else 0
+        PROFILER.end(name, t0, 2.0 * M * N * Kc, 2.0 * (M * Kc + N * Kc) + out.element_size() * M * N + rmw)
         if PROFILER.by_shape:
             s0, e0 = PROFILER.records[-1][1], PROFILER.records[-1][2]
-            PROFILER.records.append((f"gemm{'T' if trans_a else 'N'}{'T' if trans_b else 'N'}[{M}x{N}x{Kc}]", s0, e0, 2.0 * M * N * Kc, 0.0))
+            PROFILER.records.append((f"gemm[{'dW' if trans_a else 'dX'} {M}x{N}x{Kc}]", s0, e0, 2.0 * M * N * Kc, 0.0))
     return out
 
 

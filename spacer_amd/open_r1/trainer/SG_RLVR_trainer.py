@@ -195,6 +195,9 @@ class SGRLVRTrainer:
         self.len_control = bool(self.script_args.len_control)
         self.beta = args.beta
         self.era_rule = bool(getattr(self.script_args, "mrope_era_rule", True))
+        # video rows: resize + patchify on the GPU (libspacer_hip) when the processor exposes its tokenizer; SPACER_FRONTEND=hf
+        # keeps the reference's CPU route (torch resize + HF processor patchify) for A/B runs
+        self.native_frontend = os.environ.get("SPACER_FRONTEND", "native") != "hf"
         self.train_dataset, self.eval_dataset = train_dataset, eval_dataset
         n_rows = len(train_dataset) if train_dataset is not None else 0
         per_step = max(1, self.world * args.per_device_train_batch_size * args.gradient_accumulation_steps)
@@ -217,6 +220,8 @@ class SGRLVRTrainer:
             print("[spacer_amd] " + msg, flush=True)
 
     def _prompt_input(self, proc_out: dict) -> PromptInput:
+        if proc_out.get("native"):
+            return self._prompt_input_native(proc_out)
         ids = proc_out["input_ids"]
         if self.max_prompt_length is not None:                 # TR:432-440 (left truncation of ids)
             ids = ids[:, -self.max_prompt_length:]
@@ -234,6 +239,53 @@ class SGRLVRTrainer:
         if sec is not None:
             sec = [float(v) for v in (sec.tolist() if hasattr(sec, "tolist") else sec)]
         return PromptInput(ids=ids, pix=pix, grids=grids, second_per_grid_ts=sec)
+
+    def _prompt_input_native(self, nat: dict) -> PromptInput:
+        """GPU front end: sampled uint8 frames -> (H2D) -> bicubic-antialias resize -> rescale / normalise / patchify, all in
+        libspacer_hip (spacer_resize_bicubic_aa_u8 + spacer_patchify = K1) instead of torchvision + the HF processor on the CPU
+        (QU:310-315, TR:417-425).  ``perm``: the T-GRPO twin's temporal shuffle (TR:442-458), applied to the resized frames."""
+        from ... import kernels as K
+        from ...qwen_vl_utils.vision_process import resize_frames_gpu
+        cfg = self.cfg
+        frames = nat["frames_u8"].to(self.device, non_blocking=True)
+        if tuple(frames.shape[2:]) != tuple(nat["hw"]):
+            frames = resize_frames_gpu(frames, nat["hw"])
+        if nat.get("perm") is not None:
+            frames = frames[nat["perm"].to(self.device)].contiguous()
+        pix, grid = K.patchify(frames, cfg.patch, cfg.tpatch, cfg.merge, cfg.patch_kpad)
+        assert tuple(grid) == tuple(nat["grid"]), (grid, nat["grid"])
+        ids = nat["input_ids"]
+        if self.max_prompt_length is not None:
+            ids = ids[:, -self.max_prompt_length:]
+        return PromptInput(ids=ids[0].to(self.device).long(), pix=pix, grids=[tuple(grid)], second_per_grid_ts=nat.get("second_per_grid_ts"))
+
+    def _prepare_native(self, inputs, prompts_text, conv, shuffle_seed: int) -> Optional[dict]:
+        """Host half of the GPU front end for a video row: frame sampling plan + tokenisation with the placeholder expanded
+        to the number of merged video tokens (what the HF processor does before it tokenises).  None -> use the processor."""
+        from ...qwen_vl_utils.vision_process import sample_video
+        tok = getattr(self.processing_class, "tokenizer", None)
+        part = conv[0]["content"][0]
+        if tok is None or not self.native_frontend or len(prompts_text) != 1 or prompts_text[0].count("<|video_pad|>") != 1:
+            return None
+        got = sample_video(part)
+        if got is None:
+            return None
+        frames, hw, _ = got
+        cfg = self.cfg
+        gt = (frames.shape[0] + cfg.tpatch - 1) // cfg.tpatch
+        grid = (gt, hw[0] // cfg.patch, hw[1] // cfg.patch)
+        nv = grid[0] * grid[1] * grid[2] // (cfg.merge ** 2)
+        text = prompts_text[0].replace("<|video_pad|>", "<|video_pad|>" * nv)
+        ids = tok([text], add_special_tokens=False)["input_ids"]
+        ids = torch.as_tensor(ids, dtype=torch.long).view(1, -1)
+        assert int((ids == cfg.video_token_id).sum()) == nv, "tokenizer did not keep one id per <|video_pad|>"
+        sec = [cfg.tpatch / 2.0] if cfg.vit_kind == "qwen2_5" else None     # HF video processor default fps 2.0, no fps passed (TR:417-425)
+        main = dict(native=True, input_ids=ids, frames_u8=frames, hw=hw, grid=grid, second_per_grid_ts=sec)
+        twin = None
+        if self.temporal:
+            perm = torch.randperm(frames.shape[0], generator=torch.Generator().manual_seed(shuffle_seed))
+            twin = dict(main, perm=perm)
+        return dict(proc=main, sproc=twin, has_video=True)
 
     def _run_rewards(self, inputs, prompts, completion_ids, n, video_path=None) -> torch.Tensor:
         """TR:576-593 (and the shuffled twin :554-572): decode, wrap, call every reward function."""
@@ -264,6 +316,10 @@ class SGRLVRTrainer:
         conv = remove_none_from_data(copy.deepcopy(inputs[0]["prompt"]))
         if inputs[0]["data_type"] in ("image", "video"):
             conv[0]["content"][0][inputs[0]["data_type"]] = inputs[0]["path"]
+        if inputs[0]["data_type"] == "video":
+            nat = self._prepare_native(inputs, prompts_text, conv, shuffle_seed)
+            if nat is not None:
+                return nat
         image_inputs, video_inputs, _ = process_vision_info(conv, return_video_kwargs=True)
         call = dict(return_tensors="pt", padding=True, padding_side="left", add_special_tokens=False)
         proc = self.processing_class(text=copy.deepcopy(prompts_text), images=image_inputs, videos=video_inputs, **call)

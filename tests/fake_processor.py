@@ -5,12 +5,37 @@ import torch
 from oracle import qwen2vl_fp32 as O
 
 
+class FakeTokenizer:
+    """``processor.tokenizer`` surface: text with special markers -> ids, one id per <|video_pad|> / <|image_pad|>."""
+
+    def __init__(self, proc):
+        self.p = proc
+
+    def __call__(self, text, add_special_tokens=False):
+        import re
+        cfg = self.p.cfg
+        special = {"<|vision_start|>": cfg.vision_start_id, "<|vision_end|>": cfg.vision_end_id,
+                   "<|video_pad|>": cfg.video_token_id, "<|image_pad|>": cfg.image_token_id}
+        out = []
+        for t in text:
+            ids = []
+            for piece in re.split(r"(<\|vision_start\|>|<\|vision_end\|>|<\|video_pad\|>|<\|image_pad\|>)", t):
+                if piece in special:
+                    ids.append(special[piece])
+                else:
+                    ids += [self.p._tok(w) for w in piece.split()]
+            out.append(ids)
+        return {"input_ids": out}
+
+
 class FakeProcessor:
-    def __init__(self, cfg):
+    def __init__(self, cfg, with_tokenizer: bool = True):
         self.cfg = cfg
         self.eos_token_id = cfg.eos_token_id
         self.pad_token_id = cfg.pad_token_id
         self.ocfg = cfg.as_oracle_dict()
+        if with_tokenizer:
+            self.tokenizer = FakeTokenizer(self)
 
     def _tok(self, word):
         return 10 + (sum(ord(c) * (i + 1) for i, c in enumerate(word)) % 900)

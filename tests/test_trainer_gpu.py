@@ -170,3 +170,29 @@ def test_resume_skips_consumed_steps_and_restores_optimizer(dev, tmp_path, monke
     a, b = full.engine.policy.flat.float(), res.engine.policy.flat.float()
     assert float((a - b).abs().max()) <= 2e-3 * float(a.abs().max())
     assert float((full.engine.m - res.engine.m).abs().max()) <= 1e-2 * float(full.engine.m.abs().max()) + 1e-8
+
+
+def test_gpu_front_end_equals_the_processor_route(dev, tmp_path):
+    """Video rows: frames sampled -> resized on the GPU (spacer_resize_bicubic_aa_u8) -> K1 patchify, against the reference's
+    route (torch bicubic-antialias resize on the CPU + the processor's patchify): same token ids, same grid, and the same
+    bf16 pixel rows except where the GPU resize rounds a .5 tie the other way (< 1e-3 of the values, one uint8 level)."""
+    g = load_tiny()
+    params = FlatParams.empty(TINY, dev)
+    load_state_dict(params, g["w"])
+    frames = torch.randint(0, 256, (40, 3, 120, 160), generator=torch.Generator().manual_seed(77), dtype=torch.uint8)
+    row = dict(prompt=[{"role": "user", "content": [{"type": "video"}, {"type": "text", "text": "what moves ?"}]}],
+               path=frames, data_type="video", problem_type="multiple choice", solution="<answer>A</answer>", problem_id=0,
+               options=["A. x", "B. y"], data_source="other")
+    args = GRPOConfig(output_dir=str(tmp_path), max_completion_length=4, num_generations=2, max_steps=1, save_steps=0)
+    common = dict(model=params, reward_funcs=[format_reward], args=args, script_args=GRPOScriptArguments(temporal=True),
+                  train_dataset=[row], device=dev)
+    nat = SGRLVRTrainer(processing_class=FakeProcessor(TINY), **common)
+    ref = SGRLVRTrainer(processing_class=FakeProcessor(TINY, with_tokenizer=False), **common)
+    pa, pb = nat._prepare([row], 5), ref._prepare([row], 5)
+    assert pa["proc"].get("native") and not (hasattr(pb["proc"], "get") and pb["proc"].get("native"))
+    for key in ("proc", "sproc"):
+        a, b = nat._prompt_input(pa[key]), ref._prompt_input(pb[key])
+        assert torch.equal(a.ids, b.ids) and list(a.grids) == list(b.grids)
+        d = (a.pix.float() - b.pix.float()).abs()
+        assert float((d > 0).float().mean()) < 1e-3 and float(d.max()) < 0.08, (float((d > 0).float().mean()), float(d.max()))
+    assert not torch.equal(nat._prompt_input(pa["proc"]).pix, nat._prompt_input(pa["sproc"]).pix)      # the twin is shuffled
