@@ -123,15 +123,34 @@ def cpu_baseline(cfg, workload):
             "cpu_gemm_rate_gflops": round(1e3 * cpu_gemm_rate(cfg), 1)}
 
 
-def pmc_traffic(workload: str):
-    """L2-miss (fabric/HBM side) bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_gemm_pmc.json: FETCH_SIZE doubled + WRITE_SIZE, KiB -> bytes, weighted by the cfg3 launch mix).
-    PMC collection is a separate run by construction; null for workloads it was not collected on."""
-    path = os.path.join(ROOT, "profiles", "r01_gemm_pmc.json")
-    if workload not in ("cfg3", "cfg4") or not os.path.exists(path):
-        return None
-    with open(path) as f:
-        return round(json.load(f)["hbm_bytes_per_launch"])
+def pmc_traffic(workload: str, kernel: str, live: bool):
+    """HBM-side (L2-miss, fabric) bytes per launch of the dominant kernel.  ``live``: measured in THIS session by two rocprofv3
+    --pmc passes (FETCH_SIZE, WRITE_SIZE: MI355X_MICROARCH.md HBM section) over the step's GEMM shapes (scripts/pmc_gemm_table.py;
+    PMC collection around the whole 7B step crashes rocprofv3, so the shapes are replayed stand-alone).  Otherwise, or when
+    rocprofv3 is unavailable / fails, the committed table of the same procedure (profiles/r02_gemm_pmc.json).  Returns
+    (bytes or None, source)."""
+    if workload not in ("cfg3", "cfg4"):
+        return None, "not collected for this workload"
+    import shutil
+    if live and shutil.which("rocprofv3"):
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            import pmc_gemm_table
+            kinds = {"gemm_bf16_nt_256h_kernel<true, false, false>": {"nt", "swiglu"}, "gemm_bf16_nt_256h_kernel<true, false, true>": {"dx"},
+                     "gemm_bf16_nt_256h_kernel<true, true, true>": {"dw"}}[kernel]
+            res = pmc_gemm_table.collect(kinds)
+            return round(res["per_kernel"][kernel]["hbm_bytes_per_launch"]), "measured in this run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+        except Exception as exc:        # noqa: BLE001  -- the bench line must survive a profiler failure
+            err = f"{type(exc).__name__}: {exc}"[:120]
+    else:
+        err = "rocprofv3 not used"
+    path = os.path.join(ROOT, "profiles", "r02_gemm_pmc.json")
+    if os.path.exists(path):
+        with open(path) as f:
+            pk = json.load(f)["per_kernel"].get(kernel)
+        if pk:
+            return round(pk["hbm_bytes_per_launch"]), f"profiles/r02_gemm_pmc.json ({err})"
+    return None, err
 
 
 def main():
@@ -150,6 +169,7 @@ def main():
     ap.add_argument("--grad-comm", choices=("fp32", "bf16"), default="bf16",
                     help="wire format of the gradient all-reduce (N > 1): bf16 as the reference's DeepSpeed bf16 mode sends them, or fp32")
     ap.add_argument("--no-overlap", action="store_true", help="exchange gradients after the last backward instead of during it")
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 --pmc passes for roofline.traffic (use the committed table)")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra --temporal / free-running measurements (N = 1)")
     ap.add_argument("--phase-times", action="store_true", help="print per-phase wall times (adds synchronisations)")
     ap.add_argument("--gemm-shapes", action="store_true", help="also print the GEMM time broken down by (M,N,K) to stderr")
@@ -327,7 +347,7 @@ def main():
                        "devices": [torch.cuda.get_device_name(local)] if world == 1 else f"{world} x {torch.cuda.get_device_name(local)}"},
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": round(gemm["tflops"], 2),
                          "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gemm["tflops"] / MFMA_PEAK_TFLOPS, 4),
-                         "traffic": pmc_traffic(args.workload), "launches": gemm["launches"],
+                         "traffic": None, "launches": gemm["launches"],
                          "algorithmic_bytes_per_launch": round(gemm["bytes"] / max(1, gemm["launches"])),
                          "avg_launch_us": round(1e6 * gemm["seconds"] / max(1, gemm["launches"]), 2),
                          "share_of_step": round(gemm["seconds"] / elapsed, 3)},
@@ -354,6 +374,8 @@ def main():
             out["step_algorithmic_tflops"] = round(ALGO_TF_PER_SAMPLE[args.workload] * value / world, 2)
         if args.phase_times:
             out["phase_seconds_per_step"] = {k: round(v / args.steps, 3) for k, v in phase.items()}
+        if world == 1:
+            out["roofline"]["traffic"], out["roofline"]["traffic_source"] = pmc_traffic(args.workload, dom_name, not args.no_pmc)
         if variants:
             out["variants"] = variants
         if not args.no_cpu_baseline and world == 1:

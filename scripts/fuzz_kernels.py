@@ -1,6 +1,7 @@
-"""Randomised parity sweep of the hot kernels against fp32 torch on the GPU (run by hand:  python scripts/fuzz_kernels.py [seconds]).
+"""Randomised parity sweep of the hot kernels against fp32 torch on the GPU:  python scripts/fuzz_kernels.py [seconds] [seed].
 The fixed-shape parity tests live in tests/; this sweep draws ragged shapes / segment layouts to look for corner cases
-(ragged last tiles, K-split tails, tails crossing key tiles, windows of odd sizes).  Exits non-zero on the first mismatch."""
+(ragged last tiles, K-split tails, ragged contraction lengths of the in-place dW GEMM, tails crossing key tiles, windows of odd
+sizes).  A mismatch raises AssertionError; tests/test_fuzz_gpu.py runs a seeded 45-second slice of it under `-m gpu`."""
 import math
 import os
 import random
@@ -14,7 +15,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 from spacer_amd import kernels as K  # noqa: E402
 from test_kernels_gpu import attn_ref, dense_mask  # noqa: E402
 
-dev = torch.device("cuda:0")
+dev = torch.device("cuda:0")         # the module is imported on the GPU box only (script, or tests/test_fuzz_gpu.py)
 BF = torch.bfloat16
 
 
@@ -26,8 +27,7 @@ def close(got, want, atol, rtol, what):
     err = (got.float() - want.float()).abs()
     tol = atol + rtol * want.float().abs()
     if bool((err > tol).any()):
-        print(f"MISMATCH {what}: max err {float(err.max()):.4g}, {int((err > tol).sum())}/{err.numel()} off")
-        sys.exit(1)
+        raise AssertionError(f"MISMATCH {what}: max err {float(err.max()):.4g}, {int((err > tol).sum())}/{err.numel()} off")
 
 
 def fuzz_gemm(r):
@@ -54,6 +54,33 @@ def fuzz_gemm(r):
         close(c, want + c0, tol, 1e-2, f"gemm accumulate {M}x{N}x{Kd}")
 
 
+def fuzz_gemm_trans(r):
+    """The backward GEMMs with operands read in place: dX = dY . W (trans_b) and dW += dY^T . X (trans_a + trans_b, ragged K)."""
+    if r.randint(0, 1):
+        M, N, Kd = r.choice([r.randint(1, 700), r.randint(700, 6000)]), r.randint(1, 500) * 8, r.randint(1, 40) * 64
+        dy, w = rnd((M, Kd), 0.5), rnd((Kd, N), 0.1)
+        close(K.gemm(dy, w, trans_b=True), dy.float() @ w.float(), 0.02 * math.sqrt(Kd) * 0.05 + 0.02, 1e-2, f"gemm dX {M}x{N}x{Kd}")
+    else:
+        T, Nout, Kin = r.choice([r.randint(1, 300), r.randint(300, 6000)]), r.randint(1, 500) * 8, r.randint(1, 500) * 8
+        dy, x = rnd((T, Nout), 0.5), rnd((T, Kin), 0.5)
+        acc = rnd((Nout, Kin), dtype=torch.float32)
+        want = acc + dy.float().t() @ x.float()
+        K.gemm(dy, x, trans_a=True, trans_b=True, out=acc, residual=acc)
+        close(acc, want, 0.02 * math.sqrt(T) * 0.3 + 0.02, 1e-2, f"gemm dW {Nout}x{Kin}x{T}")
+
+
+def fuzz_resize(r):
+    """GPU bicubic-antialias resize vs torch's operator + uint8 rounding (at most one level off, on < 1e-3 of the pixels)."""
+    from spacer_amd.qwen_vl_utils import vision_process as VP
+    H, W = r.randint(20, 300), r.randint(20, 400)
+    h, w = r.randint(1, 12) * 28, r.randint(1, 14) * 28
+    fr = torch.randint(0, 256, (r.randint(1, 3), 3, H, W), dtype=torch.uint8)
+    got = VP.resize_frames_gpu(fr.to(dev), (h, w)).cpu().float()
+    d = (got - VP.resize_frames(fr, (h, w))).abs()
+    if float(d.max()) > 1.0 or float((d > 0).float().mean()) > 1e-3:
+        raise AssertionError(f"MISMATCH resize {H}x{W}->{h}x{w}: max {float(d.max())}, frac {float((d > 0).float().mean()):.2e}")
+
+
 def fuzz_swiglu(r):
     M, I, Kd = r.randint(1, 6000), r.randint(1, 40) * 128, r.randint(1, 30) * 64
     a, w = rnd((M, Kd), 0.5), rnd((2 * I, Kd), 0.08)
@@ -61,8 +88,7 @@ def fuzz_swiglu(r):
     act, gu = K.gemm_swiglu(a, w, bias=bias, keep_gu=True)
     gu_ref = K.gemm_nt(a, w, bias=bias, split_k=False)
     if not torch.equal(gu, gu_ref) or not torch.equal(act, K.swiglu_fwd(gu_ref)):
-        print(f"MISMATCH gemm_swiglu {M}x{I}x{Kd} (fused={K._lib.load().spacer_gemm_swiglu_fused(M, I, Kd)})")
-        sys.exit(1)
+        raise AssertionError(f"MISMATCH gemm_swiglu {M}x{I}x{Kd} (fused={K._lib.load().spacer_gemm_swiglu_fused(M, I, Kd)})")
 
 
 def fuzz_attention(r):
@@ -161,12 +187,10 @@ def fuzz_norm(r):
     close(dw, wr.grad, 3e-2 * math.sqrt(rows), 2e-2, f"rmsnorm dw {rows}x{cols} f32={f32}")
 
 
-if __name__ == "__main__":
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+def run(budget: float, seed: int) -> dict:
     r = random.Random(seed)
     torch.manual_seed(seed)
-    fns = [fuzz_gemm, fuzz_swiglu, fuzz_attention, fuzz_decode_attention, fuzz_skinny, fuzz_norm]
+    fns = [fuzz_gemm, fuzz_gemm_trans, fuzz_swiglu, fuzz_attention, fuzz_decode_attention, fuzz_skinny, fuzz_norm, fuzz_resize]
     counts = {f.__name__: 0 for f in fns}
     t0 = time.time()
     while time.time() - t0 < budget:
@@ -174,4 +198,8 @@ if __name__ == "__main__":
         f(r)
         counts[f.__name__] += 1
     torch.cuda.synchronize()
-    print("fuzz ok:", counts)
+    return counts
+
+
+if __name__ == "__main__":
+    print("fuzz ok:", run(float(sys.argv[1]) if len(sys.argv) > 1 else 120.0, int(sys.argv[2]) if len(sys.argv) > 2 else 0))

@@ -1,54 +1,80 @@
-"""Combine the FETCH_SIZE / WRITE_SIZE passes over scripts/gemm_step_shapes.py into profiles/<name>.json:
-per-shape HBM bytes per launch (FETCH_SIZE doubled, both in KiB -> bytes: MI355X_MICROARCH.md HBM section) and the
-launch-weighted average over one cfg3 step.   usage: pmc_gemm_table.py fetch.db write.db out.json"""
+"""HBM-side traffic of the 256-tile GEMM per shape from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE -- they do not fit one
+pass) over scripts/gemm_step_shapes.py.  bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md HBM section: on gfx950
+FETCH_SIZE reports half of the bytes of wide streaming reads; both counters are in KiB); the split-K reduce launch that follows a
+GEMM launch is charged to it; averages are launch-weighted over the cfg3 step's mix, per kernel instantiation.
+
+    collect(kinds)            run both passes (subprocess rocprofv3) and return the table -- bench.py's live `roofline.traffic`
+    pmc_gemm_table.py out.json [kind ...]     the same from the command line, written to out.json
+"""
 import json
 import os
 import sqlite3
+import subprocess
 import sys
+import tempfile
 
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
 from gemm_step_shapes import SHAPES  # noqa: E402
 
+INST = {"nt": "gemm_bf16_nt_256h_kernel<true, false, false>", "swiglu": "gemm_bf16_nt_256h_kernel<true, false, false>",
+        "dx": "gemm_bf16_nt_256h_kernel<true, false, true>", "dw": "gemm_bf16_nt_256h_kernel<true, true, true>"}
 
-def per_dispatch(db, counter):
-    """[(kernel short name, value)] of the main GEMM launches in dispatch order, plus {dispatch order index: value} of the
-    split-K reduce launches that follow some of them (their traffic is charged to the GEMM launch they finish)."""
+
+def _per_dispatch(db, counter):
     cur = sqlite3.connect(db).cursor()
     rows = list(cur.execute("select dispatch_id, kernel_name, value from counters_collection where counter_name = ? and "
-                            "(kernel_name like '%gemm_bf16_nt_%' or kernel_name like '%gemm_tail_reduce%') order by dispatch_id",
-                            (counter,)))
-    main, extra = [], {}
+                            "(kernel_name like '%gemm_bf16_nt_%' or kernel_name like '%gemm_tail_re%' or kernel_name like '%gemm_tail_ro%') "
+                            "order by dispatch_id", (counter,)))
+    main, extra, pending = [], {}, 0.0
     for _, name, v in rows:
-        if "tail_reduce" in name:
+        if "tail_rows" in name:                 # K-tail copies run BEFORE the dW launch they serve
+            pending += v
+        elif "tail_reduce" in name:
             extra[len(main) - 1] = extra.get(len(main) - 1, 0.0) + v
         else:
-            main.append(("256h" if "256h" in name else "128", v))
+            main.append(v + pending)
+            pending = 0.0
     return main, extra
 
 
-(fetch, fx), (write, wx) = per_dispatch(sys.argv[1], "FETCH_SIZE"), per_dispatch(sys.argv[2], "WRITE_SIZE")
-reps = len(fetch) // len(SHAPES)
-assert len(fetch) == len(write) == reps * len(SHAPES), (len(fetch), len(write), len(SHAPES))
-table, tot = [], {"256h": [0.0, 0, 0.0], "128": [0.0, 0, 0.0]}
-for i, (M, N, K, launches, f32) in enumerate(SHAPES):
-    idx = range(i * reps, (i + 1) * reps)
-    f = sum(fetch[k][1] + fx.get(k, 0.0) for k in idx) / reps
-    w = sum(write[k][1] + wx.get(k, 0.0) for k in idx) / reps
-    kern = fetch[i * reps][0]
-    hbm = (2.0 * f + w) * 1024.0
-    algo = 2.0 * (M * K + N * K) + (4 if f32 else 2) * M * N
-    table.append(dict(M=M, N=N, K=K, kernel=kern, launches_per_step=launches, fetch_kib=f, write_kib=w, hbm_bytes=hbm,
-                      algorithmic_bytes=algo, ratio=hbm / algo))
-    t = tot[kern]
-    t[0] += hbm * launches; t[1] += launches; t[2] += algo * launches
-d = tot["256h"]
-out = dict(kernel="gemm_bf16_nt_256h_kernel", method="rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over "
-           "scripts/gemm_step_shapes.py; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts half of wide reads); "
-           "the split-K reduce launch that follows a GEMM launch is charged to it; launch-weighted over the cfg3 step's shapes "
-           "that run on this kernel",
-           hbm_bytes_per_launch=d[0] / max(1, d[1]), algorithmic_bytes_per_launch=d[2] / max(1, d[1]), launches_per_step=d[1],
-           other_kernel_128=dict(hbm_bytes_per_launch=tot["128"][0] / max(1, tot["128"][1]),
-                                 algorithmic_bytes_per_launch=tot["128"][2] / max(1, tot["128"][1]), launches_per_step=tot["128"][1]),
-           shapes=table)
-json.dump(out, open(sys.argv[3], "w"), indent=1)
-print(json.dumps({k: v for k, v in out.items() if k != "shapes"}))
+def _pass(counter, reps, kinds, tmp, timeout):
+    out = os.path.join(tmp, counter)
+    cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", out, "-o", "r", "--", sys.executable,
+           os.path.join(HERE, "gemm_step_shapes.py"), str(reps)] + sorted(kinds or [])
+    subprocess.run(cmd, check=True, timeout=timeout, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                   env=dict(os.environ, TMPDIR=tmp), cwd=tmp)
+    for root, _, files in os.walk(out):
+        for f in files:
+            if f.endswith(".db"):
+                return os.path.join(root, f)
+    raise FileNotFoundError("rocprofv3 left no .db")
+
+
+def collect(kinds=None, reps=2, timeout=240):
+    shapes = [s for s in SHAPES if not kinds or s[0] in kinds]
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        (fetch, fx), (write, wx) = (_per_dispatch(_pass(c, reps, kinds, tmp, timeout), c) for c in ("FETCH_SIZE", "WRITE_SIZE"))
+    assert len(fetch) == len(write) == reps * len(shapes), (len(fetch), len(write), len(shapes))
+    table, tot = [], {}
+    for i, (kind, M, N, K, launches, f32) in enumerate(shapes):
+        idx = range(i * reps, (i + 1) * reps)
+        f = sum(fetch[k] + fx.get(k, 0.0) for k in idx) / reps
+        w = sum(write[k] + wx.get(k, 0.0) for k in idx) / reps
+        hbm = (2.0 * f + w) * 1024.0
+        out_b = (2.0 * M * (N // 2) if kind == "swiglu" else (4 if f32 else 2) * M * N)
+        algo = 2.0 * (M * K + N * K) + out_b + ((4.0 * M * N) if (kind == "dw" or (kind == "nt" and f32 and N != 152064)) else 0.0)
+        table.append(dict(kind=kind, M=M, N=N, K=K, launches_per_step=launches, fetch_kib=f, write_kib=w, hbm_bytes=hbm,
+                          algorithmic_bytes=algo, ratio=hbm / algo))
+        t = tot.setdefault(INST[kind], [0.0, 0, 0.0])
+        t[0] += hbm * launches; t[1] += launches; t[2] += algo * launches
+    return dict(method="rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over scripts/gemm_step_shapes.py; "
+                       "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024; launch-weighted over the cfg3 step's shapes",
+                per_kernel={k: dict(hbm_bytes_per_launch=v[0] / max(1, v[1]), algorithmic_bytes_per_launch=v[2] / max(1, v[1]),
+                                    launches_per_step=v[1]) for k, v in tot.items()}, shapes=table)
+
+
+if __name__ == "__main__":
+    res = collect(set(sys.argv[2:]) or None)
+    json.dump(res, open(sys.argv[1], "w"), indent=1)
+    print(json.dumps(res["per_kernel"]))

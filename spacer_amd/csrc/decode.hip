@@ -819,7 +819,9 @@ static int launch_skinny(const void* A, long lda, const void* B, long ldb, void*
     // a test can switch it
     const char* tb = getenv("SPACER_SKINNY_BLOCKS");
     const int target_blocks = tb ? atoi(tb) : 512;
-    if (col_groups < 448) ranges = min(slices, cdiv(target_blocks, col_groups));
+    // as many K ranges as keep the whole launch in ONE resident round (2 workgroups x 256 CUs): down-proj at 7B (56 column
+    // groups x 74 slices) ran as 560 blocks = a full round + a 48-block tail before; now 9 ranges = 504 blocks
+    if (col_groups < 448) ranges = max(1, min(slices, target_blocks / col_groups));
     const int spr = cdiv(slices, ranges);
     ranges = cdiv(slices, spr);
     SP_REQUIRE(!overwrite || ranges == 1, SPACER_EINVAL, "gemm_skinny: C = A.B^T (store form) needs whole-K workgroups; N=%d splits K %d ways", N, ranges);

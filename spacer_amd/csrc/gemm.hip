@@ -370,7 +370,7 @@ static int launch_gemm(const void* A, long lda, const void* B, long ldb, void* C
         (void)once;
         g.tiles_m = cdiv(M, 256); g.tiles_n = cdiv(N, 256);
         const long tiles = (long)g.tiles_m * g.tiles_n;
-        static const char* nosplit = getenv("SPACER_GEMM_NOSPLIT");
+        const char* nosplit = getenv("SPACER_GEMM_NOSPLIT");       // per call: tests switch the K-split tail off for bit-exact comparisons
         tail_plan(tiles, cdiv(K, BK), have_ws && !nosplit, &g.full_tiles, &g.splits);
         g.slabs = have_ws ? (float*)epi->workspace : nullptr;
         const long tail_tiles = tiles - g.full_tiles;

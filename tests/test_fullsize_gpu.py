@@ -85,3 +85,61 @@ def test_decode_path_agrees_with_scoring(big):
     assert (lp[:, :-1] - lp[0:1, :-1]).abs().max() < 2e-3                       # same prefix -> same log-probs
     assert float(lp[0, -1]) >= float(lp[1:, -1].max()) - 3e-2, (lp[:, -1].tolist())   # decode's arg-max is scoring's arg-max
     roll._packed = None
+
+
+# ---------------------------------------------------------------------------------------------- the benchmark's own shapes
+def test_cfg3_shapes_shared_prefix_and_decode(big, monkeypatch):
+    """BASELINE.json configs[2] as bench.py runs it: 16 frames 280x364 -> 1040 video tokens, P = 1402 (= 21*64 + 58), K = 8
+    rollouts of C = 512 tokens (T = 5498 token-packed rows, ragged last tiles everywhere).  Size-independent properties:
+    the log-probs of rollouts 0 and 5 inside the 8-rollout shared-prompt group equal the same rollouts scored alone (the
+    reference's K independent rows, TR:527-528) -- BIT FOR BIT when the GEMM's K-split tail is off (every row then sees the same
+    fp32 summation order whatever the batch), and within the bf16-operand floor of a 28-layer model when it is on (a different
+    summation order flips bf16 roundings, which 28 layers amplify to rms ~1.6e-2: DESIGN.md section 4); greedy decode of
+    the K copies coincides and picks scoring's arg-max."""
+    cfg, eng = big["cfg"], big["eng"]
+    dev = big["comps"].device
+    prompt, _ = make_prompt(cfg, 0, 16, 280, 364, 360, dev)
+    assert prompt.ids.numel() == 1402 and tuple(prompt.grids[0]) == (8, 20, 26)
+    comps = torch.randint(1000, 150000, (8, 512), generator=torch.Generator().manual_seed(3)).to(dev)
+    monkeypatch.setenv("SPACER_GEMM_NOSPLIT", "1")
+    lp = eng.score_group(prompt.ids, comps, prompt.pix, prompt.grids)
+    assert tuple(lp.shape) == (8, 512) and torch.isfinite(lp).all()
+    for k in (0, 5):
+        alone = eng.score_group(prompt.ids, comps[k:k + 1], prompt.pix, prompt.grids)
+        assert torch.equal(lp[k], alone[0]), f"rollout {k}: shared-prefix vs alone differ by {float((lp[k] - alone[0]).abs().max())}"
+    monkeypatch.delenv("SPACER_GEMM_NOSPLIT")
+    lp_split = eng.score_group(prompt.ids, comps, prompt.pix, prompt.grids)       # the shipped configuration: K-split tail on
+    d = lp_split - lp
+    assert float(d.pow(2).mean().sqrt()) < 3e-2 and float(d.abs().max()) < 0.15, (float(d.pow(2).mean().sqrt()), float(d.abs().max()))
+    roll = RolloutEngine(eng)
+    out = roll.generate([prompt], 8, SamplingParams(max_new_tokens=8, top_k=1, top_p=1.0, suppress_eos=True), use_graph=True)
+    assert tuple(out.shape) == (8, 8) and all(torch.equal(out[0], out[k]) for k in range(1, 8))
+    alts = out[:1].repeat(6, 1)
+    alts[1:, -1] = torch.randint(1000, 150000, (5,), generator=torch.Generator().manual_seed(4)).to(dev)
+    sc = eng.score_group(prompt.ids, alts, prompt.pix, prompt.grids)
+    assert float(sc[0, -1]) >= float(sc[1:, -1].max()) - 3e-2
+    roll._packed = None
+
+
+def test_cfg5_vit_shape(big):
+    """BASELINE.json configs[4]: 32 frames @ 448^2 -> grid (16, 32, 32), 16384 patches, 16 attention segments of 1024 keys
+    (16 key tiles each).  The whole 32-block tower runs; block 0's per-frame attention output equals torch attention on the
+    engine's own q/k/v (2e-2), and the merged embeddings are finite with the right shape."""
+    from test_kernels_gpu import attn_ref
+    cfg, eng = big["cfg"], big["eng"]
+    dev = big["comps"].device
+    frames = torch.randint(0, 256, (32, 3, 448, 448), generator=torch.Generator().manual_seed(8), dtype=torch.uint8).to(dev)
+    pix, grid = K.patchify(frames, cfg.patch, cfg.tpatch, cfg.merge, cfg.patch_kpad)
+    assert tuple(grid) == (16, 32, 32)
+    tape = {}
+    out = eng.vit_forward(pix, [tuple(grid)], tape)
+    assert tuple(out.shape) == (4096, cfg.hidden) and torch.isfinite(out.float()).all()
+    blk = tape["blocks"][0]
+    D, Hh, hd = cfg.vit_dim, cfg.vit_heads, cfg.vit_head_dim
+    qkv = blk["qkv"]
+    for f in (0, 15):                                   # first and last frame: 1024 tokens each, non-causal
+        sl = slice(f * 1024, (f + 1) * 1024)
+        q, k, v = qkv[sl, :D], qkv[sl, D:2 * D], qkv[sl, 2 * D:]
+        want = attn_ref(q, k, v, torch.ones(1024, 1024, dtype=torch.bool), Hh, Hh, hd, hd ** -0.5)
+        assert float((blk["o"][sl].float() - want).abs().max()) < 2e-2
+    del tape
