@@ -164,6 +164,9 @@ def main():
                          "frame-shuffled video feeds the temporal bonus (TR:442-481, 598-617); not the headline config")
     ap.add_argument("--groups", type=int, default=None, help="prompt groups per GPU per step (default: workload's)")
     ap.add_argument("--completion-len", type=int, default=None)
+    ap.add_argument("--groups-per-pass", type=int, default=None,
+                    help="prompt groups scored / back-propagated in one token-packed pass (default: 2 where 288 GB holds two groups' "
+                         "activations -- cfg3 peaks at 254 GB -- else 1 = group by group as in round 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--grad-comm", choices=("fp32", "bf16"), default="bf16",
@@ -231,7 +234,9 @@ def main():
             return time.perf_counter()
         return t0
 
-    def step(step_idx, temporal=args.temporal, sp=sp):
+    gpp_default = args.groups_per_pass or (2 if args.workload in ("cfg3", "cfg3_qwen25", "cfg2", "tiny") else 1)
+
+    def step(step_idx, temporal=args.temporal, sp=sp, groups_per_pass=None):
         t0 = time.perf_counter()
         prompts = [make_prompt(cfg, rank * groups + g, F, Hpx, Wpx, n_text, dev, frames_u8=frames[g])[0] for g in range(groups)]
         scomp = None
@@ -248,15 +253,24 @@ def main():
         else:
             comp = ge.roll.generate(prompts, Kgen, sp, use_graph=not args.no_graph, stats=roll_stats)
         t0 = tick("rollout", t0)
+        advs = []
         for g in range(groups):
             cg = comp[g * Kgen:(g + 1) * Kgen]
             rpf = synthetic_rewards(step_idx, rank * groups + g, Kgen)
             srpf = synthetic_rewards(step_idx + 100003, rank * groups + g, Kgen // 2) if scomp is not None else None
             rewards, _ = temporal_bonus(rpf, srpf, scomp is not None, True)
             rewards = length_bonus(rewards, rpf, torch.full((Kgen,), cg.shape[1]), hyper.len_control)
-            adv, _ = group_advantages(rewards, Kgen)
+            advs.append(group_advantages(rewards, Kgen)[0])
+        gpp = max(1, min(groups_per_pass or gpp_default, groups))
+        for g0 in range(0, groups, gpp):
+            gs = list(range(g0, min(groups, g0 + gpp)))
             # the rank's last backward of the step hands finished layer ranges to the data-parallel reducer (overlap_comm)
-            ge.score_and_backward(prompts[g], cg, adv.to(dev), grad_scale=1.0 / groups, last_group=g == groups - 1)
+            last = gs[-1] == groups - 1
+            if len(gs) == 1:
+                ge.score_and_backward(prompts[g0], comp[g0 * Kgen:(g0 + 1) * Kgen], advs[g0].to(dev), grad_scale=1.0 / groups, last_group=last)
+            else:
+                ge.score_and_backward_multi([prompts[g] for g in gs], [comp[g * Kgen:(g + 1) * Kgen] for g in gs], [advs[g] for g in gs],
+                                            grad_scale=len(gs) / groups, last_group=last)
         t0 = tick("score+backward", t0)
         ge.reduce_gradients()
         ge.optimizer_step(world)
@@ -295,7 +309,8 @@ def main():
         # (EOS allowed, --max_completion_length 1024, :33): reported beside the headline, never as it
         from dataclasses import replace
         for name, kw in (("temporal", dict(temporal=True)),
-                         ("free_running", dict(sp=replace(sp, max_new_tokens=2 * C if args.workload == "tiny" else 1024, suppress_eos=False)))):
+                         ("free_running", dict(sp=replace(sp, max_new_tokens=2 * C if args.workload == "tiny" else 1024, suppress_eos=False),
+                                               groups_per_pass=1))):       # 1024-token rollouts: one group's activations per pass
             try:
                 roll_stats.clear()
                 step(10_000, **kw)
@@ -343,7 +358,8 @@ def main():
                                    f"K={Kgen}, C={C} (EOS suppressed), {groups} prompt groups/GPU, full step "
                                    f"(rollout+ref/policy scoring+backward+AdamW)",
                        "global_batch": groups * Kgen * world, "parallelism": f"dp{world}", "decode_graph": not args.no_graph,
-                       "grad_comm": args.grad_comm, "overlap_comm": not args.no_overlap, "rccl_world": world,
+                       "grad_comm": args.grad_comm, "overlap_comm": not args.no_overlap, "groups_per_pass": max(1, min(gpp_default, groups)),
+                       "rccl_world": world,
                        "devices": [torch.cuda.get_device_name(local)] if world == 1 else f"{world} x {torch.cuda.get_device_name(local)}"},
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": round(gemm["tflops"], 2),
                          "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gemm["tflops"] / MFMA_PEAK_TFLOPS, 4),

@@ -261,6 +261,28 @@ class GRPOEngine:
             self.engine.backward_group(tape, dlogp, self.G, on_ready=hook)
         return dict(loss=loss, kl=kl, logps=lp, ref_logps=ref_lp, mask=mask, lengths=lengths)
 
+    def score_and_backward_multi(self, prompts: List[PromptInput], completions: List[torch.Tensor], advantages: List[torch.Tensor],
+                                 grad_scale: float = 1.0, *, era_rule: bool = False, last_group: bool = False) -> Dict[str, torch.Tensor]:
+        """``score_and_backward`` for several prompt groups in ONE scoring pass each for the reference and the policy and ONE
+        backward (Qwen2VLEngine.score_groups): the same gradients as calling it group by group -- the loss is the mean over
+        groups, each group's rows enter the loss kernel with 1/len(prompts) -- with G x the rows per kernel launch."""
+        cfg, Gn = self.cfg, len(prompts)
+        Kn, C = completions[0].shape
+        comp_all = torch.cat(completions, 0)
+        mask, lengths = K.completion_mask(comp_all, cfg.eos_token_id)
+        entries = [(p.ids, p.pix, p.grids) for p in prompts]
+        with torch.no_grad():
+            ref_lp = self.ref_engine.score_groups(entries, completions, era_rule=era_rule)
+            tape: dict = {}
+            lp = self.engine.score_groups(entries, completions, tape=tape, era_rule=era_rule)
+            # the loss kernel averages over its rows: G groups of K rows -> mean over G*K rows = (1/G) * sum of group means
+            loss, kl, dlogp = K.grpo_loss(lp, ref_lp, torch.cat(advantages).to(self.dev), mask, self.h.beta)
+            if grad_scale * Gn != 1.0:
+                dlogp.mul_(grad_scale * Gn)
+            hook = self.reducer.ready if (last_group and self.reducer is not None and self.h.overlap_comm) else None
+            self.engine.backward_group(tape, dlogp, self.G, on_ready=hook)
+        return dict(loss=loss, kl=kl, logps=lp, ref_logps=ref_lp, mask=mask, lengths=lengths)
+
     def sft_forward_backward(self, ids: torch.Tensor, pix, grids, label_mask: torch.Tensor, *, grad_scale: float = 1.0,
                              second_per_grid_ts=None, last_group: bool = False) -> float:
         """Supervised objective of open_r1/sft.py on the same kernels: mean cross-entropy of ids[1:] over the positions whose

@@ -303,17 +303,20 @@ class Qwen2VLEngine:
         return dx
 
     # ================================================================== embeddings
-    def embed(self, ids: torch.Tensor, video: Optional[torch.Tensor], n_placeholder_scope: Optional[int] = None):
-        """ids int64 [T] (device); video bf16 [Nv, hidden] rows replace placeholder tokens in order.  Only the first
-        ``n_placeholder_scope`` tokens (the prompt) can be placeholders: a SAMPLED completion token that happens to be
-        <|video_pad|> / <|image_pad|> (random-init policies do emit them) is an ordinary token with its own embedding row --
-        HF raises on the count mismatch there and the reference falls back to a text-only forward (TR:526-532)."""
+    def embed(self, ids: torch.Tensor, video: Optional[torch.Tensor], placeholder_scopes: Optional[Sequence[Tuple[int, int]]] = None):
+        """ids int64 [T] (device); video bf16 [Nv, hidden] rows replace placeholder tokens in order.  Only tokens inside
+        ``placeholder_scopes`` ([start, end) ranges: the prompts) can be placeholders: a SAMPLED completion token that happens
+        to be <|video_pad|> / <|image_pad|> (random-init policies do emit them) is an ordinary token with its own embedding row
+        -- HF raises on the count mismatch there and the reference falls back to a text-only forward (TR:526-532)."""
         cfg = self.cfg
         vrow = None
         if video is not None:
             is_vis = (ids == cfg.video_token_id) | (ids == cfg.image_token_id)
-            if n_placeholder_scope is not None:
-                is_vis[n_placeholder_scope:] = False
+            if placeholder_scopes is not None:
+                inside = torch.zeros_like(is_vis)
+                for a, b in placeholder_scopes:
+                    inside[a:b] = True
+                is_vis &= inside
             vrow = torch.where(is_vis, torch.cumsum(is_vis.int(), 0, dtype=torch.int32) - 1,
                                torch.full_like(ids, -1, dtype=torch.int32)).int().contiguous()
         return K.embed_fwd(ids, self.W["llm.embed"], video, vrow), vrow
@@ -331,35 +334,59 @@ class Qwen2VLEngine:
                     *, tape: Optional[dict] = None, era_rule: bool = False) -> torch.Tensor:
         """Per-token log-probs [K, C] of K completions of one prompt (SG_RLVR_trainer.py:353-366,527-528),
         computed with the prompt shared: the prompt runs once and every rollout attends its keys."""
+        return self.score_groups([(prompt_ids, pix, grids)], [completion_ids], tape=tape, era_rule=era_rule)
+
+    def score_groups(self, prompts: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor], Optional[Sequence]]],
+                     completions: Sequence[torch.Tensor], *, tape: Optional[dict] = None, era_rule: bool = False) -> torch.Tensor:
+        """``score_group`` for SEVERAL prompt groups in ONE token-packed pass: prompts[g] = (prompt_ids, pix, grids),
+        completions[g] int64 [K, C] (same K, C for all g); returns [G*K, C] in group order.  Groups are independent (their
+        segments never see each other), so the numbers are the single-group ones; what changes is the launch shape: every GEMM
+        sees G x the rows (fewer, fuller launches: the dW GEMMs' fp32 read-modify-write of the gradient is paid once per pass,
+        the ViT's small-K GEMMs fill the chip) at G x the activation memory (27 GB per 7B group)."""
         cfg = self.cfg
-        Kn, C = completion_ids.shape
-        P = prompt_ids.numel()
-        T = P + Kn * C
+        Kn, C = completions[0].shape
+        assert all(tuple(c.shape) == (Kn, C) for c in completions) and len(prompts) == len(completions)
+        with_video = [g for g, (_, pix, _) in enumerate(prompts) if pix is not None]
+        assert len(with_video) in (0, len(prompts)), "groups of one pass either all carry vision inputs or none does"
         vit_tape = {} if tape is not None else None
-        video = self.vit_forward(pix, grids, vit_tape) if pix is not None else None
-        ids = torch.cat([prompt_ids.reshape(-1), completion_ids.reshape(-1)])
-        x0, vrow = self.embed(ids, video, n_placeholder_scope=P)
-        pos3, delta = POS.mrope_positions(prompt_ids.tolist(), list(grids or []), cfg, era_rule)
-        comp_pos = (P + delta) + torch.arange(C)                       # same for every rollout
-        pos_all = torch.cat([pos3] + [comp_pos.view(1, C).expand(3, C)] * Kn, dim=1)
-        cos, sin = POS.mrope_tables(pos_all, cfg, self.dev)
-        seg_list, sel = self.group_layout(P, Kn, C)
+        video, all_grids = None, []
+        if with_video:
+            all_grids = [g for _, _, gr in prompts for g in gr]
+            pix_all = prompts[0][1] if len(prompts) == 1 else torch.cat([p[1] for p in prompts], 0)
+            video = self.vit_forward(pix_all, all_grids, vit_tape)
+        ids_parts, pos_parts, seg_list, sel_parts, scope = [], [], [], [], []
+        off = 0
+        for (prompt_ids, _, grids), comp in zip(prompts, completions):
+            P = prompt_ids.numel()
+            ids_parts += [prompt_ids.reshape(-1), comp.reshape(-1)]
+            pos3, delta = POS.mrope_positions(prompt_ids.tolist(), list(grids or []), cfg, era_rule)
+            comp_pos = (P + delta) + torch.arange(C)                       # same for every rollout of the group
+            pos_parts += [pos3] + [comp_pos.view(1, C).expand(3, C)] * Kn
+            segs_g, sel_g = self.group_layout(P, Kn, C)
+            seg_list += [(off + qs, ql, off + ps if pl else 0, pl) for qs, ql, ps, pl in segs_g]
+            sel_parts.append(sel_g + off)
+            scope.append((off, off + P))
+            off += P + Kn * C
+        T = off
+        ids = torch.cat(ids_parts)
+        x0, vrow = self.embed(ids, video, placeholder_scopes=scope)
+        cos, sin = POS.mrope_tables(torch.cat(pos_parts, dim=1), cfg, self.dev)
         segs = K.make_segments(seg_list, self.dev)
-        sel = sel.to(self.dev)
-        max_q = max(P, C)
+        sel = torch.cat(sel_parts).to(self.dev)
+        max_q = max(s[1] for s in seg_list)
         llm_tape = [] if tape is not None else None
         x = self.llm_forward(x0, cos, sin, segs, max_q, tape=llm_tape)
         rstd_f = self._empty(T)
         hn = K.rmsnorm_fwd(x, self.W["llm.norm_w"], cfg.rms_eps, rstd=rstd_f)
         hsel = K.gather_rows(hn, sel)
         logits = K.gemm_nt(hsel, self.W["llm.lm_head"], out_dtype=F32)
-        targets = completion_ids.reshape(-1).contiguous()
+        targets = torch.cat([c.reshape(-1) for c in completions]).contiguous()
         logp, lse = K.logprob_fwd(logits, targets)
         if tape is not None:
             tape.update(vit=vit_tape, llm=llm_tape, ids=ids, vrow=vrow, cos=cos, sin=sin, segs=segs, max_q=max_q, sel=sel,
                         x_final=x, rstd_f=rstd_f, hsel=hsel, logits=logits, targets=targets, lse=lse, T=T,
                         has_video=video is not None)
-        return logp.view(Kn, C)
+        return logp.view(len(prompts) * Kn, C)
 
     def score_sequence(self, ids: torch.Tensor, pix: Optional[torch.Tensor], grids, *, tape: Optional[dict] = None,
                        era_rule: bool = False, second_per_grid_ts=None) -> torch.Tensor:

@@ -115,6 +115,34 @@ def test_sampled_placeholder_ids_are_plain_tokens(setup):
     assert torch.isfinite(G.flat).all() and float(G["vit.patch_w"].abs().max()) > 0
 
 
+def test_several_groups_per_pass_equal_group_by_group(setup):
+    """Qwen2VLEngine.score_groups / GRPOEngine.score_and_backward_multi: two prompt groups (different prompts, one with a
+    shorter text tail) in ONE token-packed pass give the log-probs of the two single-group passes, and the accumulated
+    gradient of the pair equals the sum of the two single-group backward passes (same loss weighting)."""
+    from spacer_amd.grpo import GRPOEngine, GRPOHyper
+    from spacer_amd.rollout import PromptInput
+    s, g = setup, setup["g"]
+    dev = s["pix"].device
+    cfg = s["cfg"]
+    p0 = PromptInput(g["prompt"].to(dev), s["pix"], [s["grid"]])
+    p1 = PromptInput(g["prompt"][:-4].to(dev), s["pix"], [s["grid"]])
+    gen = torch.Generator().manual_seed(33)
+    c0, c1 = torch.randint(5, 990, (3, 6), generator=gen).to(dev), torch.randint(5, 990, (3, 6), generator=gen).to(dev)
+    eng = s["eng"]
+    both = eng.score_groups([(p0.ids, p0.pix, p0.grids), (p1.ids, p1.pix, p1.grids)], [c0, c1])
+    one0, one1 = eng.score_group(p0.ids, c0, p0.pix, p0.grids), eng.score_group(p1.ids, c1, p1.pix, p1.grids)
+    assert float((both[:3] - one0).abs().max()) < 2e-3 and float((both[3:] - one1).abs().max()) < 2e-3
+    adv = [torch.tensor([1.0, -0.5, 0.2]), torch.tensor([-1.0, 0.3, 0.9])]
+    ge_a = GRPOEngine(cfg, s["params"], GRPOHyper(num_generations=3), ref=s["params"])
+    ge_a.score_and_backward(p0, c0, adv[0].to(dev), grad_scale=0.5)
+    ge_a.score_and_backward(p1, c1, adv[1].to(dev), grad_scale=0.5)
+    ge_b = GRPOEngine(cfg, s["params"], GRPOHyper(num_generations=3), ref=s["params"])
+    res = ge_b.score_and_backward_multi([p0, p1], [c0, c1], adv, grad_scale=0.5)
+    assert tuple(res["logps"].shape) == (6, 6)
+    a, b = ge_a.G.flat, ge_b.G.flat
+    assert float((a - b).abs().max()) <= 2e-2 * float(a.abs().max()) + 1e-6, (float((a - b).abs().max()), float(a.abs().max()))
+
+
 def test_backward_matches_oracle_autograd(setup):
     s, g = setup, setup["g"]
     dev = s["pix"].device
