@@ -109,6 +109,13 @@ int spacer_gemm_skinny_packed_store_bf16(const void* A, long lda, const void* Bp
 int spacer_pack_weight_frag_swiglu(const void* W, long ld, void* out, int inter, int K, spacer_stream_t stream);
 int spacer_gemm_skinny_swiglu_bf16(const void* A, long lda, const void* Bpacked, void* Y, long ldy, int M, int inter, int K,
                                    spacer_stream_t stream);
+/* The same with a caller-owned workspace of spacer_gemm_skinny_swiglu_workspace_bytes() bytes, ZERO-FILLED ONCE by the caller
+ * (the kernel leaves it zeroed; launches sharing it must be ordered on one stream).  With it, when N/64 column groups leave a
+ * short last round on the 512 resident workgroup slots (7B: 592), the tail groups are cut along K into small blocks that run
+ * beside the whole-K blocks and meet through agent-scope atomics + a ticket (last arriver runs the SwiGLU epilogue). */
+long spacer_gemm_skinny_swiglu_workspace_bytes(void);
+int spacer_gemm_skinny_swiglu_bf16_ws(const void* A, long lda, const void* Bpacked, void* Y, long ldy, int M, int inter, int K,
+                                      void* workspace, long workspace_bytes, spacer_stream_t stream);
 
 /* out[C, Rpad] = in[R, C]^T, zero-filling columns R..Rpad-1 (bf16).  Feeds the NT GEMM in backward. */
 int spacer_transpose_bf16(const void* in, long ld_in, void* out, long ld_out, int R, int C, int Rpad,

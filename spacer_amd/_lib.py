@@ -40,6 +40,7 @@ SIGNATURES = {
     "spacer_gemm_skinny_packed_store_bf16": [_p, _l, _p, _p, _l, _i, _i, _i, _p],
     "spacer_pack_weight_frag_swiglu": [_p, _l, _p, _i, _i, _p],
     "spacer_gemm_skinny_swiglu_bf16": [_p, _l, _p, _p, _l, _i, _i, _i, _p],
+    "spacer_gemm_skinny_swiglu_bf16_ws": [_p, _l, _p, _p, _l, _i, _i, _i, _p, _l, _p],
     "spacer_transpose_bf16": [_p, _l, _p, _l, _i, _i, _i, _p],
     "spacer_rmsnorm_fwd": [_p, _i, _p, _p, _p, _i, _i, _f, _p],
     "spacer_rmsnorm_bwd": [_p, _i, _p, _p, _p, _p, _i, _p, _i, _i, _p],
@@ -79,7 +80,7 @@ SIGNATURES = {
     "spacer_sumsq_f32": [_p, _l, _p, _p],
     "spacer_adamw_step": [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _f, _p, _f, _f, _p],
 }
-OTHER_SYMBOLS = ["spacer_last_error", "spacer_version", "spacer_sample_workspace_bytes", "spacer_attn_decode_workspace_bytes", "spacer_gemm_tile", "spacer_gemm_workspace_bytes", "spacer_gemm_swiglu_fused", "spacer_resize_workspace_bytes"]
+OTHER_SYMBOLS = ["spacer_last_error", "spacer_version", "spacer_sample_workspace_bytes", "spacer_attn_decode_workspace_bytes", "spacer_gemm_tile", "spacer_gemm_workspace_bytes", "spacer_gemm_swiglu_fused", "spacer_resize_workspace_bytes", "spacer_gemm_skinny_swiglu_workspace_bytes"]
 
 _lib = None
 
@@ -108,6 +109,8 @@ def load() -> C.CDLL:
     lib.spacer_gemm_swiglu_fused.restype = _i
     lib.spacer_gemm_workspace_bytes.argtypes = []
     lib.spacer_gemm_workspace_bytes.restype = C.c_long
+    lib.spacer_gemm_skinny_swiglu_workspace_bytes.argtypes = []
+    lib.spacer_gemm_skinny_swiglu_workspace_bytes.restype = C.c_long
     lib.spacer_resize_workspace_bytes.argtypes = [_i, _i, _i]
     lib.spacer_resize_workspace_bytes.restype = C.c_long
     lib.spacer_attn_decode_workspace_bytes.argtypes = [_i, _i]

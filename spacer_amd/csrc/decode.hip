@@ -27,20 +27,41 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 // MT = 64-row blocks of A handled per weight pass: 1 (M <= 64, 256-wide K slices) or 2 (M <= 128, 128-wide K slices -- the
 // same 64 KiB of LDS and two workgroups per CU; every weight fragment feeds 8 instead of 4 MFMAs, so 128 rows stream the
 // weights once instead of twice).
+// SWIGLU tail balance (split_groups > 0): N / 64 column groups on 512 resident slots leave a short last round (592 groups at
+// 7B: 80 workgroups alone on the chip stream at the per-workgroup rate, 33 GB/s each: +15 us).  The LAST `split_groups`
+// column groups are therefore cut into `split_ranges` K ranges each, dispatched FIRST (lowest block ids, so they run beside the
+// whole-K blocks instead of after them); their partial sums meet in an fp32 scratch tile through agent-scope atomics, an
+// agent-scope ticket per column group counts arrivals, and the last arriver takes the totals back with atomic exchanges (read +
+// re-zero in one read-modify-write: both sides atomics on the same words, so no fence is needed) and applies the SwiGLU epilogue.
 template <bool PACKED, bool SWIGLU = false, int MT = 1>
 __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __restrict__ A, long lda,
                                                              const bf16_t* __restrict__ B, long ldb,
                                                              float* __restrict__ C, long ldc, int M, int N, int K,
-                                                             int slices_per_range, int mflush, int overwrite) {
+                                                             int slices_per_range, int mflush, int overwrite,
+                                                             int split_groups = 0, int split_ranges = 1,
+                                                             float* __restrict__ scratch = nullptr, int* __restrict__ tickets = nullptr) {
     constexpr int KS = 256 / MT, ROWB = KS * 2;            // LDS row bytes (512 / 256); 16-byte chunk index ^= row & 15
     constexpr int NU = KS / 32, MF = 4 * MT;               // MFMA k-steps per slice, 16-row A fragments
     constexpr int CH = KS / 8, CHS = (MT == 1) ? 5 : 4;    // 16-byte chunks per LDS row and log2
     __shared__ __attribute__((aligned(16))) char smem[2][64 * MT * ROWB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int n0 = blockIdx.x * 64 + wave * 16;
     const int total_slices = K / KS;
-    const int s_begin = blockIdx.y * slices_per_range, s_end = min(total_slices, s_begin + slices_per_range);
+    int cgroup = blockIdx.x, s_begin = blockIdx.y * slices_per_range, s_end = min(total_slices, s_begin + slices_per_range);
+    bool split_block = false;
+    if (SWIGLU && split_groups > 0) {
+        const int n_split_blocks = split_groups * split_ranges, whole = (N >> 6) - split_groups;
+        const int bx = (int)blockIdx.x;        // split blocks first: measured 55.4 us vs 56.0 us with them last (592 groups, 7B)
+        if (bx < n_split_blocks) {
+            split_block = true;
+            cgroup = whole + bx / split_ranges;
+            const int r = bx % split_ranges, spr = (total_slices + split_ranges - 1) / split_ranges;
+            s_begin = r * spr; s_end = min(total_slices, s_begin + spr);
+        } else {
+            cgroup = bx - n_split_blocks;
+        }
+    }
+    const int n0 = cgroup * 64 + wave * 16;
     if (s_begin >= s_end) return;
 
     // ---- staging map: instruction j of a thread covers row (tid >> CHS) + (256 / CH) j, 16-byte chunk tid & (CH - 1)
@@ -118,6 +139,35 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __res
     }
     // lane holds C[m = mf*16 + g*4 + r][n = n0 + l15]
     const int n = n0 + l15;
+    if (SWIGLU && split_block) {
+        // partial sums -> scratch tile of this column group ([64 rows][64 cols] fp32), then the arrival ticket
+        float* tile = scratch + (long)(cgroup - ((N >> 6) - split_groups)) * 64 * 64 * MT;
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                __hip_atomic_fetch_add(tile + (mf * 16 + g * 4 + r) * 64 + wave * 16 + l15, acc[mf][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's atomics are performed before it reaches the barrier
+        __syncthreads();
+        __shared__ int last_flag;
+        if (tid == 0) {
+            const int t = __hip_atomic_fetch_add(tickets + (cgroup - ((N >> 6) - split_groups)), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last_flag = (t == split_ranges - 1);
+        }
+        __syncthreads();
+        if (!last_flag) return;
+        // last arriver: every other block's atomics preceded its ticket; read the totals (agent-scope loads), re-zero
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // exchange = read the total AND re-zero in one read-modify-write at the same place the adds were performed
+                // (a plain or sc1 load could be served by this XCD's L2)
+                float* p = tile + (mf * 16 + g * 4 + r) * 64 + wave * 16 + l15;
+                acc[mf][r] = __hip_atomic_exchange(p, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        if (tid == 0) __hip_atomic_exchange(tickets + (cgroup - ((N >> 6) - split_groups)), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (SWIGLU) {
         bf16_t* Y = (bf16_t*)C;
         const int col = (n0 >> 1) + (l15 & 7);                               // output column of this gate/up pair
@@ -873,21 +923,53 @@ extern "C" int spacer_pack_weight_frag_swiglu(const void* W, long ld, void* out,
     return SPACER_OK;
 }
 
-extern "C" int spacer_gemm_skinny_swiglu_bf16(const void* A, long lda, const void* Bpacked, void* Y, long ldy, int M, int inter,
-                                              int K, spacer_stream_t stream) {
+// workspace of the SwiGLU decode GEMM's tail balance: scratch tiles + tickets, ZERO-initialised once by the caller (the kernel
+// leaves it zeroed); launches that share it must be ordered on one stream
+constexpr int SWIGLU_MAX_SPLIT_GROUPS = 256;
+extern "C" long spacer_gemm_skinny_swiglu_workspace_bytes(void) { return (long)SWIGLU_MAX_SPLIT_GROUPS * (64 * 64 * 4 + 4); }
+
+static int launch_skinny_swiglu(const void* A, long lda, const void* Bpacked, void* Y, long ldy, int M, int inter, int K, void* ws,
+                                long ws_bytes, hipStream_t stream) {
     SP_REQUIRE(A && Bpacked && Y, SPACER_EINVAL, "gemm_skinny_swiglu: null operand");
     SP_REQUIRE(M > 0 && M <= 128, SPACER_EINVAL, "gemm_skinny_swiglu: M=%d must be in 1..128", M);
     SP_REQUIRE(K % 256 == 0 && inter % 32 == 0 && lda % 8 == 0, SPACER_EINVAL,
                "gemm_skinny_swiglu: need K %% 256 == 0, inter %% 32 == 0, lda %% 8 == 0");
-    const int N = 2 * inter;
-    if (M > 64)
-        hipLaunchKernelGGL((gemm_skinny_kernel<true, true, 2>), dim3(cdiv(N, 64), 1), dim3(256), 0, (hipStream_t)stream,
+    const int N = 2 * inter, col_groups = cdiv(N, 64);
+    if (M > 64) {
+        hipLaunchKernelGGL((gemm_skinny_kernel<true, true, 2>), dim3(col_groups, 1), dim3(256), 0, stream,
                            (const bf16_t*)A, lda, (const bf16_t*)Bpacked, 0L, (float*)Y, ldy, M, N, K, K / 128, M, 0);
-    else
-        hipLaunchKernelGGL((gemm_skinny_kernel<true, true, 1>), dim3(cdiv(N, 64), 1), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16_t*)A, lda, (const bf16_t*)Bpacked, 0L, (float*)Y, ldy, M, N, K, K / 256, M, 0);
+        SP_CHECK_LAUNCH();
+        return SPACER_OK;
+    }
+    // tail balance: the column groups beyond the last full round of 512 resident workgroups, when that tail is short
+    int split_groups = 0, split_ranges = 1;
+    const int slots = 512, rem = col_groups % slots, slices = K / 256;
+    const bool enabled = ws && ws_bytes >= spacer_gemm_skinny_swiglu_workspace_bytes() && getenv("SPACER_SKINNY_NOBALANCE") == nullptr
+                         && getenv("SPACER_SKINNY_BLOCKS") == nullptr && N % 64 == 0;
+    if (enabled && col_groups > slots && rem > 0 && rem <= 192 && rem <= SWIGLU_MAX_SPLIT_GROUPS && slices >= 4) {
+        split_groups = rem;
+        const int want = min(slices / 2, max(2, slots / rem));                // >= 2 K slices per range, about one round of small blocks
+        const int spr = cdiv(slices, want);
+        split_ranges = cdiv(slices, spr);                                     // every range non-empty (the kernel derives the same spr)
+    }
+    const int blocks = split_groups * split_ranges + (col_groups - split_groups);
+    float* scratch = (float*)ws;
+    int* tickets = ws ? (int*)((char*)ws + (long)SWIGLU_MAX_SPLIT_GROUPS * 64 * 64 * 4) : nullptr;
+    hipLaunchKernelGGL((gemm_skinny_kernel<true, true, 1>), dim3(blocks, 1), dim3(256), 0, stream, (const bf16_t*)A, lda,
+                       (const bf16_t*)Bpacked, 0L, (float*)Y, ldy, M, N, K, K / 256, M, 0, split_groups,
+                       split_ranges, scratch, tickets);
     SP_CHECK_LAUNCH();
     return SPACER_OK;
+}
+
+extern "C" int spacer_gemm_skinny_swiglu_bf16(const void* A, long lda, const void* Bpacked, void* Y, long ldy, int M, int inter,
+                                              int K, spacer_stream_t stream) {
+    return launch_skinny_swiglu(A, lda, Bpacked, Y, ldy, M, inter, K, nullptr, 0, (hipStream_t)stream);
+}
+
+extern "C" int spacer_gemm_skinny_swiglu_bf16_ws(const void* A, long lda, const void* Bpacked, void* Y, long ldy, int M, int inter,
+                                                 int K, void* workspace, long workspace_bytes, spacer_stream_t stream) {
+    return launch_skinny_swiglu(A, lda, Bpacked, Y, ldy, M, inter, K, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int spacer_decode_rope_table(const int* pos_base, const int* step_dev, float theta, float* cos_t, float* sin_t,

@@ -231,14 +231,22 @@ def pack_weight_frag_swiglu(w: torch.Tensor, out: Optional[torch.Tensor] = None)
     return out
 
 
+_SWIGLU_WS = {}
+
+
 def gemm_skinny_swiglu(a: torch.Tensor, bp: torch.Tensor, inter: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[M, inter] (bf16) = silu(a @ Wgate^T) * (a @ Wup^T), weights from pack_weight_frag_swiglu."""
+    """out[M, inter] (bf16) = silu(a @ Wgate^T) * (a @ Wup^T), weights from pack_weight_frag_swiglu.  The per-device
+    workspace (zeroed once, left zeroed by the kernel) lets the launch balance its last round of column groups."""
     M, K = a.shape
     assert bp.numel() == 2 * inter * K
     if out is None:
         out = torch.empty(M, inter, device=a.device, dtype=BF16)
-    check(_lib.load().spacer_gemm_skinny_swiglu_bf16(_ptr(a), _rowmajor(a), _ptr(bp), _ptr(out), _rowmajor(out), M, inter, K,
-                                                     _stream()), "gemm_skinny_swiglu_bf16")
+    ws = _SWIGLU_WS.get(a.device)
+    if ws is None:
+        ws = torch.zeros(_lib.load().spacer_gemm_skinny_swiglu_workspace_bytes() // 4, device=a.device, dtype=torch.int32)
+        _SWIGLU_WS[a.device] = ws
+    check(_lib.load().spacer_gemm_skinny_swiglu_bf16_ws(_ptr(a), _rowmajor(a), _ptr(bp), _ptr(out), _rowmajor(out), M, inter, K,
+                                                        _ptr(ws), ws.numel() * 4, _stream()), "gemm_skinny_swiglu_bf16")
     return out
 
 

@@ -173,6 +173,31 @@ def test_gemm_skinny_swiglu(dev, M, I, Kd):
     assert_close(y, want, 2e-2, 1e-2, "skinny swiglu")
 
 
+def test_gemm_skinny_swiglu_tail_balance_leaves_workspace_clean(dev):
+    """7B gate|up shape: 592 column groups = one round of 512 + 80; the 80 tail groups run as K-split blocks that meet through
+    agent-scope atomics + a ticket.  Repeated launches agree with the fp32 product and with the unbalanced form, and the shared
+    workspace is all zero again after every launch."""
+    M, I, Kd = 64, 18944, 3584
+    a, w = rnd((M, Kd), dev, 31, 0.5), rnd((2 * I, Kd), dev, 32, 0.05)
+    wp = K.pack_weight_frag_swiglu(w)
+    gu = a.float() @ w.float().t()
+    want = torch.nn.functional.silu(gu[:, :I]) * gu[:, I:]
+    outs = [K.gemm_skinny_swiglu(a, wp, I).clone() for _ in range(5)]
+    for o in outs:
+        assert_close(o, want, 2e-2, 1e-2, "skinny swiglu (tail-balanced)")
+    ws = K._SWIGLU_WS[a.device]
+    torch.cuda.synchronize()
+    assert int(ws.abs().sum()) == 0
+    os.environ["SPACER_SKINNY_NOBALANCE"] = "1"
+    try:
+        plain = K.gemm_skinny_swiglu(a, wp, I).clone()
+    finally:
+        del os.environ["SPACER_SKINNY_NOBALANCE"]
+    # whole-K columns are bit-identical; the 80 split groups differ only by fp32 summation order before the bf16 rounding
+    assert torch.equal(outs[0][:, :(512 * 64) // 2], plain[:, :(512 * 64) // 2])
+    assert_close(outs[0], plain, 1e-2, 1e-2, "balanced vs plain")
+
+
 @pytest.mark.parametrize("M,N,Kd", [(128, 3584, 3584), (96, 4608, 3584), (65, 512, 18944), (100, 1008, 256)])
 def test_gemm_skinny_packed_up_to_128_rows(dev, M, N, Kd):
     """65..128 rows: two 64-row blocks per weight pass (128-wide K slices), packed weights only."""
