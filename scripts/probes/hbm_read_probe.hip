@@ -1,0 +1,68 @@
+// Pure streaming-read bandwidth on MI355X: what the weight-streaming decode GEMMs could reach at best.
+// Each wave reads 1 KiB per instruction (16 B per lane), UNROLL loads in flight, non-temporal or plain; grid-stride.
+// build: hipcc -O3 --offload-arch=gfx950 hbm_read_probe.hip -o hbm_read_probe
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+template <int UNROLL, bool NT>
+__global__ __launch_bounds__(256) void rd(const u32x4* __restrict__ p, long n16, unsigned* out) {
+    u32x4 acc = {0, 0, 0, 0};
+    const long stride = (long)gridDim.x * 256;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + (UNROLL - 1) * stride < n16; i += UNROLL * stride) {
+        u32x4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) v[u] = NT ? __builtin_nontemporal_load(p + i + u * stride) : p[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) acc ^= v[u];
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = 1;
+}
+// contiguous chunk per block (the GEMM's pattern: a workgroup streams its own 458 KB range sequentially)
+template <int UNROLL>
+__global__ __launch_bounds__(256) void rd_chunk(const u32x4* __restrict__ p, long per_block16, unsigned* out) {
+    u32x4 acc = {0, 0, 0, 0};
+    const u32x4* q = p + (long)blockIdx.x * per_block16;
+    for (long i = threadIdx.x; i + (UNROLL - 1) * 256 < per_block16; i += UNROLL * 256) {
+        u32x4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) v[u] = __builtin_nontemporal_load(q + i + u * 256);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) acc ^= v[u];
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = 1;
+}
+int main() {
+    const long bytes = 2L << 30;
+    char* buf; unsigned* out;
+    hipMalloc(&buf, bytes); hipMalloc(&out, 4);
+    hipMemset(buf, 1, bytes);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    auto run = [&](const char* name, auto launch, long nbytes) {
+        for (int w = 0; w < 3; ++w) launch(0);
+        hipDeviceSynchronize();
+        hipEventRecord(e0);
+        const int reps = 20;
+        for (int r = 0; r < reps; ++r) launch(r);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("%-44s %8.1f us  %6.2f TB/s\n", name, ms / reps * 1e3, nbytes / (ms / reps * 1e-3) / 1e12);
+    };
+    for (long mb : {64L, 272L, 1024L}) {
+        const long nb = mb * 1000000 / 16 * 16, n16 = nb / 16;
+        char name[96];
+        for (int blocks : {512, 1024, 2048}) {
+            snprintf(name, 96, "%4ld MB grid-stride nt  x8  %4d blocks", mb, blocks);
+            run(name, [&](int r) { hipLaunchKernelGGL((rd<8, true>), dim3(blocks), dim3(256), 0, 0, (const u32x4*)(buf + (r % 4) * (bytes / 8)), n16, out); }, nb);
+        }
+        snprintf(name, 96, "%4ld MB grid-stride plain x8 1024 blocks", mb);
+        run(name, [&](int r) { hipLaunchKernelGGL((rd<8, false>), dim3(1024), dim3(256), 0, 0, (const u32x4*)(buf + (r % 4) * (bytes / 8)), n16, out); }, nb);
+        snprintf(name, 96, "%4ld MB grid-stride nt x16 1024 blocks", mb);
+        run(name, [&](int r) { hipLaunchKernelGGL((rd<16, true>), dim3(1024), dim3(256), 0, 0, (const u32x4*)(buf + (r % 4) * (bytes / 8)), n16, out); }, nb);
+        const int cb = 592; const long per = n16 / cb;
+        snprintf(name, 96, "%4ld MB chunk/block nt x8   %4d blocks", mb, cb);
+        run(name, [&](int r) { hipLaunchKernelGGL((rd_chunk<8>), dim3(cb), dim3(256), 0, 0, (const u32x4*)(buf + (r % 4) * (bytes / 8)), per, out); }, per * cb * 16);
+    }
+    return 0;
+}
