@@ -1,0 +1,42 @@
+"""GPU: the driver's bench.py contract on the tiny workload -- one JSON line on stdout with the required keys (metric, value,
+unit, n_gpus, steps, warmup, ms_per_step, higher_is_better, scaling, vs_baseline, dtype, data, config.workload) plus the
+`roofline` and `cpu_baseline` objects; `--gpus N` beyond the visible GPUs refuses loudly instead of silently running one rank."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_json_contract_tiny(dev):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tiny", "--steps", "2", "--warmup", "1", "--no-pmc"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "samples/s" and d["value"] > 0
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["rccl_world"] == 1
+    assert abs(d["value"] - d["config"]["global_batch"] * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] in ("mfma", "hbm") and rf["unit"] in ("TFLOP/s", "GB/s") and rf["peak"] > 0 and "frac" in rf and "traffic" in rf
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "samples/s" and cb["sample"]
+    assert set(d["variants"]) == {"temporal", "free_running"} and all("samples_per_s" in v for v in d["variants"].values())
+
+
+def test_bench_refuses_more_gpus_than_visible(dev):
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tiny", "--gpus", str(n)], capture_output=True,
+                       text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "GPU(s) visible" in (r.stderr + r.stdout)
