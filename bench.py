@@ -172,6 +172,9 @@ def main():
     ap.add_argument("--grad-comm", choices=("fp32", "bf16"), default="bf16",
                     help="wire format of the gradient all-reduce (N > 1): bf16 as the reference's DeepSpeed bf16 mode sends them, or fp32")
     ap.add_argument("--no-overlap", action="store_true", help="exchange gradients after the last backward instead of during it")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="gloo: every rank on cuda:0, gradients staged through the host -- exercises the multi-rank control flow on a "
+                         "one-GPU box (tests only; the number it prints is not a scaling measurement)")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 --pmc passes for roofline.traffic (use the committed table)")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra --temporal / free-running measurements (N = 1)")
     ap.add_argument("--phase-times", action="store_true", help="print per-phase wall times (adds synchronisations)")
@@ -183,7 +186,7 @@ def main():
         import socket
         import subprocess
         n_dev = torch.cuda.device_count()
-        if n_dev < args.gpus:
+        if n_dev < args.gpus and args.backend == "nccl":
             sys.exit(f"bench.py --gpus {args.gpus}: only {n_dev} GPU(s) visible")
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
@@ -197,12 +200,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         sys.exit(f"bench.py --gpus {args.gpus} was launched with WORLD_SIZE={world}")
+    if args.backend == "gloo":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pg = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         pg = dist.group.WORLD
         world = dist.get_world_size()            # the RCCL world actually formed
 
@@ -297,7 +305,7 @@ def main():
     K.PROFILER.enabled = False
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     prof = K.PROFILER.summary()
@@ -358,7 +366,7 @@ def main():
                                    f"K={Kgen}, C={C} (EOS suppressed), {groups} prompt groups/GPU, full step "
                                    f"(rollout+ref/policy scoring+backward+AdamW)",
                        "global_batch": groups * Kgen * world, "parallelism": f"dp{world}", "decode_graph": not args.no_graph,
-                       "grad_comm": args.grad_comm, "overlap_comm": not args.no_overlap, "groups_per_pass": max(1, min(gpp_default, groups)),
+                       "grad_comm": args.grad_comm, "overlap_comm": not args.no_overlap, "backend": args.backend, "groups_per_pass": max(1, min(gpp_default, groups)),
                        "rccl_world": world,
                        "devices": [torch.cuda.get_device_name(local)] if world == 1 else f"{world} x {torch.cuda.get_device_name(local)}"},
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": round(gemm["tflops"], 2),

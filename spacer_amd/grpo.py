@@ -137,7 +137,11 @@ class GradReducer:
             for pre in {s.name, s.name.rsplit(".", 1)[0] + "." if "." in s.name else s.name}:
                 lo, hi = self.ranges.get(pre, (s.offset, end[s.name]))
                 self.ranges[pre] = (min(lo, s.offset), max(hi, end[s.name]))
-        self.cuda = flat.is_cuda
+        import torch.distributed as dist
+        # gloo moves host memory: device gradients are staged through the host (tests of the multi-rank control flow on a
+        # one-GPU box; RCCL ("nccl") takes the device buffers directly on a side stream)
+        self.host_staged = flat.is_cuda and dist.get_backend(pg) == "gloo"
+        self.cuda = flat.is_cuda and not self.host_staged
         self.side = torch.cuda.Stream(device=flat.device) if self.cuda else None
         self.reset()
 
@@ -149,7 +153,10 @@ class GradReducer:
     def _send(self, lo: int, hi: int) -> None:
         import torch.distributed as dist
         view = self.flat[lo:hi]
-        wire = view.to(self.wire_dtype) if self.wire_dtype not in (None, view.dtype) else None
+        if self.host_staged:
+            wire = view.to("cpu", self.wire_dtype or view.dtype)
+        else:
+            wire = view.to(self.wire_dtype) if self.wire_dtype not in (None, view.dtype) else None
         buf = wire if wire is not None else view
         if self.cuda:
             ev = torch.cuda.Event()

@@ -40,3 +40,20 @@ def test_bench_refuses_more_gpus_than_visible(dev):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tiny", "--gpus", str(n)], capture_output=True,
                        text=True, timeout=300, env=env)
     assert r.returncode != 0 and "GPU(s) visible" in (r.stderr + r.stdout)
+
+
+def test_bench_two_ranks_control_flow_on_one_gpu(dev):
+    """`python bench.py --gpus 2` with no launcher environment becomes the launcher (torch.distributed.run, 2 ranks); with
+    --backend gloo both ranks share cuda:0 and the overlapped gradient reducer stages through the host, so the whole multi-rank
+    control flow -- rendezvous, per-rank seeds, reducer hooks during the last backward, barrier + max-over-ranks timing, rank 0
+    printing ONE line with n_gpus = the world formed -- runs on the one-GPU test box (RCCL itself needs >= 2 GPUs:
+    tests/test_multigpu_gpu.py)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tiny", "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--backend", "gloo"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["rccl_world"] == 2 and d["config"]["parallelism"] == "dp2"
+    assert d["config"]["global_batch"] == 2 * 2 * 4 and d["value"] > 0 and "cpu_baseline" not in d and "variants" not in d
