@@ -1,4 +1,4 @@
-"""cfg3 scoring attention forward, 2 groups per pass, a few launches (the workload of the PMC probes); SPACER_ATTN_FWD_DMA picks the kernel."""
+"""cfg3 scoring attention forward, 2 groups per pass, a few launches (the workload of the PMC probes); SPACER_ATTN_FWD picks the kernel."""
 import sys
 import torch
 sys.path.insert(0, "/root/repo")

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void rd_chunk(const u32x4* __restrict__ p, lon
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = 1;
 }
 int main() {
-    const long bytes = 2L << 30;
+    const long bytes = 10L << 30;
     char* buf; unsigned* out;
     hipMalloc(&buf, bytes); hipMalloc(&out, 4);
     hipMemset(buf, 1, bytes);
@@ -49,20 +49,20 @@ int main() {
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("%-44s %8.1f us  %6.2f TB/s\n", name, ms / reps * 1e3, nbytes / (ms / reps * 1e-3) / 1e12);
     };
-    for (long mb : {64L, 272L, 1024L}) {
+    for (long mb : {26L, 33L, 64L, 136L, 272L, 1024L}) {
         const long nb = mb * 1000000 / 16 * 16, n16 = nb / 16;
         char name[96];
         for (int blocks : {512, 1024, 2048}) {
             snprintf(name, 96, "%4ld MB grid-stride nt  x8  %4d blocks", mb, blocks);
-            run(name, [&](int r) { hipLaunchKernelGGL((rd<8, true>), dim3(blocks), dim3(256), 0, 0, (const u32x4*)(buf + (r % 4) * (bytes / 8)), n16, out); }, nb);
+            run(name, [&](int r) { hipLaunchKernelGGL((rd<8, true>), dim3(blocks), dim3(256), 0, 0, (const u32x4*)(buf + (r % 8) * (bytes / 8)), n16, out); }, nb);
         }
         snprintf(name, 96, "%4ld MB grid-stride plain x8 1024 blocks", mb);
-        run(name, [&](int r) { hipLaunchKernelGGL((rd<8, false>), dim3(1024), dim3(256), 0, 0, (const u32x4*)(buf + (r % 4) * (bytes / 8)), n16, out); }, nb);
+        run(name, [&](int r) { hipLaunchKernelGGL((rd<8, false>), dim3(1024), dim3(256), 0, 0, (const u32x4*)(buf + (r % 8) * (bytes / 8)), n16, out); }, nb);
         snprintf(name, 96, "%4ld MB grid-stride nt x16 1024 blocks", mb);
-        run(name, [&](int r) { hipLaunchKernelGGL((rd<16, true>), dim3(1024), dim3(256), 0, 0, (const u32x4*)(buf + (r % 4) * (bytes / 8)), n16, out); }, nb);
+        run(name, [&](int r) { hipLaunchKernelGGL((rd<16, true>), dim3(1024), dim3(256), 0, 0, (const u32x4*)(buf + (r % 8) * (bytes / 8)), n16, out); }, nb);
         const int cb = 592; const long per = n16 / cb;
         snprintf(name, 96, "%4ld MB chunk/block nt x8   %4d blocks", mb, cb);
-        run(name, [&](int r) { hipLaunchKernelGGL((rd_chunk<8>), dim3(cb), dim3(256), 0, 0, (const u32x4*)(buf + (r % 4) * (bytes / 8)), per, out); }, per * cb * 16);
+        run(name, [&](int r) { hipLaunchKernelGGL((rd_chunk<8>), dim3(cb), dim3(256), 0, 0, (const u32x4*)(buf + (r % 8) * (bytes / 8)), per, out); }, per * cb * 16);
     }
     return 0;
 }

@@ -1,0 +1,246 @@
+// Anatomy of the decode (M = 64) weight-streaming GEMM: the production loop of spacer_amd/csrc/decode.hip (packed weights,
+// 64 columns x a K range per workgroup, A slice global -> regs -> LDS per 256-wide K slice) with parts switched off, next to a
+// pure read of the same bytes.  dbg bits: 1 = no A global loads, 2 = no LDS staging / barriers, 4 = no MFMA, 8 = no epilogue.
+// build: hipcc -O3 --offload-arch=gfx950 skinny_anatomy.hip -o skinny_anatomy
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef unsigned short bf16_t;
+
+// NW waves of 16 columns each per workgroup (64 / 128 / 256 columns share one staged A slice).  dbg bit 16: the grid is 1-D with
+// id = range * groups8 + group (groups8 = groups rounded up to 8), so that every K range of a column group lands on the same
+// XCD (workgroups go to XCDs round-robin by id), and the flush uses WORKGROUP-scope atomics = performed in that XCD's L2.
+template <int NW>
+__global__ __launch_bounds__(NW * 64, (NW == 4) ? 2 : (NW == 8 ? 2 : 1)) void skinny(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B,
+                                                 float* __restrict__ C, long ldc, int M, int N, int K, int spr, int dbg, int groups8,
+                                                 float* __restrict__ scratch, int* __restrict__ tickets) {
+    constexpr int KS = 256, ROWB = 512, NU = 8, MF = 4, CH = 32, CHS = 5, NA = 32 / NW, RS = NW * 2;
+    __shared__ __attribute__((aligned(16))) char smem[2][64 * ROWB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
+    const int bx = (dbg & 16) ? (int)blockIdx.x % groups8 : (int)blockIdx.x, by = (dbg & 16) ? (int)blockIdx.x / groups8 : (int)blockIdx.y;
+    const int total = K / KS, s_begin = by * spr, s_end = min(total, s_begin + spr);
+    const int n0 = bx * (NW * 16) + wave * 16;
+    if (s_begin >= s_end || bx * (NW * 16) >= N) return;
+    const int ar0 = tid >> CHS, ach = tid & (CH - 1);
+    uint4 areg[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) areg[j] = make_uint4(0, 0, 0, 0);
+    auto load_a = [&](int slice) {
+        if (dbg & 1) return;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int row = ar0 + RS * j;
+            if (row < M) areg[j] = *(const uint4*)(A + (long)row * lda + slice * KS + ach * 8);
+        }
+    };
+    auto store_a = [&](char* buf) {
+        if (dbg & 2) return;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int row = ar0 + RS * j;
+            *(uint4*)(buf + row * ROWB + ((ach ^ (row & 15)) * 16)) = areg[j];
+        }
+        __syncthreads();
+    };
+    const bf16_t* bbase = B + ((long)(n0 >> 4) * (K >> 5)) * 512 + lane * 8;
+    auto load_w = [&](u32x4 (&w)[NU], int slice) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) w[u] = __builtin_nontemporal_load((const u32x4*)(bbase + ((long)slice * NU + u) * 512));
+    };
+    f32x4 acc[MF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](const u32x4 (&w)[NU], const char* buf) {
+        if (dbg & 4) {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) acc[u & 3][0] += __uint_as_float(w[u][0] ^ w[u][1] ^ w[u][2] ^ w[u][3]);
+            return;
+        }
+        bf16x8 af[2][MF];
+        auto read_a = [&](bf16x8 (&dst)[MF], int u) {
+            const int ch = u * 4 + g;
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) {
+                const int row = mf * 16 + l15;
+                dst[mf] = *(const bf16x8*)(buf + row * ROWB + ((ch ^ (row & 15)) * 16));
+            }
+        };
+        read_a(af[0], 0);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            if (u + 1 < NU) read_a(af[(u + 1) & 1], u + 1);
+            const bf16x8 wf = __builtin_bit_cast(bf16x8, w[u]);
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) acc[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][mf], wf, acc[mf], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    u32x4 wa[NU], wb[NU];
+    load_a(s_begin);
+    load_w(wa, s_begin);
+    int s = s_begin;
+    while (true) {
+        store_a(smem[0]);
+        if (s + 1 < s_end) { load_a(s + 1); load_w(wb, s + 1); }
+        compute(wa, smem[0]);
+        if (++s >= s_end) break;
+        store_a(smem[1]);
+        if (s + 1 < s_end) { load_a(s + 1); load_w(wa, s + 1); }
+        compute(wb, smem[1]);
+        if (++s >= s_end) break;
+    }
+    const int n = n0 + l15;
+    const bool whole_k = (s_begin == 0 && s_end == total);
+    if (dbg & 8) {
+        float t = 0.f;
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) t += acc[mf][0] + acc[mf][1] + acc[mf][2] + acc[mf][3];
+        if (t == 1.2345e-30f) C[0] = t;
+        return;
+    }
+    if ((dbg & 96) && !whole_k) {
+        // partial tile -> scratch [group][range][wave][mf][lane] as float4, release, ticket; the last arriver sums and stores
+        const int nr = gridDim.y;
+        float4* mine = (float4*)scratch + (((long)bx * nr + by) * NW + wave) * MF * 64 + lane;
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+            if (dbg & 64) {            // agent-scope relaxed atomic stores (write-through), then wait for their completion
+#pragma unroll
+                for (int r = 0; r < 4; ++r) __hip_atomic_store((float*)(mine + mf * 64) + r, acc[mf][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else mine[mf * 64] = make_float4(acc[mf][0], acc[mf][1], acc[mf][2], acc[mf][3]);
+        }
+        if (dbg & 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        __shared__ int last_flag;
+        if (tid == 0) last_flag = (__hip_atomic_fetch_add(tickets + bx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nr - 1);
+        __syncthreads();
+        if (!last_flag) return;
+        if (!(dbg & 64)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (tid == 0) tickets[bx] = 0;
+        float4 part[MF];
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) part[mf] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int rr = 0; rr < nr; ++rr) {
+            const float4* src = (const float4*)scratch + (((long)bx * nr + rr) * NW + wave) * MF * 64 + lane;
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) {
+                float4 v;
+                if (dbg & 64) {
+                    v.x = __hip_atomic_load((const float*)(src + mf * 64) + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    v.y = __hip_atomic_load((const float*)(src + mf * 64) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    v.z = __hip_atomic_load((const float*)(src + mf * 64) + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    v.w = __hip_atomic_load((const float*)(src + mf * 64) + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else v = src[mf * 64];
+                part[mf].x += v.x; part[mf].y += v.y; part[mf].z += v.z; part[mf].w += v.w;
+            }
+        }
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+            const float v[4] = {part[mf].x, part[mf].y, part[mf].z, part[mf].w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = mf * 16 + g * 4 + r;
+                if (m < M) C[(long)m * ldc + n] = v[r];
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = mf * 16 + g * 4 + r;
+            if (m < M) {
+                float* c = C + (long)m * ldc + n;
+                if (whole_k) *c = acc[mf][r];
+                else if (dbg & 16) __hip_atomic_fetch_add(c, acc[mf][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else atomicAdd(c, acc[mf][r]);
+            }
+        }
+}
+
+// pure read with the GEMM's own access pattern (each wave: its 16-column fragment stream, 8 KiB per slice)
+__global__ __launch_bounds__(256, 2) void stream_only(const bf16_t* __restrict__ B, float* __restrict__ C, int K, int spr) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int total = K / 256, s_begin = blockIdx.y * spr, s_end = min(total, s_begin + spr);
+    const int n0 = blockIdx.x * 64 + wave * 16;
+    const bf16_t* bbase = B + ((long)(n0 >> 4) * (K >> 5)) * 512 + lane * 8;
+    u32x4 x = {0, 0, 0, 0};
+    for (int s = s_begin; s < s_end; ++s) {
+        u32x4 w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = __builtin_nontemporal_load((const u32x4*)(bbase + ((long)s * 8 + u) * 512));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x ^= w[u];
+    }
+    if ((x[0] ^ x[1] ^ x[2] ^ x[3]) == 0x12345678u) C[0] = 1.f;
+}
+
+int main() {
+    const int M = 64;
+    const long wbytes_max = 37888L * 3584 * 2;
+    const int COPIES = 6;
+    bf16_t *A, *W; float *C, *scratch; int* tickets;
+    hipMalloc(&scratch, 1024L * 64 * 64 * 4 * 2); hipMalloc(&tickets, 4096); hipMemset(tickets, 0, 4096);
+    hipMalloc(&A, (long)M * 18944 * 2); hipMalloc(&W, wbytes_max * COPIES); hipMalloc(&C, (long)M * 37888 * 4);
+    hipMemset(A, 0, (long)M * 18944 * 2); hipMemset(W, 0, wbytes_max * COPIES); hipMemset(C, 0, (long)M * 37888 * 4);
+    {   // bf16 1.0 everywhere: every element of A.W^T is K
+        const long na = (long)M * 18944, nw = wbytes_max * COPIES / 2;
+        unsigned short* h = (unsigned short*)malloc(nw * 2);
+        for (long i = 0; i < nw; ++i) h[i] = 0x3F80;
+        hipMemcpy(A, h, na * 2, hipMemcpyHostToDevice); hipMemcpy(W, h, nw * 2, hipMemcpyHostToDevice);
+        free(h);
+    }
+    float* hc = (float*)malloc((long)M * 37888 * 4);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    auto run = [&](const char* name, auto launch, double bytes) {
+        for (int w = 0; w < 3; ++w) launch(w);
+        hipDeviceSynchronize();
+        hipEventRecord(e0);
+        const int reps = 24;
+        for (int r = 0; r < reps; ++r) launch(r);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("  %-34s %7.1f us  %5.2f TB/s\n", name, ms / reps * 1e3, bytes / (ms / reps * 1e-3) / 1e12);
+    };
+    struct Shape { const char* name; int N, K, ranges; };
+    const Shape shapes[] = {{"qkv 4608x3584 (72 groups x 7)", 4608, 3584, 7}, {"o 3584x3584 (56 x 9 -> 7)", 3584, 3584, 9},
+                            {"down 3584x18944 (56 x 9)", 3584, 18944, 9}};
+    for (const Shape& sh : shapes) {
+        const int groups = sh.N / 64, slices = sh.K / 256;
+        int spr = (slices + sh.ranges - 1) / sh.ranges;
+        const int ranges = (slices + spr - 1) / spr;
+        const double bytes = (double)sh.N * sh.K * 2;
+        const long wstride = (long)sh.N * sh.K;
+        printf("%s: %d blocks, %d slices each, %.0f MB\n", sh.name, groups * ranges, spr, bytes / 1e6);
+        run("stream only", [&](int r) { hipLaunchKernelGGL(stream_only, dim3(groups, ranges), dim3(256), 0, 0, W + (r % COPIES) * wstride, C, sh.K, spr); }, bytes);
+        const struct { const char* n; int d; } cfgs[] = {{"full kernel", 0}, {"no epilogue", 8}, {"scratch + ticket, agent fences", 32}, {"scratch + ticket, sc1 stores/loads", 64}};
+        auto launch = [&](int nw, int d, int r) {
+            const int g = sh.N / (nw * 16), g8 = (g + 7) / 8 * 8;
+            const dim3 grid = (d & 16) ? dim3(g8 * ranges, 1) : dim3(g, ranges);
+            const bf16_t* w = W + (r % COPIES) * wstride;
+            if (nw == 4) hipLaunchKernelGGL(skinny<4>, grid, dim3(256), 0, 0, A, (long)sh.K, w, C, (long)sh.N, M, sh.N, sh.K, spr, d, g8, scratch, tickets);
+            else if (nw == 8) hipLaunchKernelGGL(skinny<8>, grid, dim3(512), 0, 0, A, (long)sh.K, w, C, (long)sh.N, M, sh.N, sh.K, spr, d, g8, scratch, tickets);
+            else hipLaunchKernelGGL(skinny<16>, grid, dim3(1024), 0, 0, A, (long)sh.K, w, C, (long)sh.N, M, sh.N, sh.K, spr, d, g8, scratch, tickets);
+        };
+        for (int nw : {4}) {
+            if (sh.N % (nw * 16)) continue;
+            for (auto& c : cfgs) {
+                if ((c.d & 112) && ranges == 1) continue;
+                char nm[96]; snprintf(nm, 96, "%2d waves: %s", nw, c.n);
+                run(nm, [&](int r) { launch(nw, c.d, r); }, bytes);
+                if (c.d == 0 || c.d == 16 || c.d == 32 || c.d == 64) {          // one launch from zero: every element must equal K
+                    hipMemset(C, 0, (long)M * sh.N * 4); launch(nw, c.d, 0); hipDeviceSynchronize();
+                    hipMemcpy(hc, C, (long)M * sh.N * 4, hipMemcpyDeviceToHost);
+                    long bad = 0; for (long i = 0; i < (long)M * sh.N; ++i) bad += (hc[i] != (float)sh.K);
+                    if (bad) printf("      WRONG: %ld of %ld elements != K\n", bad, (long)M * sh.N);
+                }
+            }
+        }
+    }
+    return 0;
+}

@@ -527,8 +527,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(AttnArgs a) {
     unsigned kx[4];
 #pragma unroll
     for (int dc = 0; dc < 4; ++dc) kx[dc] = smem0 + (unsigned)(l15 * AT_RM_ROW_BYTES + ((((dc < DC ? dc : 0) * 4 + g) ^ l15) << 4));
+    //      The V image is swizzled by chunk ^= (row & 7) << 1 (not row & 15 as the K image): one ds_read_b64_tr_b16 cycle serves
+    //      32 lanes = 8 rows x 32 contiguous bytes, and with row & 15 rows 2j and 2j+1 land on the same two chunks (2-way
+    //      conflict on every read, SQ_LDS_BANK_CONFLICT = 1/3 of the LDS cycles); with (row & 7) << 1 the eight rows take eight
+    //      different chunk pairs.
     const int vrr = 4 * g + (l15 >> 2);
-    const unsigned vx0 = (unsigned)(vrr * AT_RM_ROW_BYTES + (((((l15 & 3) >> 1)) ^ vrr) << 4) + (l15 & 1) * 8);
+    const unsigned vx0 = (unsigned)(vrr * AT_RM_ROW_BYTES + ((vrr & 7) << 5) + ((l15 & 3) >> 1) * 16 + (l15 & 1) * 8);
     // DMA: waves 0,1 fill the K image, waves 2,3 the V image; piece i = rows (wave&1)*32 + 4i + g, i = 0..7; pieces i and
     // i+4 share the chunk permutation, so four lane offsets + two scalar bases (rows +0 / +16) cover a full tile
     const bf16_t* gsrc = (wave >= 2 ? a.v : a.k) + (long)hk * D;
@@ -539,7 +543,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(AttnArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int row = prow + 4 * j;
-        int c = l15 ^ (row & 15);
+        int c = l15 ^ (wave >= 2 ? (row & 7) << 1 : (row & 15));             // logical chunk stored at this lane's LDS position
         if (c >= D / 8) c = 0;
         dchunk[j] = (unsigned)c * 16u;
         doff[j] = (unsigned)row * stride_b + dchunk[j];
