@@ -344,6 +344,38 @@ def test_attention_fwd_bwd(dev, case):
     assert_close(dv32, vr.grad, 0.03 * float(vr.grad.abs().max()) + 1e-3, 3e-2, f"{name} dv")
 
 
+@pytest.mark.parametrize("case", [ATTN_CASES[1], ATTN_CASES[5]], ids=["vit_520", "shared_prefix_big"])
+def test_attention_kernel_forms_agree(dev, case, monkeypatch):
+    """The register-staged kernels (SPACER_ATTN_FWD=reg / SPACER_ATTN_BWD=reg) and the LDS-DMA pipelined ones (default) share the
+    arithmetic: O and dQ bit for bit, the LSE to an ulp, dK / dV (fp32 atomics, a bf16 rounding of dS may flip) to rounding."""
+    name, D, Hq, Hkv, causal, segs = case
+    T = max(s[0] + s[1] for s in segs)
+    qkv = rnd((T, (Hq + 2 * Hkv) * D), dev, 11, 0.7)
+    q, k, v = qkv[:, :Hq * D], qkv[:, Hq * D:(Hq + Hkv) * D], qkv[:, (Hq + Hkv) * D:]
+    sd = K.make_segments(segs, dev)
+    mq = max(s[1] for s in segs)
+    d_o = rnd((T, Hq * D), dev, 12, 0.5)
+    fwd = {}
+    for form in ("reg", "dma", "pipe"):
+        monkeypatch.setenv("SPACER_ATTN_FWD", form)
+        fwd[form] = K.attn_fwd(q, k, v, sd, mq, Hq, Hkv, D, causal, D ** -0.5)
+    for form in ("dma", "pipe"):
+        assert torch.equal(fwd["reg"][0], fwd[form][0]), f"{name}: O differs ({form})"
+        assert float((fwd["reg"][1] - fwd[form][1]).abs().max()) <= 4e-6, f"{name}: lse ({form})"
+    o, lse = fwd["reg"]
+    bwd = {}
+    for form in ("reg", "pipe"):                       # same O / LSE into both backward forms
+        monkeypatch.setenv("SPACER_ATTN_BWD", form)
+        dqkv = torch.zeros_like(qkv)
+        dk32 = torch.zeros(T, Hkv * D, device=dev); dv32 = torch.zeros(T, Hkv * D, device=dev)
+        K.attn_bwd(q, k, v, o, d_o, lse, sd, mq, Hq, Hkv, D, causal, D ** -0.5, dq=dqkv[:, :Hq * D], dk32=dk32, dv32=dv32)
+        bwd[form] = (dqkv[:, :Hq * D].clone(), dk32, dv32)
+    assert torch.equal(bwd["reg"][0], bwd["pipe"][0]), f"{name}: dQ differs"
+    for i, nm in ((1, "dK"), (2, "dV")):
+        ref = bwd["reg"][i]
+        assert float((ref - bwd["pipe"][i]).abs().max()) <= 5e-3 * float(ref.abs().max()), f"{name}: {nm}"
+
+
 def test_attention_forced_rescale(dev):
     """Spike one key so the running max jumps at a late tile (rescale branch is exercised)."""
     D, Hq, Hkv, T = 128, 1, 1, 256
