@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(AttnArgs a) {
 //   * row max across the four lane groups: v_permlane16_swap / v_permlane32_swap (VALU) instead of two ds_bpermute trips.
 //   * addresses: per-lane LDS bases hoisted (the swizzle is an XOR on a bit field disjoint from the row and tile fields),
 //     DMA source = scalar tile base + hoisted 32-bit lane offsets; only ragged tiles take the clamping path.
-// Arithmetic is that of attn_fwd_kernel: O is bit-identical, the LSE agrees to 1 ulp (the row sum associates differently).
+// Arithmetic is that of attn_fwd_kernel up to the lazy softmax reference (see the loop): O agrees to a bf16 ulp, the LSE to ~1e-6.
 typedef __attribute__((ext_vector_type(4))) unsigned int attn_u32x4;
 
 template <int OFF> __device__ __forceinline__ void lds_b128(attn_u32x4& x, unsigned addr) {
@@ -627,7 +627,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(AttnArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kf][f][r]);
             mx = group_max4(mx);
-            const float m_new = fmaxf(m_run[f], mx * c2);
+            // lazy reference: m_run follows the row maximum only when it jumps by more than 2^8 (or leaves -inf), so p <= 256
+            // instead of <= 1 (bf16 P keeps its relative precision, l and O are fp32) and the O rescale -- 32 v_pk_mul per
+            // fragment, taken on most tiles of random data with the exact rule -- almost never runs: 759 -> 799 TF/s.  O / l and the
+            // LSE m_run ln2 + log l are the same quantities; O moves by at most a bf16 ulp against attn_fwd_kernel.
+            const float m_cand = mx * c2;
+            const float m_new = (m_cand > m_run[f] + 8.f) ? m_cand : m_run[f];
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
             const float alpha = __builtin_amdgcn_exp2f(m_run[f] - m_use);
             float psum = 0.f;
@@ -1419,7 +1424,7 @@ extern "C" int spacer_attn_fwd(const void* q, const void* k, const void* v, void
     a.lpt = getenv("SPACER_ATTN_FIFO") ? 0 : 1;
     const dim3 grid(num_segs * a.nqb, Hq);
     // forward kernel: "pipe" (default, LDS-DMA tiles + pipelined fragment reads), "dma" (LDS-DMA tiles, compiler-placed K reads),
-    // "reg" (register-staged tiles); the three agree bit for bit in O (LSE to 1 ulp), the switch exists for A/B timing (scripts/probes/attn_fwd_time.py)
+    // "reg" (register-staged tiles); reg and dma agree bit for bit, pipe to a bf16 ulp of O (lazy softmax reference); the switch exists for A/B timing (scripts/probes/attn_fwd_time.py)
     const char* form = getenv("SPACER_ATTN_FWD");
     const int which = (form && form[0] == 'r') ? 0 : (form && form[0] == 'd') ? 1 : 2;
     constexpr int LDS = 4 * AT_RM_BYTES;

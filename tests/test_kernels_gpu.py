@@ -347,7 +347,8 @@ def test_attention_fwd_bwd(dev, case):
 @pytest.mark.parametrize("case", [ATTN_CASES[1], ATTN_CASES[5]], ids=["vit_520", "shared_prefix_big"])
 def test_attention_kernel_forms_agree(dev, case, monkeypatch):
     """The register-staged kernels (SPACER_ATTN_FWD=reg / SPACER_ATTN_BWD=reg) and the LDS-DMA pipelined ones (default) share the
-    arithmetic: O and dQ bit for bit, the LSE to an ulp, dK / dV (fp32 atomics, a bf16 rounding of dS may flip) to rounding."""
+    arithmetic: forward reg == dma bit for bit, pipe (lazy softmax reference) to a bf16 ulp of O; backward dQ bit for bit, dK / dV
+    (fp32 atomics, a bf16 rounding of dS may flip) to rounding."""
     name, D, Hq, Hkv, causal, segs = case
     T = max(s[0] + s[1] for s in segs)
     qkv = rnd((T, (Hq + 2 * Hkv) * D), dev, 11, 0.7)
@@ -359,9 +360,12 @@ def test_attention_kernel_forms_agree(dev, case, monkeypatch):
     for form in ("reg", "dma", "pipe"):
         monkeypatch.setenv("SPACER_ATTN_FWD", form)
         fwd[form] = K.attn_fwd(q, k, v, sd, mq, Hq, Hkv, D, causal, D ** -0.5)
-    for form in ("dma", "pipe"):
-        assert torch.equal(fwd["reg"][0], fwd[form][0]), f"{name}: O differs ({form})"
-        assert float((fwd["reg"][1] - fwd[form][1]).abs().max()) <= 4e-6, f"{name}: lse ({form})"
+    assert torch.equal(fwd["reg"][0], fwd["dma"][0]) and torch.equal(fwd["reg"][1], fwd["dma"][1]), f"{name}: dma form differs"
+    # pipe: lazy softmax reference -> every P element is rounded to bf16 at another scale (<= 2^-8 relative each), so O agrees to a
+    # bf16 ulp of the output scale; the LSE to fp32 rounding
+    od = (fwd["reg"][0].float() - fwd["pipe"][0].float()).abs()
+    assert float(od.max()) <= 2 ** -7 * float(fwd["reg"][0].float().abs().max()), f"{name}: O (pipe) differs by {float(od.max())}"
+    assert float((fwd["reg"][1] - fwd["pipe"][1]).abs().max()) <= 1e-5, f"{name}: lse (pipe)"
     o, lse = fwd["reg"]
     bwd = {}
     for form in ("reg", "pipe"):                       # same O / LSE into both backward forms
