@@ -163,6 +163,119 @@ __global__ __launch_bounds__(NW * 64, (NW == 4) ? 2 : (NW == 8 ? 2 : 1)) void sk
         }
 }
 
+
+// 8-wave variant: waves 0-3 and 4-7 take alternate K slices of the workgroup's range for the same 64 columns (two A slices staged
+// per step), the two partial sums meet in LDS, then ONE flush: half the K ranges (= half the atomics) for the same number of
+// weight-streaming waves.  One workgroup per CU (128 KiB of LDS).
+__global__ __launch_bounds__(512, 2) void skinny_k2(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B,
+                                                    float* __restrict__ C, long ldc, int M, int N, int K, int spr, int dbg) {
+    constexpr int KS = 256, ROWB = 512, NU = 8, MF = 4, CH = 32, CHS = 5;
+    extern __shared__ __attribute__((aligned(16))) char smem[];        // [2 parities][2 slices][64 * ROWB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
+    const int kh = wave >> 2, cw = wave & 3;
+    const int total = K / KS, s_begin = blockIdx.y * spr, s_end = min(total, s_begin + spr);
+    const int n0 = blockIdx.x * 64 + cw * 16;
+    if (s_begin >= s_end) return;
+    const int t2 = tid & 255, ar0 = t2 >> CHS, ach = t2 & (CH - 1);    // threads 0-255 stage slice s, 256-511 slice s+1
+    uint4 areg[8];
+    auto load_a = [&](int s0) {
+        const int slice = s0 + kh;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = ar0 + 8 * j;
+            areg[j] = (row < M && slice < s_end) ? *(const uint4*)(A + (long)row * lda + slice * KS + ach * 8) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_a = [&](char* buf) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = ar0 + 8 * j;
+            *(uint4*)(buf + kh * 64 * ROWB + row * ROWB + ((ach ^ (row & 15)) * 16)) = areg[j];
+        }
+        __syncthreads();
+    };
+    const bf16_t* bbase = B + ((long)(n0 >> 4) * (K >> 5)) * 512 + lane * 8;
+    auto load_w = [&](u32x4 (&w)[NU], int s0) {
+        const int slice = min(s0 + kh, total - 1);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) w[u] = __builtin_nontemporal_load((const u32x4*)(bbase + ((long)slice * NU + u) * 512));
+    };
+    f32x4 acc[MF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](const u32x4 (&w)[NU], const char* buf0, int s0) {
+        if (s0 + kh >= s_end) return;                                   // odd slice count: the second half idles on the last step
+        const char* buf = buf0 + kh * 64 * ROWB;
+        bf16x8 af[2][MF];
+        auto read_a = [&](bf16x8 (&dst)[MF], int u) {
+            const int ch = u * 4 + g;
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) {
+                const int row = mf * 16 + l15;
+                dst[mf] = *(const bf16x8*)(buf + row * ROWB + ((ch ^ (row & 15)) * 16));
+            }
+        };
+        read_a(af[0], 0);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            if (u + 1 < NU) read_a(af[(u + 1) & 1], u + 1);
+            const bf16x8 wf = __builtin_bit_cast(bf16x8, w[u]);
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) acc[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][mf], wf, acc[mf], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    u32x4 wa[NU], wb[NU];
+    char* b0 = smem; char* b1 = smem + 2 * 64 * ROWB;
+    load_a(s_begin);
+    load_w(wa, s_begin);
+    int s = s_begin;
+    while (true) {
+        store_a(b0);
+        if (s + 2 < s_end) { load_a(s + 2); load_w(wb, s + 2); }
+        compute(wa, b0, s);
+        if ((s += 2) >= s_end) break;
+        store_a(b1);
+        if (s + 2 < s_end) { load_a(s + 2); load_w(wa, s + 2); }
+        compute(wb, b1, s);
+        if ((s += 2) >= s_end) break;
+    }
+    __syncthreads();                                                    // everyone is done with the A images
+    float* red = (float*)smem;                                          // [4 column waves][MF][4][64 lanes]
+    if (kh == 1) {
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[((cw * MF + mf) * 4 + r) * 64 + lane] = acc[mf][r];
+    }
+    __syncthreads();
+    if (kh == 1) return;
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[mf][r] += red[((cw * MF + mf) * 4 + r) * 64 + lane];
+    const int n = n0 + l15;
+    const bool whole_k = (s_begin == 0 && s_end == total);
+    if (dbg & 8) {
+        float t = 0.f;
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) t += acc[mf][0] + acc[mf][1] + acc[mf][2] + acc[mf][3];
+        if (t == 1.2345e-30f) C[0] = t;
+        return;
+    }
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = mf * 16 + g * 4 + r;
+            if (m < M) {
+                float* c = C + (long)m * ldc + n;
+                if (whole_k) *c = acc[mf][r];
+                else atomicAdd(c, acc[mf][r]);
+            }
+        }
+}
+
 // pure read with the GEMM's own access pattern (each wave: its 16-column fragment stream, 8 KiB per slice)
 __global__ __launch_bounds__(256, 2) void stream_only(const bf16_t* __restrict__ B, float* __restrict__ C, int K, int spr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -218,7 +331,7 @@ int main() {
         const long wstride = (long)sh.N * sh.K;
         printf("%s: %d blocks, %d slices each, %.0f MB\n", sh.name, groups * ranges, spr, bytes / 1e6);
         run("stream only", [&](int r) { hipLaunchKernelGGL(stream_only, dim3(groups, ranges), dim3(256), 0, 0, W + (r % COPIES) * wstride, C, sh.K, spr); }, bytes);
-        const struct { const char* n; int d; } cfgs[] = {{"full kernel", 0}, {"no epilogue", 8}, {"scratch + ticket, agent fences", 32}, {"scratch + ticket, sc1 stores/loads", 64}};
+        const struct { const char* n; int d; } cfgs[] = {{"full kernel", 0}, {"no epilogue", 8}, };
         auto launch = [&](int nw, int d, int r) {
             const int g = sh.N / (nw * 16), g8 = (g + 7) / 8 * 8;
             const dim3 grid = (d & 16) ? dim3(g8 * ranges, 1) : dim3(g, ranges);
@@ -227,6 +340,22 @@ int main() {
             else if (nw == 8) hipLaunchKernelGGL(skinny<8>, grid, dim3(512), 0, 0, A, (long)sh.K, w, C, (long)sh.N, M, sh.N, sh.K, spr, d, g8, scratch, tickets);
             else hipLaunchKernelGGL(skinny<16>, grid, dim3(1024), 0, 0, A, (long)sh.K, w, C, (long)sh.N, M, sh.N, sh.K, spr, d, g8, scratch, tickets);
         };
+        hipFuncSetAttribute((const void*)skinny_k2, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 512);
+        for (int r2 : {ranges, (ranges + 1) / 2, (ranges + 2) / 3}) {
+            const int spr2 = (slices + r2 - 1) / r2, rr = (slices + spr2 - 1) / spr2;
+            for (int d : {0, 8}) {
+                char nm[96]; snprintf(nm, 96, "8 waves (2 K halves), %d ranges x %d slices%s", rr, spr2, d ? ", no epilogue" : "");
+                run(nm, [&](int r) { hipLaunchKernelGGL(skinny_k2, dim3(groups, rr), dim3(512), 4 * 64 * 512, 0, A, (long)sh.K, W + (r % COPIES) * wstride, C, (long)sh.N, M, sh.N, sh.K, spr2, d); }, bytes);
+                if (d == 0) {
+                    hipMemset(C, 0, (long)M * sh.N * 4);
+                    hipLaunchKernelGGL(skinny_k2, dim3(groups, rr), dim3(512), 4 * 64 * 512, 0, A, (long)sh.K, W, C, (long)sh.N, M, sh.N, sh.K, spr2, 0);
+                    hipDeviceSynchronize();
+                    hipMemcpy(hc, C, (long)M * sh.N * 4, hipMemcpyDeviceToHost);
+                    long bad = 0; for (long i = 0; i < (long)M * sh.N; ++i) bad += (hc[i] != (float)sh.K);
+                    if (bad) printf("      WRONG: %ld of %ld elements != K\n", bad, (long)M * sh.N);
+                }
+            }
+        }
         for (int nw : {4}) {
             if (sh.N % (nw * 16)) continue;
             for (auto& c : cfgs) {
