@@ -107,9 +107,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 4) ? 2 : (NW == 8 ? 2 : 1)) void sk
         float4* mine = (float4*)scratch + (((long)bx * nr + by) * NW + wave) * MF * 64 + lane;
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) {
-            if (dbg & 64) {            // agent-scope relaxed atomic stores (write-through), then wait for their completion
-#pragma unroll
-                for (int r = 0; r < 4; ++r) __hip_atomic_store((float*)(mine + mf * 64) + r, acc[mf][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (dbg & 64) {            // 16-byte write-through (sc1) stores, then wait for their completion
+                const f32x4 v = acc[mf];
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(mine + mf * 64), "v"(v) : "memory");
             } else mine[mf * 64] = make_float4(acc[mf][0], acc[mf][1], acc[mf][2], acc[mf][3]);
         }
         if (dbg & 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -124,17 +124,28 @@ __global__ __launch_bounds__(NW * 64, (NW == 4) ? 2 : (NW == 8 ? 2 : 1)) void sk
         float4 part[MF];
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) part[mf] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (dbg & 64) {
+            // every range's tile requested at once (nr <= 9 here), sc1 loads = served past this XCD's L2
+            f32x4 got[9][MF];
+            for (int rr = 0; rr < 9; ++rr) {
+                if (rr < nr) {
+                    const float4* src = (const float4*)scratch + (((long)bx * nr + rr) * NW + wave) * MF * 64 + lane;
+#pragma unroll
+                    for (int mf = 0; mf < MF; ++mf) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(got[rr][mf]) : "v"(src + mf * 64) : "memory");
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int rr = 0; rr < 9; ++rr)
+                if (rr < nr) {
+#pragma unroll
+                    for (int mf = 0; mf < MF; ++mf) { part[mf].x += got[rr][mf][0]; part[mf].y += got[rr][mf][1]; part[mf].z += got[rr][mf][2]; part[mf].w += got[rr][mf][3]; }
+                }
+        } else
         for (int rr = 0; rr < nr; ++rr) {
             const float4* src = (const float4*)scratch + (((long)bx * nr + rr) * NW + wave) * MF * 64 + lane;
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf) {
-                float4 v;
-                if (dbg & 64) {
-                    v.x = __hip_atomic_load((const float*)(src + mf * 64) + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    v.y = __hip_atomic_load((const float*)(src + mf * 64) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    v.z = __hip_atomic_load((const float*)(src + mf * 64) + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    v.w = __hip_atomic_load((const float*)(src + mf * 64) + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else v = src[mf * 64];
+                const float4 v = src[mf * 64];
                 part[mf].x += v.x; part[mf].y += v.y; part[mf].z += v.z; part[mf].w += v.w;
             }
         }
@@ -331,7 +342,7 @@ int main() {
         const long wstride = (long)sh.N * sh.K;
         printf("%s: %d blocks, %d slices each, %.0f MB\n", sh.name, groups * ranges, spr, bytes / 1e6);
         run("stream only", [&](int r) { hipLaunchKernelGGL(stream_only, dim3(groups, ranges), dim3(256), 0, 0, W + (r % COPIES) * wstride, C, sh.K, spr); }, bytes);
-        const struct { const char* n; int d; } cfgs[] = {{"full kernel", 0}, {"no epilogue", 8}, };
+        const struct { const char* n; int d; } cfgs[] = {{"full kernel", 0}, {"no epilogue", 8}, {"scratch + ticket, 16-B sc1 stores/loads", 64}};
         auto launch = [&](int nw, int d, int r) {
             const int g = sh.N / (nw * 16), g8 = (g + 7) / 8 * 8;
             const dim3 grid = (d & 16) ? dim3(g8 * ranges, 1) : dim3(g, ranges);
