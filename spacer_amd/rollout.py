@@ -201,7 +201,9 @@ class RolloutEngine:
         for s in range(1, C):
             if use_graph and graph is None and s == 2:       # step 1 ran eagerly (warm-up); capture step 2, replay after
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                # thread_local: every launch of the step comes from this thread; a device query from another thread (the RCCL
+                # watchdog of a multi-rank job polling its events) must not invalidate the capture
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     self._decode_step(st, sp)
                 graph.replay()                                # capture records only; this runs step 2
             elif graph is not None:
