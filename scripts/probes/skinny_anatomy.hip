@@ -232,6 +232,111 @@ __global__ __launch_bounds__(512, 2) void skinny_k2(const bf16_t* __restrict__ A
         }
 }
 
+
+// Loader-wave variant: waves 0-3 stream weights and run the MFMAs; wave 4 does nothing but bring the A tiles in, by LDS-DMA into a
+// ring of NSLOT 128-wide slots, running ahead of the consumers.  Its memory queue holds only A requests (L2 hits), so an A tile
+// never waits behind the weight stream's in-order returns, and the consumers never wait for A.  One barrier per slice.
+template <int NSLOT>
+__global__ __launch_bounds__(320, 2) void skinny_ld(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B,
+                                                    float* __restrict__ C, long ldc, int M, int N, int K, int spr, int dbg) {
+    constexpr int KS = 128, ROWB = 256, NU = 4, MF = 4, SLOT = 64 * ROWB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];                 // [NSLOT][64 rows][256 B], chunk ^= row & 15
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int total = K / KS, s_begin = blockIdx.y * spr, s_end = min(total, s_begin + spr), ns = s_end - s_begin;
+    if (ns <= 0) return;
+    if (wave == 4) {
+        // ---------------------------------------------------------------- loader: 16 DMA instructions (1 KiB each) per slice
+        // instruction i covers rows 4i .. 4i+3: lane -> row 4i + (lane >> 4), LDS position lane & 15 holds chunk (lane & 15) ^ (row & 15)
+        auto issue = [&](int s) {
+            char* dst = smem + (s % NSLOT) * SLOT;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = 4 * i + g, ch = l15 ^ (row & 15);
+                const bf16_t* src = A + (long)min(row, M - 1) * lda + (long)(s_begin + s) * KS + ch * 8;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+            }
+        };
+        for (int s = 0; s < NSLOT - 1 && s < ns; ++s) issue(s);
+        for (int s = 0; s < ns; ++s) {
+            // slices s+1 .. s+NSLOT-2 may stay in flight; slice s must have landed
+            const int later = min(ns - 1, s + NSLOT - 2) - s;
+            if (later >= 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            else if (later == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                          // slot s ready; consumers are done with slot s-1
+            if (s + NSLOT - 1 < ns) issue(s + NSLOT - 1);
+        }
+        return;
+    }
+    // -------------------------------------------------------------------- consumers
+    const int n0 = blockIdx.x * 64 + wave * 16;
+    const bf16_t* bbase = B + ((long)(n0 >> 4) * (K >> 5)) * 512 + lane * 8;
+    auto load_w = [&](u32x4 (&w)[NU], int s) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) w[u] = __builtin_nontemporal_load((const u32x4*)(bbase + ((long)(s_begin + s) * NU + u) * 512));
+    };
+    f32x4 acc[MF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](const u32x4 (&w)[NU], int s) {
+        const char* buf = smem + (s % NSLOT) * SLOT;
+        bf16x8 af[2][MF];
+        auto read_a = [&](bf16x8 (&dst)[MF], int u) {
+            const int ch = u * 4 + g;
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) {
+                const int row = mf * 16 + l15;
+                dst[mf] = *(const bf16x8*)(buf + row * ROWB + ((ch ^ (row & 15)) * 16));
+            }
+        };
+        read_a(af[0], 0);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            if (u + 1 < NU) read_a(af[(u + 1) & 1], u + 1);
+            const bf16x8 wf = __builtin_bit_cast(bf16x8, w[u]);
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) acc[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][mf], wf, acc[mf], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // four weight register sets = three slices of prefetch (as many bytes in flight per wave as two 256-wide sets)
+    u32x4 w0[NU], w1[NU], w2[NU], w3[NU];
+    load_w(w0, 0);
+    if (1 < ns) load_w(w1, 1);
+    if (2 < ns) load_w(w2, 2);
+    for (int s = 0; s < ns; s += 4) {
+        __builtin_amdgcn_s_barrier(); if (s + 3 < ns) load_w(w3, s + 3); compute(w0, s);
+        if (s + 1 >= ns) break;
+        __builtin_amdgcn_s_barrier(); if (s + 4 < ns) load_w(w0, s + 4); compute(w1, s + 1);
+        if (s + 2 >= ns) break;
+        __builtin_amdgcn_s_barrier(); if (s + 5 < ns) load_w(w1, s + 5); compute(w2, s + 2);
+        if (s + 3 >= ns) break;
+        __builtin_amdgcn_s_barrier(); if (s + 6 < ns) load_w(w2, s + 6); compute(w3, s + 3);
+    }
+    const int n = n0 + l15;
+    const bool whole_k = (s_begin == 0 && s_end == total);
+    if (dbg & 8) {
+        float t = 0.f;
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) t += acc[mf][0] + acc[mf][1] + acc[mf][2] + acc[mf][3];
+        if (t == 1.2345e-30f) C[0] = t;
+        return;
+    }
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = mf * 16 + g * 4 + r;
+            if (m < M) {
+                float* c = C + (long)m * ldc + n;
+                if (whole_k) *c = acc[mf][r];
+                else atomicAdd(c, acc[mf][r]);
+            }
+        }
+}
+
 // pure read with the GEMM's own access pattern (each wave: its 16-column fragment stream, 8 KiB per slice)
 __global__ __launch_bounds__(256, 2) void stream_only(const bf16_t* __restrict__ B, float* __restrict__ C, int K, int spr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -251,8 +356,8 @@ __global__ __launch_bounds__(256, 2) void stream_only(const bf16_t* __restrict__
 
 int main() {
     const int M = 64;
-    const long wbytes_max = 152064L * 3584 * 2;
-    const int COPIES = 3;
+    const long wbytes_max = 37888L * 3584 * 2;
+    const int COPIES = 6;
     bf16_t *A, *W; float *C, *scratch; int* tickets;
     hipMalloc(&scratch, 1024L * 64 * 64 * 4 * 2); hipMalloc(&tickets, 4096); hipMemset(tickets, 0, 4096);
     hipMalloc(&A, (long)M * 18944 * 2); hipMalloc(&W, wbytes_max * COPIES); hipMalloc(&C, (long)M * 152064 * 4);
@@ -277,8 +382,9 @@ int main() {
         printf("  %-34s %7.1f us  %5.2f TB/s\n", name, ms / reps * 1e3, bytes / (ms / reps * 1e-3) / 1e12);
     };
     struct Shape { const char* name; int N, K, ranges; };
-    const Shape shapes[] = {{"gate|up 32768x3584 (512 x 1)", 32768, 3584, 1}, {"gate|up 37888x3584 (592 x 1)", 37888, 3584, 1},
-                            {"lm_head 152064x3584 (2376 x 1)", 152064, 3584, 1}};
+    const Shape shapes[] = {{"qkv 4608x3584 (72 groups x 7)", 4608, 3584, 7}, {"o 3584x3584 (56 x 9 -> 7)", 3584, 3584, 9},
+                            {"down 3584x18944 (56 x 9)", 3584, 18944, 9}, {"gate|up 32768x3584 (512 x 1)", 32768, 3584, 1},
+                            {"gate|up 37888x3584 (592 x 1)", 37888, 3584, 1}};
     for (const Shape& sh : shapes) {
         const int groups = sh.N / 64, slices = sh.K / 256;
         int spr = (slices + sh.ranges - 1) / sh.ranges;
@@ -287,7 +393,7 @@ int main() {
         const long wstride = (long)sh.N * sh.K;
         printf("%s: %d blocks, %d slices each, %.0f MB\n", sh.name, groups * ranges, spr, bytes / 1e6);
         run("stream only", [&](int r) { hipLaunchKernelGGL(stream_only, dim3(groups, ranges), dim3(256), 0, 0, W + (r % COPIES) * wstride, C, sh.K, spr); }, bytes);
-        const struct { const char* n; int d; } cfgs[] = {{"full kernel", 0}, {"no epilogue", 8}};
+        const struct { const char* n; int d; } cfgs[] = {{"full kernel", 0}, {"no epilogue", 8}, {"no A loads", 1}, {"no A loads, no epilogue", 9}};
         auto launch = [&](int nw, int d, int r) {
             const int g = sh.N / (nw * 16), g8 = (g + 7) / 8 * 8;
             const dim3 grid = (d & 16) ? dim3(g8 * ranges, 1) : dim3(g, ranges);
@@ -312,7 +418,23 @@ int main() {
                 }
             }
         }
-        if (ranges == 1) {
+        {
+            hipFuncSetAttribute((const void*)skinny_ld<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 256);
+            const int spr_l = 2 * spr;                                     // same K ranges, in 128-wide slices
+            for (int d : {0, 8}) {
+                char nm[96]; snprintf(nm, 96, "loader wave + 4 consumers, 4-slot A ring%s", d == 8 ? ", no epilogue" : "");
+                run(nm, [&](int r) { hipLaunchKernelGGL(skinny_ld<4>, dim3(groups, ranges), dim3(320), 4 * 64 * 256, 0, A, (long)sh.K, W + (r % COPIES) * wstride, C, (long)sh.N, M, sh.N, sh.K, spr_l, d); }, bytes);
+                if (d == 0) {
+                    hipMemset(C, 0, (long)M * sh.N * 4);
+                    hipLaunchKernelGGL(skinny_ld<4>, dim3(groups, ranges), dim3(320), 4 * 64 * 256, 0, A, (long)sh.K, W, C, (long)sh.N, M, sh.N, sh.K, spr_l, 0);
+                    hipDeviceSynchronize();
+                    hipMemcpy(hc, C, (long)M * sh.N * 4, hipMemcpyDeviceToHost);
+                    long bad = 0; for (long i = 0; i < (long)M * sh.N; ++i) bad += (hc[i] != (float)sh.K);
+                    if (bad) printf("      WRONG: %ld of %ld elements != K\n", bad, (long)M * sh.N);
+                }
+            }
+        }
+        if (false) {
             for (int occ : {3, 4}) {
                 for (int d : {0, 8, 1}) {
                     char nm[96]; snprintf(nm, 96, "128-wide slices, %d workgroups/CU%s", occ, d == 8 ? ", no epilogue" : d == 1 ? ", no A loads" : "");
@@ -332,7 +454,7 @@ int main() {
                 }
             }
         }
-        if (ranges == 1 && sh.N % 128 == 0) {
+        if (false) {
             for (int d : {0, 8, 1}) {
                 char nm[96]; snprintf(nm, 96, "8 waves x 128 columns, 128-wide slices, 2 workgroups/CU%s", d == 8 ? ", no epilogue" : d == 1 ? ", no A loads" : "");
                 run(nm, [&](int r) {
