@@ -136,8 +136,10 @@ def pmc_traffic(workload: str, kernel: str, live: bool):
         try:
             sys.path.insert(0, os.path.join(ROOT, "scripts"))
             import pmc_gemm_table
-            kinds = {"gemm_bf16_nt_256h_kernel<true, false, false>": {"nt", "swiglu"}, "gemm_bf16_nt_256h_kernel<true, false, true>": {"dx"},
-                     "gemm_bf16_nt_256h_kernel<true, true, true>": {"dw"}}[kernel]
+            kinds = {"gemm_bf16_nt_256h_kernel<true, false, false, true>": {"nt", "swiglu"},
+                     "gemm_bf16_nt_256h_kernel<true, false, false, false>": {"nt"},
+                     "gemm_bf16_nt_256h_kernel<true, false, true, true>": {"dx"},
+                     "gemm_bf16_nt_256h_kernel<true, true, true, false>": {"dw"}}[kernel]
             res = pmc_gemm_table.collect(kinds)
             return round(res["per_kernel"][kernel]["hbm_bytes_per_launch"]), "measured in this run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
         except Exception as exc:        # noqa: BLE001  -- the bench line must survive a profiler failure
@@ -348,13 +350,14 @@ def main():
     if rank == 0:
         samples = groups * Kgen * world * args.steps
         value = samples / elapsed
-        # the 256-tile GEMM has three instantiations (rocprof: gemm_bf16_nt_256h_kernel<true, TA, TB>): forward NT (the
-        # un-suffixed key), dX (trans_b) and dW (trans_a + trans_b, fp32 read-modify-write epilogue); the roofline object is
-        # for the one with the most time in the step
+        # the 256-tile GEMM runs as four instantiations in the step (rocprof: gemm_bf16_nt_256h_kernel<true, TA, TB, STG16>): forward
+        # NT with bf16 output and no residual (q|k|v, gate|up + SwiGLU: bf16 staging, persistent), forward NT with an fp32
+        # residual (o, down, lm_head), dX (trans_b) and dW (trans_a + trans_b, fp32 read-modify-write epilogue); the roofline
+        # object is for the one with the most time in the step
         fams = {k: v for k, v in prof.items() if k.startswith("gemm_bf16_nt_256h_kernel")}
         dom = max(fams, key=lambda k: fams[k]["seconds"]) if fams else "gemm_bf16_nt_256h_kernel"
         gemm = prof.get(dom, dict(tflops=0.0, launches=0, seconds=0.0, flops=0.0, bytes=0.0))
-        dom_name = dom if "<" in dom else dom + "<true, false, false>"
+        dom_name = dom if "<" in dom else dom + "<true, false, false, true>"
         out = {
             "metric": ("GRPO samples/sec (K=8 rollouts) Qwen2-VL-7B 16-frame" + (" [T-GRPO twin rollouts on]" if args.temporal else ""))
             if args.workload in ("cfg3", "cfg4")

@@ -17,8 +17,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 from gemm_step_shapes import SHAPES  # noqa: E402
 
-INST = {"nt": "gemm_bf16_nt_256h_kernel<true, false, false>", "swiglu": "gemm_bf16_nt_256h_kernel<true, false, false>",
-        "dx": "gemm_bf16_nt_256h_kernel<true, false, true>", "dw": "gemm_bf16_nt_256h_kernel<true, true, true>"}
+def inst(kind: str, f32: int) -> str:
+    """rocprof name of the instantiation <BALANCED, TA, TB, STG16> a step shape runs on (STG16 = bf16 output, no residual)."""
+    if kind == "swiglu" or (kind == "nt" and not f32):
+        return "gemm_bf16_nt_256h_kernel<true, false, false, true>"
+    if kind == "nt":
+        return "gemm_bf16_nt_256h_kernel<true, false, false, false>"
+    return "gemm_bf16_nt_256h_kernel<true, false, true, true>" if kind == "dx" else "gemm_bf16_nt_256h_kernel<true, true, true, false>"
 
 
 def _per_dispatch(db, counter):
@@ -66,7 +71,7 @@ def collect(kinds=None, reps=2, timeout=240):
         algo = 2.0 * (M * K + N * K) + out_b + ((4.0 * M * N) if (kind == "dw" or (kind == "nt" and f32 and N != 152064)) else 0.0)
         table.append(dict(kind=kind, M=M, N=N, K=K, launches_per_step=launches, fetch_kib=f, write_kib=w, hbm_bytes=hbm,
                           algorithmic_bytes=algo, ratio=hbm / algo))
-        t = tot.setdefault(INST[kind], [0.0, 0, 0.0])
+        t = tot.setdefault(inst(kind, f32), [0.0, 0, 0.0])
         t[0] += hbm * launches; t[1] += launches; t[2] += algo * launches
     return dict(method="rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over scripts/gemm_step_shapes.py; "
                        "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024; launch-weighted over the cfg3 step's shapes",

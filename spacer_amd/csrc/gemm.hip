@@ -47,7 +47,19 @@ struct GemmArgs {
     // 64-row copies of the operands' last K % 64 rows (same row strides lda / ldb); -1 = none
     int k_tail_tile;
     const bf16_t* A_tail; const bf16_t* B_tail;
+    // 256h kernel, persistent form: work items (whole tiles + K ranges of tail tiles) in the launch, walked by min(items, CUs)
+    // workgroups; stage_bf16 = bf16 output without a residual (and the SwiGLU form): the epilogue stages bf16 through half of the
+    // LDS and the next item's first K tile is requested under it (gemm_halftile.h)
+    int total_blocks, stage_bf16;
 };
+
+// workgroups of a persistent 256-tile launch: one per CU (SPACER_GEMM_PERSIST=0: one per work item, the round-1 form, for A/B runs)
+static unsigned persistent_grid(long items) {
+    static const int cus = [] { hipDeviceProp_t p; int d = 0; hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
+    const char* e = getenv("SPACER_GEMM_PERSIST");
+    if (e && e[0] == '0') return (unsigned)items;
+    return (unsigned)(items < cus ? items : cus);
+}
 
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
@@ -361,12 +373,12 @@ static int launch_gemm(const void* A, long lda, const void* B, long ldb, void* C
     }
     if (big) {
         constexpr int LDS = 8 * 128 * BK * 2;
-        static const int once = hipFuncSetAttribute((const void*)gemm_bf16_nt_256h_kernel<true>,
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS)
-                              + hipFuncSetAttribute((const void*)gemm_bf16_nt_256h_kernel<true, false, true>,
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS)
-                              + hipFuncSetAttribute((const void*)gemm_bf16_nt_256h_kernel<true, true, true>,
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        static const int once = hipFuncSetAttribute((const void*)gemm_bf16_nt_256h_kernel<true, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)
+                              + hipFuncSetAttribute((const void*)gemm_bf16_nt_256h_kernel<true, false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)
+                              + hipFuncSetAttribute((const void*)gemm_bf16_nt_256h_kernel<true, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)
+                              + hipFuncSetAttribute((const void*)gemm_bf16_nt_256h_kernel<true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)
+                              + hipFuncSetAttribute((const void*)gemm_bf16_nt_256h_kernel<true, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)
+                              + hipFuncSetAttribute((const void*)gemm_bf16_nt_256h_kernel<true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         (void)once;
         g.tiles_m = cdiv(M, 256); g.tiles_n = cdiv(N, 256);
         const long tiles = (long)g.tiles_m * g.tiles_n;
@@ -374,10 +386,18 @@ static int launch_gemm(const void* A, long lda, const void* B, long ldb, void* C
         tail_plan(tiles, cdiv(K, BK), have_ws && !nosplit, &g.full_tiles, &g.splits);
         g.slabs = have_ws ? (float*)epi->workspace : nullptr;
         const long tail_tiles = tiles - g.full_tiles;
-        const dim3 grid((unsigned)(g.full_tiles + tail_tiles * g.splits));
-        if (ta) hipLaunchKernelGGL((gemm_bf16_nt_256h_kernel<true, true, true>), grid, dim3(512), LDS, s, g);
-        else if (tb) hipLaunchKernelGGL((gemm_bf16_nt_256h_kernel<true, false, true>), grid, dim3(512), LDS, s, g);
-        else hipLaunchKernelGGL((gemm_bf16_nt_256h_kernel<true>), grid, dim3(512), LDS, s, g);
+        g.total_blocks = (int)(g.full_tiles + tail_tiles * g.splits);
+        g.stage_bf16 = (!g.out_f32 && !g.resid) ? 1 : 0;
+        const dim3 grid(g.stage_bf16 ? persistent_grid(g.total_blocks) : (unsigned)g.total_blocks);
+        if (g.stage_bf16) {
+            if (ta) hipLaunchKernelGGL((gemm_bf16_nt_256h_kernel<true, true, true, true>), grid, dim3(512), LDS, s, g);
+            else if (tb) hipLaunchKernelGGL((gemm_bf16_nt_256h_kernel<true, false, true, true>), grid, dim3(512), LDS, s, g);
+            else hipLaunchKernelGGL((gemm_bf16_nt_256h_kernel<true, false, false, true>), grid, dim3(512), LDS, s, g);
+        } else {
+            if (ta) hipLaunchKernelGGL((gemm_bf16_nt_256h_kernel<true, true, true, false>), grid, dim3(512), LDS, s, g);
+            else if (tb) hipLaunchKernelGGL((gemm_bf16_nt_256h_kernel<true, false, true, false>), grid, dim3(512), LDS, s, g);
+            else hipLaunchKernelGGL((gemm_bf16_nt_256h_kernel<true, false, false, false>), grid, dim3(512), LDS, s, g);
+        }
         if (g.splits > 1) hipLaunchKernelGGL(gemm_tail_reduce_kernel, dim3((unsigned)(tail_tiles * 32)), dim3(512), 0, s, g);
     } else {
         constexpr int LDS = 2 * (128 * BK * 2 + 128 * BK * 2);
@@ -424,10 +444,11 @@ extern "C" int spacer_gemm_swiglu_bf16(const void* A, long lda, const void* W, l
     g.k_tail_tile = -1; g.A_tail = nullptr; g.B_tail = nullptr;
     g.tiles_m = cdiv(M, 256); g.tiles_n = inter / 128;
     g.full_tiles = g.tiles_m * g.tiles_n; g.splits = 1; g.slabs = nullptr;      // no K-split tail: the reduce kernel has no SwiGLU form
+    g.total_blocks = g.full_tiles; g.stage_bf16 = 1;
     constexpr int LDS = 8 * 128 * BK * 2;
-    static const int once = hipFuncSetAttribute((const void*)gemm_bf16_nt_256h_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    static const int once = hipFuncSetAttribute((const void*)gemm_bf16_nt_256h_kernel<true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     (void)once;
-    hipLaunchKernelGGL((gemm_bf16_nt_256h_kernel<true>), dim3((unsigned)g.full_tiles), dim3(512), LDS, (hipStream_t)stream, g);
+    hipLaunchKernelGGL((gemm_bf16_nt_256h_kernel<true, false, false, true>), dim3(persistent_grid(g.total_blocks)), dim3(512), LDS, (hipStream_t)stream, g);
     SP_CHECK_LAUNCH();
     return SPACER_OK;
 }

@@ -35,6 +35,14 @@
 // A ragged contraction length (dW: K = tokens) costs nothing in the loop: the host copies the last K % 64 rows of both operands
 // into zero-padded 64-row tail buffers (caller's workspace) and the kernel stages that one K tile from them (a scalar
 // base-pointer select per DMA).
+//
+// Persistent form (round 2).  A launch whose work items outnumber the CUs runs min(items, CUs) workgroups, each walking the items
+// b, b + G, b + 2G, ... (item = a whole tile, or one K range of a tail tile).  When the output is bf16 without a residual (or the
+// SwiGLU form) the epilogue stages through the PARITY-1 half of the LDS only, as bf16 ([128 rows][512 B] per pass, 8-byte chunk
+// index ^= row & 15), and the first K tile of the workgroup's NEXT item is requested into the parity-0 half before the epilogue
+// starts: the ~8 us pipeline fill of every tile rides under the store phase of the tile before it.  (vmcnt also counts the
+// epilogue's stores; they are older than every DMA that a later counted wait is meant for, and returns are in order, so the
+// counted waits of the main loop stay conservative.)
 #include <type_traits>
 
 // pid (position in the launch's tile order) -> tile coordinates: groups of 4 tile-rows walked column by column, so the
@@ -51,7 +59,8 @@ __device__ __forceinline__ void tile_of_256(int pid, const GemmArgs& g, int& tm,
 typedef __attribute__((ext_vector_type(4))) short gemm_s16x4;
 typedef __attribute__((ext_vector_type(8))) short gemm_s16x8;
 
-template <bool BALANCED, bool TA = false, bool TB = false>
+// STG16: bf16 staging epilogue + early prologue (bf16 output without a residual, SwiGLU); else the fp32 staging of round 1
+template <bool BALANCED, bool TA = false, bool TB = false, bool STG16 = false>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
     constexpr int BM = 256, BN = 256;
     constexpr int HALF = 128 * BK * 2;                 // one half-tile image
@@ -64,10 +73,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
     // ---- block -> (tile, K range).  Blocks [0, full_tiles) own whole tiles (bijective XCD remap); the remaining
     // tiles (the last, partially filled round of the 256 CUs) are each cut into `splits` K ranges, so the tail of the
     // launch also fills the chip.  splits == 1 -> full_tiles == all tiles and there is no tail.
-    int pid, split = 0, kt0 = 0, ntl = (g.K + BK - 1) / BK;
+    int pid = 0, split = 0, kt0 = 0, nt = 0, tm = 0, tn = 0, m0 = 0, n0 = 0;
     bool tail = false;
-    {
-        const int b = blockIdx.x;
+    // ---- DMA sources: this wave owns pieces (wave*2 + i), i = 0..1, of every half-tile image.
+    // plain image: piece = 8 rows x 128 B;  contraction-major image: piece = 4 k-rows x 256 B.  32-bit element offsets
+    // relative to a per-K-tile scalar base (plain: + k0 elements; contraction-major: + k0 rows).
+    unsigned offA[2][2], offB[2][2];                   // [half][piece] element offsets of this lane's 16-byte chunk
+    auto setup = [&](int b) {                          // work item b: tile, K range, DMA offsets
+        split = 0; kt0 = 0; nt = (g.K + BK - 1) / BK; tail = false;
         if (b < g.full_tiles) {
             const int x = b & 7, q = g.full_tiles >> 3, r = g.full_tiles & 7;
             pid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
@@ -78,17 +91,10 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
             tail = true;
             const int nt_all = (g.K + BK - 1) / BK;
             kt0 = (int)((long)split * nt_all / g.splits);
-            ntl = (int)((long)(split + 1) * nt_all / g.splits) - kt0;
+            nt = (int)((long)(split + 1) * nt_all / g.splits) - kt0;
         }
-    }
-    int tm, tn;
-    tile_of_256(pid, g, tm, tn);
-    const int m0 = tm * BM, n0 = tn * BN;
-
-    // ---- DMA sources: this wave owns pieces (wave*2 + i), i = 0..1, of every half-tile image.
-    // plain image: piece = 8 rows x 128 B;  contraction-major image: piece = 4 k-rows x 256 B.  32-bit element offsets
-    // relative to a per-K-tile scalar base (plain: + k0 elements; contraction-major: + k0 rows).
-    unsigned offA[2][2], offB[2][2];                   // [half][piece] element offsets of this lane's 16-byte chunk
+        tile_of_256(pid, g, tm, tn);
+        m0 = tm * BM; n0 = tn * BN;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -119,7 +125,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
                 offB[h][i] = (unsigned)((long)rb * g.ldb + chunk * 8);
             }
         }
-    const int nt = ntl;                                 // K tiles of THIS block: global tiles kt0 .. kt0+nt-1
+    };
+    // K tiles of the current item: global tiles kt0 .. kt0+nt-1
     auto stage = [&](int par, int which, int t) {
         const int kt = kt0 + (t < nt ? t : nt - 1);     // global K tile (wave-uniform)
         char* dst = smem + (par * 4 + which) * HALF + wave * 2048;
@@ -134,23 +141,33 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
         }
     };
 
+    f32x4 acc[8][4];
+    const EpiArgs e = {g.C, g.bias, g.resid, g.ldc, g.ldr, g.M, g.N, g.out_f32, g.act, g.alpha};
+    const int sw = g.swiglu_inter;
+    int vb = blockIdx.x;
+    setup(vb);
+    bool early = false;                                  // K tile 0 of this item was requested during the previous epilogue
+  while (true) {
+    // The per-lane fragment offsets are recomputed for every work item from an opaque copy of the lane id: as loop invariants
+    // they would stay live across the epilogue, and the register allocator then spills inside the K loop (scratch reloads there
+    // drain the DMA queue through the compiler's vmcnt(0)).
+    int fl = lane;
+    asm volatile("" : "+v"(fl));
     // ---- fragment read offsets: row (lane&15) of a 16-row fragment, chunk (kk*4 + lane>>4) ^ swizzle(row)
-    const int fsw = (lane & 15) >> 1;                                        // (row >> 1) & 7 for every fragment row
-    const int fo0 = (lane & 15) * 128 + (((lane >> 4) ^ fsw) << 4);          // kk = 0
+    const int fsw = (fl & 15) >> 1;                                        // (row >> 1) & 7 for every fragment row
+    const int fo0 = (fl & 15) * 128 + (((fl >> 4) ^ fsw) << 4);          // kk = 0
     const int fo1 = fo0 ^ 64;                                                // kk = 1: chunk + 4
     const int aoff = wr * 64 * 128, boff = wc * 32 * 128;
     // contraction-major image: lane i of a 16-lane group supplies the address of k-row kk*32 + g*8 + (i>>2) [+4 for the
     // second read], columns cb + 4*(i&3) .. +3 (8 bytes), and receives column cb + i of the four rows.  The swizzle term
     // (row & 3) | ((row >> 3) & 1) << 2 of those rows does not depend on kk or on the +4, so it is a per-lane constant and a
     // fragment's address is  img + [lane part] + ((block ^ hx) << 5) + kk*8192 (+1024), block = 16-column block of the image.
-    const int tq = (lane & 15) >> 2, tg = lane >> 4;
+    const int tq = (fl & 15) >> 2, tg = fl >> 4;
     const int hx = tq | ((tg & 1) << 2);
-    const int tlane = (tg * 8 + tq) * 256 + (lane & 3) * 8;
-    int toA[4], toB[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) toA[i] = tlane + (((wr * 4 + i) ^ hx) << 5);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) toB[j] = tlane + (((wc * 2 + j) ^ hx) << 5);
+    const int tlane = (tg * 8 + tq) * 256 + (fl & 3) * 8;
+    // tlane has no bit in 5..7, so tlane + ((block ^ hx) << 5) = (tlane ^ (hx << 5)) ^ (block << 5): ONE per-lane register and
+    // a scalar XOR per fragment (block = wr*4 + i / wc*2 + j is wave-uniform) instead of six offset registers
+    const int tbase = tlane ^ (hx << 5);
     // Issued as inline asm: the ds_read_tr16 builtin makes hipcc drain the LDS-DMA queue (s_waitcnt vmcnt(0)) in front of
     // every read -- it cannot tell the read from the in-flight global_load_lds writes of OTHER images -- which serialises the
     // whole pipeline.  The asm form is invisible to that pass; its completion is covered by the explicit lgkmcnt(0) that
@@ -164,21 +181,20 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
         return __builtin_bit_cast(bf16x8, both);
     };
     auto fragA = [&](const char* img, int i, int kk) -> bf16x8 {
-        if (TA) return frag_t16(img + toA[i] + kk * 8192);
+        if (TA) return frag_t16(img + (tbase ^ ((wr * 4 + i) << 5)) + kk * 8192);
         return *(const bf16x8*)(img + aoff + i * 2048 + (kk ? fo1 : fo0));
     };
     auto fragB = [&](const char* img, int j, int kk) -> bf16x8 {
-        if (TB) return frag_t16(img + toB[j] + kk * 8192);
+        if (TB) return frag_t16(img + (tbase ^ ((wc * 2 + j) << 5)) + kk * 8192);
         return *(const bf16x8*)(img + boff + j * 2048 + (kk ? fo1 : fo0));
     };
-    f32x4 acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // ---- prologue: tile 0 complete + the first two halves of tile 1, in steady-state issue order
-    stage(0, A_LO, 0); stage(0, B_LO, 0); stage(0, B_HI, 0); stage(0, A_HI, 0);
+    if (!early) { stage(0, A_LO, 0); stage(0, B_LO, 0); stage(0, B_HI, 0); stage(0, A_HI, 0); }
     stage(1, A_LO, 1); stage(1, B_LO, 1);
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                         // A-lo(0), B-lo(0) landed
     __builtin_amdgcn_sched_barrier(0);
@@ -267,6 +283,10 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
     if (wr == 0) __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // redundant tail DMAs must land before exit
 
+    // only the bf16-staging instantiations are persistent (the others keep one work item per workgroup and the register
+    // allocation of the non-looping kernel: the fp32 read-modify-write dW form has no register to give to a loop)
+    const int nvb = vb + (int)gridDim.x;
+    const bool more = STG16 && nvb < g.total_blocks;
     // ---- split-K tail: leave this block's fp32 partial tile as a slab (fragment-major, 16 B per lane, coalesced);
     // gemm_tail_reduce_kernel sums a tile's slabs in split order and runs the epilogue (launched right behind).
     if (tail) {
@@ -277,18 +297,89 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 mine[(i * 4 + j) * 512 + tid] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-        return;
+        if (!more) return;
+        vb = nvb; setup(vb); early = false;
+        __syncthreads();                                                     // every wave is done with the operand images
+        continue;
     }
 
     // ---- epilogue, staged through LDS so that every global store instruction of a wave covers ONE full output row of
     // the tile (1 KiB fp32 / 512 B bf16).  Writing accumulator fragments straight out gives 16 row segments of 32 B per
     // instruction, and those partial-line writes cost ~25 us per tile (a quarter of a K = 3584 launch).
+    const int cm0 = m0, cn0 = n0, ctn = tn;                                  // this tile; m0 / n0 / tn move on to the next item below
+    early = more && STG16;
+    if (more) { vb = nvb; setup(vb); }
+    __syncthreads();                                                         // every wave is done with the operand images
+    if (early) { stage(0, A_LO, 0); stage(0, B_LO, 0); stage(0, B_HI, 0); stage(0, A_HI, 0); }   // next item's K tile 0 -> parity 0
+    if constexpr (STG16) {
+        // bf16 staging in the parity-1 half: [128 rows][256 cols] bf16 = 64 KiB per pass; 8-byte chunk (4 columns) index ^= row & 15:
+        // a fragment store (16 rows x one chunk per 16-lane group) and a row read (64 chunks of one row) are both conflict-free.
+        // alpha / bias / activation and the ONE rounding happen on the way in (no residual in this form).
+        char* stg = smem + 4 * HALF;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            if (wr == pass) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int nl = wc * 64 + j * 16 + (lane >> 4) * 4;          // column inside the tile
+                    float b4[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (e.bias) {
+                        const int nb = sw ? (nl < 128 ? 0 : sw - 128) + ctn * 128 + nl : cn0 + nl;   // weight row of that column
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) b4[q] = (nb + q < e.N) ? bf2f(e.bias[nb + q]) : 0.f;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int row = i * 16 + (lane & 15);
+                        const uint32_t lo = pack_bf2(apply_act(acc[i][j][0] * e.alpha + b4[0], e.act), apply_act(acc[i][j][1] * e.alpha + b4[1], e.act));
+                        const uint32_t hi = pack_bf2(apply_act(acc[i][j][2] * e.alpha + b4[2], e.act), apply_act(acc[i][j][3] * e.alpha + b4[3], e.act));
+                        *(uint2*)(stg + row * 512 + (((nl >> 2) ^ (row & 15)) << 3)) = make_uint2(lo, hi);
+                    }
+                }
+            }
+            __syncthreads();
+            if (sw) {
+                // SwiGLU: a half wave per tile row; lane l reads the gate chunk l and the up chunk l + 32 of the row (bf16, what the
+                // unfused path stores and swiglu_fwd_kernel reads back) and writes 4 outputs = 8 bytes
+                for (int it = 0; it < 8; ++it) {
+                    const int row = it * 16 + wave * 2 + (lane >> 5), l = lane & 31;
+                    const uint2 gv = *(const uint2*)(stg + row * 512 + ((l ^ (row & 15)) << 3));
+                    const uint2 uv = *(const uint2*)(stg + row * 512 + (((l + 32) ^ (row & 15)) << 3));
+                    const int m = cm0 + pass * 128 + row;
+                    if (m < e.M) {
+                        const uint32_t g01 = gv.x, g23 = gv.y, u01 = uv.x, u23 = uv.y;
+                        if (g.C2) {
+                            bf16_t* c2 = (bf16_t*)g.C2 + (long)m * g.ldc2 + ctn * 128 + l * 4;
+                            *(uint2*)c2 = make_uint2(g01, g23);
+                            *(uint2*)(c2 + sw) = make_uint2(u01, u23);
+                        }
+                        const float g0 = bf_lo(g01), g1 = bf_hi(g01), g2 = bf_lo(g23), g3 = bf_hi(g23);
+                        const uint32_t o01 = pack_bf2(g0 * (1.f / (1.f + __expf(-g0))) * bf_lo(u01), g1 * (1.f / (1.f + __expf(-g1))) * bf_hi(u01));
+                        const uint32_t o23 = pack_bf2(g2 * (1.f / (1.f + __expf(-g2))) * bf_lo(u23), g3 * (1.f / (1.f + __expf(-g3))) * bf_hi(u23));
+                        *(uint2*)((bf16_t*)e.C + (long)m * e.ldc + ctn * 128 + l * 4) = make_uint2(o01, o23);
+                    }
+                }
+            } else {
+                for (int it = 0; it < 16; ++it) {
+                    const int row = it * 8 + wave;                                // one wave = one tile row
+                    const uint2 v = *(const uint2*)(stg + row * 512 + ((lane ^ (row & 15)) << 3));
+                    const int m = cm0 + pass * 128 + row, n = cn0 + lane * 4;
+                    if (m < e.M && n < e.N) {
+                        bf16_t* c = (bf16_t*)e.C + (long)m * e.ldc + n;
+                        if (n + 4 <= e.N && (e.ldc % 4) == 0) *(uint2*)c = v;
+                        else {
+                            const bf16_t t4[4] = {(bf16_t)(v.x & 0xffffu), (bf16_t)(v.x >> 16), (bf16_t)(v.y & 0xffffu), (bf16_t)(v.y >> 16)};
+                            for (int q = 0; q < 4 && n + q < e.N; ++q) c[q] = t4[q];
+                        }
+                    }
+                }
+            }
+            if (pass == 0) __syncthreads();
+        }
+    } else {
     // Two passes (wave row 0, then 1): [128 rows][256 cols] fp32 = the whole 128 KiB; 16-byte chunk index ^= row & 7 keeps
     // the fragment writes (8 rows per store group) and the row reads conflict-free.  alpha / bias / activation are applied
     // on the way in, residual + conversion on the way out (one rounding, as before).
-    const EpiArgs e = {g.C, g.bias, g.resid, g.ldc, g.ldr, g.M, g.N, g.out_f32, g.act, g.alpha};
-    const int sw = g.swiglu_inter;
-    __syncthreads();                                                         // every wave is done with the operand images
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         if (wr == pass) {
@@ -297,7 +388,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
                 const int nl = wc * 64 + j * 16 + (lane >> 4) * 4;              // column inside the tile
                 float b4[4] = {0.f, 0.f, 0.f, 0.f};
                 if (e.bias) {
-                    const int nb = sw ? (nl < 128 ? 0 : sw - 128) + tn * 128 + nl : n0 + nl;   // weight row of that column
+                    const int nb = sw ? (nl < 128 ? 0 : sw - 128) + ctn * 128 + nl : cn0 + nl;   // weight row of that column
 #pragma unroll
                     for (int q = 0; q < 4; ++q) b4[q] = (nb + q < e.N) ? bf2f(e.bias[nb + q]) : 0.f;
                 }
@@ -314,39 +405,18 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
             }
         }
         __syncthreads();
-
-        if (sw) {
-            // SwiGLU: a half wave per tile row; lane l reads the gate chunk l and the up chunk l + 32 of the row, rounds both to
-            // bf16 (what the unfused path stores and swiglu_fwd_kernel reads back) and writes 4 outputs = 8 bytes
-            for (int it = 0; it < 8; ++it) {
-                const int row = it * 16 + wave * 2 + (lane >> 5), l = lane & 31;
-                const float4 gv = *(const float4*)(smem + row * 1024 + ((l ^ (row & 7)) << 4));
-                const float4 uv = *(const float4*)(smem + row * 1024 + (((l + 32) ^ (row & 7)) << 4));
-                const int m = m0 + pass * 128 + row;
-                if (m < e.M) {
-                    const uint32_t g01 = pack_bf2(gv.x, gv.y), g23 = pack_bf2(gv.z, gv.w);
-                    const uint32_t u01 = pack_bf2(uv.x, uv.y), u23 = pack_bf2(uv.z, uv.w);
-                    if (g.C2) {
-                        bf16_t* c2 = (bf16_t*)g.C2 + (long)m * g.ldc2 + tn * 128 + l * 4;
-                        *(uint2*)c2 = make_uint2(g01, g23);
-                        *(uint2*)(c2 + sw) = make_uint2(u01, u23);
-                    }
-                    const float g0 = bf_lo(g01), g1 = bf_hi(g01), g2 = bf_lo(g23), g3 = bf_hi(g23);
-                    const uint32_t o01 = pack_bf2(g0 * (1.f / (1.f + __expf(-g0))) * bf_lo(u01), g1 * (1.f / (1.f + __expf(-g1))) * bf_hi(u01));
-                    const uint32_t o23 = pack_bf2(g2 * (1.f / (1.f + __expf(-g2))) * bf_lo(u23), g3 * (1.f / (1.f + __expf(-g3))) * bf_hi(u23));
-                    *(uint2*)((bf16_t*)e.C + (long)m * e.ldc + tn * 128 + l * 4) = make_uint2(o01, o23);
-                }
-            }
-        } else {
-            for (int it = 0; it < 16; ++it) {
-                const int row = it * 8 + wave;                                // one wave = one tile row
-                const float4 v = *(const float4*)(smem + row * 1024 + ((lane ^ (row & 7)) << 4));
-                const int m = m0 + pass * 128 + row, n = n0 + lane * 4;
-                if (m < e.M && n < e.N) store_row4(e, m, n, v);
-            }
+        for (int it = 0; it < 16; ++it) {
+            const int row = it * 8 + wave;                                // one wave = one tile row
+            const float4 v = *(const float4*)(smem + row * 1024 + ((lane ^ (row & 7)) << 4));
+            const int m = cm0 + pass * 128 + row, n = cn0 + lane * 4;
+            if (m < e.M && n < e.N) store_row4(e, m, n, v);
         }
         if (pass == 0) __syncthreads();
     }
+    }
+    if (!more) return;
+    __syncthreads();                                                         // staging reads done before the next item's DMA lands there
+  }
 }
 
 // Sums the K-split partial tiles of the tail (written by gemm_bf16_nt_256h_kernel) in split order -- deterministic --

@@ -117,7 +117,11 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = N
                                           M, N, K, C.byref(epi), _stream()), "gemm_bf16_nt")
     ka = algo_k or K       # algorithmic contraction length (dW GEMMs run on a zero-padded token dim)
     if t0 is not None:
-        name = "gemm_bf16_nt_256h_kernel" if _lib.load().spacer_gemm_tile(M, N, K, 1 if split_k else 0) == 256 else "gemm_bf16_nt_kernel"
+        # rocprof names the 256-tile instantiations <BALANCED, TA, TB, STG16>; STG16 = bf16 output without a residual (bf16 staging
+        # epilogue, persistent workgroups)
+        stg = "true" if (out.dtype == BF16 and residual is None) else "false"
+        name = (f"gemm_bf16_nt_256h_kernel<true, false, false, {stg}>"
+                if _lib.load().spacer_gemm_tile(M, N, K, 1 if split_k else 0) == 256 else "gemm_bf16_nt_kernel")
         PROFILER.end(name, t0, 2.0 * M * N * ka, 2.0 * (M * ka + N * ka) + out.element_size() * M * N)
     if PROFILER.by_shape and t0 is not None:
         s0, e0 = PROFILER.records[-1][1], PROFILER.records[-1][2]
@@ -149,8 +153,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, trans_b: bo
     check(_lib.load().spacer_gemm_bf16(_ptr(a), _rowmajor(a), _ptr(b), _rowmajor(b), _ptr(out), _rowmajor(out), M, N, Kc,
                                        int(trans_a), int(trans_b), C.byref(epi), _stream()), "gemm_bf16")
     if t0 is not None:
-        # rocprof names the three instantiations <BALANCED, TA, TB>: <true, false, false> is the forward (NT) one
-        name = "gemm_bf16_nt_256h_kernel<true, true, true>" if trans_a else "gemm_bf16_nt_256h_kernel<true, false, true>"
+        stg = "true" if (out.dtype == BF16 and residual is None) else "false"
+        name = f"gemm_bf16_nt_256h_kernel<true, {'true' if trans_a else 'false'}, true, {stg}>"
         rmw = out.element_size() * M * N if residual is not None else 0
         PROFILER.end(name, t0, 2.0 * M * N * Kc, 2.0 * (M * Kc + N * Kc) + out.element_size() * M * N + rmw)
         if PROFILER.by_shape:
@@ -177,7 +181,7 @@ def gemm_swiglu(a: torch.Tensor, w_gu: torch.Tensor, *, bias=None, keep_gu: bool
                                               _ptr(gu), _rowmajor(gu) if gu is not None else 0, M, inter, K, _stream()),
           "gemm_swiglu_bf16")
     if t0 is not None:
-        PROFILER.end("gemm_bf16_nt_256h_kernel", t0, 2.0 * M * two_i * K,
+        PROFILER.end("gemm_bf16_nt_256h_kernel<true, false, false, true>", t0, 2.0 * M * two_i * K,
                      2.0 * (M * K + two_i * K) + 2.0 * M * (inter + (two_i if keep_gu else 0)))
         if PROFILER.by_shape:
             s0, e0 = PROFILER.records[-1][1], PROFILER.records[-1][2]
