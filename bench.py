@@ -377,7 +377,10 @@ def main():
                          "traffic": None, "launches": gemm["launches"],
                          "algorithmic_bytes_per_launch": round(gemm["bytes"] / max(1, gemm["launches"])),
                          "avg_launch_us": round(1e6 * gemm["seconds"] / max(1, gemm["launches"]), 2),
-                         "share_of_step": round(gemm["seconds"] / elapsed, 3)},
+                         "share_of_step": round(gemm["seconds"] / elapsed, 3),
+                         # all instantiations of the same kernel template together (rocprof lists them as separate rows)
+                         "template_share_of_step": round(sum(v["seconds"] for v in fams.values()) / elapsed, 3),
+                         "template_tflops": round(sum(v["flops"] for v in fams.values()) / max(1e-9, sum(v["seconds"] for v in fams.values())) / 1e12, 2)},
             "kernels": {k: {"tflops": round(v["tflops"], 2), "launches": v["launches"], "seconds": round(v["seconds"], 4)}
                         for k, v in prof.items()},
         }
