@@ -275,6 +275,9 @@ class GRPOEngine:
         groups, each group's rows enter the loss kernel with 1/len(prompts) -- with G x the rows per kernel launch."""
         cfg, Gn = self.cfg, len(prompts)
         Kn, C = completions[0].shape
+        # the rollouts of this step are done: the fragment-major decode copies of the weights (1x the LLM, 14 GB at 7B) are
+        # rebuilt after the optimizer step anyway, so their memory goes to the scoring passes
+        self.roll.invalidate()
         comp_all = torch.cat(completions, 0)
         mask, lengths = K.completion_mask(comp_all, cfg.eos_token_id)
         entries = [(p.ids, p.pix, p.grids) for p in prompts]
