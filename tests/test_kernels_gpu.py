@@ -434,6 +434,33 @@ def test_attention_decode_shared_prefix(dev):
             assert_close(o[b], want, 2e-2, 2e-2, f"shared decode attn b={b} tl={tl}")
 
 
+def test_gemm_persistent_workgroups_match_one_item_per_workgroup(dev, monkeypatch):
+    """bf16 output without a residual runs on persistent workgroups (min(items, CUs) of them, the next item's first K tile
+    requested under the epilogue); SPACER_GEMM_PERSIST=0 launches one workgroup per item.  Same arithmetic: bit-identical, for
+    NT / dX / SwiGLU shapes with more items than CUs, ragged edges and a split-K tail."""
+    cases = [("nt", 4160, 5120, 1280), ("nt", 5498, 4608, 3584), ("dx", 4160, 5120, 1280), ("swiglu", 4200, 8192, 512), ("nt", 2831, 6152, 704)]
+    for kind, M, N, Kd in cases:
+        a = rnd((M, Kd), dev, 1, 0.5)
+        outs = []
+        for persist in ("1", "0"):
+            monkeypatch.setenv("SPACER_GEMM_PERSIST", persist)
+            if kind == "nt":
+                b = rnd((N, Kd), dev, 2, 0.05)
+                outs.append(K.gemm_nt(a, b, bias=rnd((N,), dev, 3, 0.2)))
+            elif kind == "dx":
+                b = rnd((Kd, N), dev, 2, 0.05)
+                outs.append(K.gemm(a, b, trans_b=True))
+            else:
+                w = rnd((N, Kd), dev, 2, 0.05)
+                act, gu = K.gemm_swiglu(a, w)
+                outs.append(torch.cat([act, gu], 1))
+        assert torch.equal(outs[0], outs[1]), f"{kind} {M}x{N}x{Kd}: persistent form differs by {float((outs[0].float() - outs[1].float()).abs().max())}"
+    monkeypatch.delenv("SPACER_GEMM_PERSIST")
+    # and against fp32 torch for one of them (the persistent path is the default everywhere else in the suite)
+    a, b = rnd((4160, 1280), dev, 1, 0.5), rnd((5120, 1280), dev, 2, 0.05)
+    assert_close(K.gemm_nt(a, b), a.float() @ b.float().t(), 2e-2, 2e-2, "persistent gemm vs fp32")
+
+
 def test_gemm_swiglu_epilogue_is_the_two_step_path(dev):
     """gate|up GEMM with the SwiGLU in its epilogue == GEMM into gu + swiglu_fwd, bit for bit (ragged M, bias, no gu)."""
     for M, I, Kd, with_bias in ((3000, 2048, 512, False), (4160, 3456, 1280, True), (5498, 1024, 256, False), (1402, 18944, 3584, False)):
