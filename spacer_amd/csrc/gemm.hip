@@ -70,6 +70,11 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     }
 }
 
+// four values at once, NOT inlined: the 256 tile's staged epilogue calls it from 32 unrolled fragment bodies
+__device__ __noinline__ f32x4 apply_act4(f32x4 v, int act) {
+    return (f32x4){apply_act(v[0], act), apply_act(v[1], act), apply_act(v[2], act), apply_act(v[3], act)};
+}
+
 // Issue the global->LDS DMA of one ROWS x 64 bf16 tile (rows r0.., cols k0..k0+63) into `lds` (ROWS*128 B).
 // ROWS/8 wave-instructions of 1 KiB cover the tile; wave w issues instructions w*PER .. w*PER+PER-1.
 template <int ROWS, int NWAVES>

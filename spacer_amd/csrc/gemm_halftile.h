@@ -328,12 +328,24 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) b4[q] = (nb + q < e.N) ? bf2f(e.bias[nb + q]) : 0.f;
                     }
+                    // the activation switch is hoisted out of the 32 unrolled fragment bodies: inlined per element it made the
+                    // epilogue 11.7 K instructions (~70 KB, more than the instruction cache two CUs share) that every tile walked
+                    // through even with act = none -- 9-12 us per tile round
+                    if (e.act == SPACER_ACT_NONE) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int row = i * 16 + (lane & 15);
-                        const uint32_t lo = pack_bf2(apply_act(acc[i][j][0] * e.alpha + b4[0], e.act), apply_act(acc[i][j][1] * e.alpha + b4[1], e.act));
-                        const uint32_t hi = pack_bf2(apply_act(acc[i][j][2] * e.alpha + b4[2], e.act), apply_act(acc[i][j][3] * e.alpha + b4[3], e.act));
-                        *(uint2*)(stg + row * 512 + (((nl >> 2) ^ (row & 15)) << 3)) = make_uint2(lo, hi);
+                        for (int i = 0; i < 8; ++i) {
+                            const int row = i * 16 + (lane & 15);
+                            const uint32_t lo = pack_bf2(acc[i][j][0] * e.alpha + b4[0], acc[i][j][1] * e.alpha + b4[1]);
+                            const uint32_t hi = pack_bf2(acc[i][j][2] * e.alpha + b4[2], acc[i][j][3] * e.alpha + b4[3]);
+                            *(uint2*)(stg + row * 512 + (((nl >> 2) ^ (row & 15)) << 3)) = make_uint2(lo, hi);
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const int row = i * 16 + (lane & 15);
+                            const f32x4 v = apply_act4(acc[i][j] * e.alpha + (f32x4){b4[0], b4[1], b4[2], b4[3]}, e.act);
+                            *(uint2*)(stg + row * 512 + (((nl >> 2) ^ (row & 15)) << 3)) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                        }
                     }
                 }
             }
@@ -395,12 +407,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int row = i * 16 + (lane & 15);
-                    float4 v;
-                    v.x = apply_act(acc[i][j][0] * e.alpha + b4[0], e.act);
-                    v.y = apply_act(acc[i][j][1] * e.alpha + b4[1], e.act);
-                    v.z = apply_act(acc[i][j][2] * e.alpha + b4[2], e.act);
-                    v.w = apply_act(acc[i][j][3] * e.alpha + b4[3], e.act);
-                    *(float4*)(smem + row * 1024 + (((nl >> 2) ^ (row & 7)) << 4)) = v;
+                    f32x4 v = acc[i][j] * e.alpha + (f32x4){b4[0], b4[1], b4[2], b4[3]};
+                    if (e.act != SPACER_ACT_NONE) v = apply_act4(v, e.act);          // out of line: see the bf16 staging form
+                    *(float4*)(smem + row * 1024 + (((nl >> 2) ^ (row & 7)) << 4)) = make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
         }
