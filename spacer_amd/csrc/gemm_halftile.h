@@ -316,8 +316,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
         // a fragment store (16 rows x one chunk per 16-lane group) and a row read (64 chunks of one row) are both conflict-free.
         // alpha / bias / activation and the ONE rounding happen on the way in (no residual in this form).
         char* stg = smem + 4 * HALF;
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {                           // (not unrolled: the body does not index registers by `pass`)
             if (wr == pass) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
