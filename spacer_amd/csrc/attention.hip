@@ -200,210 +200,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     }
 }
 
-// ================================================================================================ forward, LDS-DMA form
-// Same decomposition and arithmetic as attn_fwd_kernel; what changes is how K / V tiles reach LDS.  There: global -> registers
-// (prefetched one tile ahead) -> ds_write into ONE pair of images, two barriers per tile.  Here: global_load_lds DMA straight
-// into TWO pairs of images (64 KiB per workgroup, still two workgroups per CU), issued one tile ahead, ONE barrier per tile:
+// ================================================================================================ forward, pipelined form
+// Same decomposition and arithmetic as attn_fwd_kernel.  K / V tiles reach LDS by global_load_lds DMA straight into TWO pairs of
+// images (64 KiB per workgroup, still two workgroups per CU), issued one tile ahead, ONE barrier per tile:
 //     top of tile t:  s_waitcnt vmcnt(0)  (my pieces of tile t landed)  ->  s_barrier (everyone's landed, and everyone is done
 //                     with tile t-1's buffer)  ->  issue the DMA of tile t+1 into that buffer  ->  compute tile t.
-// No register staging (-32 VGPRs), no ds_write pass, no swizzle VALU on the store side (the swizzle sits on the DMA source
-// address).  Rows past a ragged tile's end are fetched from its last valid row (finite; their scores are masked), the D = 80
-// image's padding chunks from chunk 0 of the row (finite; they meet Q's zero padding).  The V^T fragments are read with
-// inline-asm ds_read_b64_tr_b16 in batches with counted lgkmcnt waits: through the builtin hipcc drains the in-flight DMA
-// (s_waitcnt vmcnt(0)) before every transposing read.
-typedef __attribute__((ext_vector_type(2))) unsigned int attn_u32x2;
-
-template <int D>
-__global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(AttnArgs a) {
-    constexpr int DC = (D + 31) / 32;      // 32-wide contraction chunks for QK^T (D=80 -> 3, zero padded)
-    constexpr int DF = D / 16;             // 16-wide d blocks of O^T
-    constexpr int BUF = 2 * AT_RM_BYTES;   // one K image + one V image
-    extern __shared__ __attribute__((aligned(16))) char smem[];    // [2][K | V]
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int seg_id = a.lpt ? a.num_segs - 1 - blockIdx.x / a.nqb : blockIdx.x / a.nqb;
-    const int qb = a.lpt ? a.nqb - 1 - blockIdx.x % a.nqb : blockIdx.x % a.nqb;
-    const int h = blockIdx.y, hk = h / (a.Hq / a.Hkv);
-    const spacer_attn_segment seg = a.segs[seg_id];
-    const int qb0 = qb * BQ;
-    if (qb0 >= seg.q_len) return;
-    const int l15 = lane & 15, g = lane >> 4;
-    const int wq0 = qb0 + wave * 32;
-
-    bf16x8 qf[2][DC];
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-        int qi = wq0 + f * 16 + l15;
-        qi = qi < seg.q_len ? qi : seg.q_len - 1;
-        const bf16_t* qp = a.q + (long)(seg.q_start + qi) * a.q_stride + (long)h * D;
-#pragma unroll
-        for (int dc = 0; dc < DC; ++dc) qf[f][dc] = frag_global<D>(qp, dc, lane);
-    }
-    f32x4 oacc[2][DF];
-#pragma unroll
-    for (int f = 0; f < 2; ++f)
-#pragma unroll
-        for (int d = 0; d < DF; ++d) oacc[f][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
-    const float c2 = a.scale * 1.4426950408889634f;
-
-    const int own_len = a.causal ? min(seg.q_len, qb0 + BQ) : seg.q_len;
-    const int n_pre = (seg.pre_len + BKV - 1) / BKV, n_tiles = n_pre + (own_len + BKV - 1) / BKV;
-
-    // DMA pieces: waves 0,1 fill the K image (pieces 0..15), waves 2,3 the V image; piece = 4 rows x 256 B
-    const bf16_t* gsrc = (wave >= 2 ? a.v : a.k) + (long)hk * D;
-    const int img_off = (wave >= 2 ? AT_RM_BYTES : 0) + (wave & 1) * 8 * 1024;
-    auto issue_tile = [&](int t, int buf) {
-        const KeyTile kt = key_tile(seg, n_pre, own_len, t);
-        const int valid = kt.len - kt.rel0;                                   // >= 1
-        const bf16_t* base = gsrc + (long)(kt.start_abs + kt.rel0) * a.kv_stride;
-        char* dst = smem + buf * BUF + img_off;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            int row = (wave & 1) * 32 + 4 * i + (lane >> 4);
-            int c = (lane & 15) ^ (row & 15);                                 // logical 16-byte chunk stored at this lane's LDS position
-            if (c >= D / 8) c = 0;
-            row = row < valid ? row : valid - 1;
-            const bf16_t* src = base + (long)row * a.kv_stride + c * 8;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
-        }
-    };
-    // V^T operand fragment (same slots as frag_tr) by two transposing reads, issued without a wait
-    auto vfrag_issue = [&](attn_u32x2& lo, attn_u32x2& hi, const char* v_img, int db, int c) {
-        const int i = lane & 15;
-        const int chunk = db * 2 + ((i & 3) >> 1), sub = (i & 1) * 8;
-        const int r0 = (2 * c) * 16 + 4 * g + (i >> 2), r1 = r0 + 16;
-        const unsigned a0 = (unsigned)(uintptr_t)(v_img + r0 * AT_RM_ROW_BYTES + ((chunk ^ (r0 & 15)) * 16) + sub);
-        const unsigned a1 = (unsigned)(uintptr_t)(v_img + r1 * AT_RM_ROW_BYTES + ((chunk ^ (r1 & 15)) * 16) + sub);
-        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3" : "=&v"(lo), "=&v"(hi) : "v"(a0), "v"(a1));
-    };
-
-    issue_tile(0, 0);
-    for (int t = 0; t < n_tiles; ++t) {
-        const KeyTile kt = key_tile(seg, n_pre, own_len, t);
-        const int buf = t & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < n_tiles) issue_tile(t + 1, buf ^ 1);
-        if (kt.own && a.causal && kt.rel0 > wq0 + 31) continue;               // wave-level skip (the next barrier re-syncs)
-        const char* k_lds = smem + buf * BUF;
-        const char* v_lds = k_lds + AT_RM_BYTES;
-
-        f32x4 st[4][2];
-#pragma unroll
-        for (int kf = 0; kf < 4; ++kf) {
-            st[kf][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; st[kf][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int dc = 0; dc < DC; ++dc) {
-                const bf16x8 kfr = frag_rm(k_lds, kf, dc, lane);
-                st[kf][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[0][dc], st[kf][0], 0, 0, 0);
-                st[kf][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[1][dc], st[kf][1], 0, 0, 0);
-            }
-        }
-        const bool need_mask = (kt.rel0 + BKV > kt.len) || (kt.own && a.causal && kt.rel0 + BKV - 1 > wq0);
-        bf16x8 pf[2][2];
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-            const int qi = wq0 + f * 16 + l15;
-            float mx = -INFINITY;
-            if (need_mask) {
-#pragma unroll
-                for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int kr = kt.rel0 + kf * 16 + g * 4 + r;
-                        const bool ok = kr < kt.len && !(kt.own && a.causal && kr > qi);
-                        st[kf][f][r] = ok ? st[kf][f][r] : -INFINITY;
-                    }
-            }
-#pragma unroll
-            for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kf][f][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run[f], mx * c2);
-            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = __builtin_amdgcn_exp2f(m_run[f] - m_use);
-            float psum = 0.f;
-            float p[4][4];
-#pragma unroll
-            for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    p[kf][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kf][f][r], c2, -m_use));
-                    psum += p[kf][r];
-                }
-            l_run[f] = l_run[f] * alpha + psum;
-            m_run[f] = m_new;
-            if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
-#pragma unroll
-                for (int d = 0; d < DF; ++d) oacc[f][d] *= alpha;
-            }
-            pf[f][0] = pack_slots(p[0], p[1]);
-            pf[f][1] = pack_slots(p[2], p[3]);
-        }
-
-        // ---- O^T += V^T . P^T : fragments (df, c), c fastest, in batches of 4 with the next batch's reads in flight
-        constexpr int NFR = DF * 2, NB = (NFR + 3) / 4;
-        attn_u32x2 vlo[2][4], vhi[2][4];
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // nothing of mine is left in the LDS queue
-#pragma unroll
-        for (int j = 0; j < 4; ++j) vfrag_issue(vlo[0][j], vhi[0][j], v_lds, j >> 1, j & 1);
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int nxt = (b + 1) * 4;
-            if (b + 1 < NB) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (nxt + j < NFR) vfrag_issue(vlo[(b + 1) & 1][j], vhi[(b + 1) & 1][j], v_lds, (nxt + j) >> 1, (nxt + j) & 1);
-            }
-            // LDS returns in order: leave only the next batch's reads outstanding (2 per fragment)
-            const int left = (b + 1 < NB) ? 2 * ((NFR - nxt) < 4 ? (NFR - nxt) : 4) : 0;
-            if (left == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-            else if (left == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int fr = b * 4 + j;
-                if (fr < NFR) {
-                    const uint4 both = make_uint4(vlo[b & 1][j][0], vlo[b & 1][j][1], vhi[b & 1][j][0], vhi[b & 1][j][1]);
-                    const bf16x8 vf = __builtin_bit_cast(bf16x8, both);
-                    const int df = fr >> 1, c = fr & 1;
-                    oacc[0][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[0][c], oacc[0][df], 0, 0, 0);
-                    oacc[1][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[1][c], oacc[1][df], 0, 0, 0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-        float l = l_run[f];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
-        const int qi = wq0 + f * 16 + l15;
-        if (qi >= seg.q_len) continue;
-        const float inv = 1.f / l;
-        const long tok = seg.q_start + qi;
-        bf16_t* op = a.o + tok * a.o_stride + (long)h * D;
-#pragma unroll
-        for (int df = 0; df < DF; ++df) {
-            const f32x4 v = oacc[f][df];
-            *(uint2*)(op + df * 16 + g * 4) = make_uint2(pack_bf2(v[0] * inv, v[1] * inv), pack_bf2(v[2] * inv, v[3] * inv));
-        }
-        if (a.lse && g == 0) a.lse[(long)h * a.T + tok] = m_run[f] * 0.6931471805599453f + logf(l);
-    }
-}
-
-// ================================================================================================ forward, pipelined form
-// attn_fwd_dma_kernel with every LDS latency taken off the critical path of a wave (PMC on the cfg3 layout showed the SIMDs
+// No register staging (-32 VGPRs), no ds_write pass, the swizzle sits on the DMA source address.  Rows past a ragged tile's end are
+// fetched from its last valid row (finite; their scores are masked), the D = 80 image's padding chunks from chunk 0 of the row
+// (finite; they meet Q's zero padding).  That alone (the `dma` stepping stone, 616 TF/s, since removed) was not the stall: every
+// LDS latency is also taken off the critical path of a wave (PMC on the cfg3 layout showed the SIMDs
 // idle ~45 % of the time with MFMA 29 % / other VALU 24 % busy: four exposed K-fragment round trips, two serial ds_bpermute
 // levels in the row max, the first V^T batch, and ~120 address VALU per tile):
 //   * K fragments: inline-asm ds_read_b128 with immediate offsets, two key blocks in flight (issued right after the barrier,
@@ -413,6 +218,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(AttnArgs a) {
 //   * addresses: per-lane LDS bases hoisted (the swizzle is an XOR on a bit field disjoint from the row and tile fields),
 //     DMA source = scalar tile base + hoisted 32-bit lane offsets; only ragged tiles take the clamping path.
 // Arithmetic is that of attn_fwd_kernel up to the lazy softmax reference (see the loop): O agrees to a bf16 ulp, the LSE to ~1e-6.
+typedef __attribute__((ext_vector_type(2))) unsigned int attn_u32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned int attn_u32x4;
 
 template <int OFF> __device__ __forceinline__ void lds_b128(attn_u32x4& x, unsigned addr) {
@@ -1423,23 +1229,18 @@ extern "C" int spacer_attn_fwd(const void* q, const void* k, const void* v, void
     a.nqb = cdiv(max_q_len, BQ); a.T = T; a.Hq = Hq; a.Hkv = Hkv; a.causal = causal; a.scale = scale;
     a.lpt = getenv("SPACER_ATTN_FIFO") ? 0 : 1;
     const dim3 grid(num_segs * a.nqb, Hq);
-    // forward kernel: "pipe" (default, LDS-DMA tiles + pipelined fragment reads), "dma" (LDS-DMA tiles, compiler-placed K reads),
-    // "reg" (register-staged tiles); reg and dma agree bit for bit, pipe to a bf16 ulp of O (lazy softmax reference); the switch exists for A/B timing (scripts/probes/attn_fwd_time.py)
+    // forward kernel: "pipe" (default, LDS-DMA tiles + pipelined fragment reads) or "reg" (register-staged tiles, SPACER_ATTN_FWD=reg);
+    // pipe agrees with reg to a bf16 ulp of O (lazy softmax reference); the switch exists for A/B timing (scripts/probes/attn_fwd_time.py)
     const char* form = getenv("SPACER_ATTN_FWD");
-    const int which = (form && form[0] == 'r') ? 0 : (form && form[0] == 'd') ? 1 : 2;
+    const bool reg = form && form[0] == 'r';
     constexpr int LDS = 4 * AT_RM_BYTES;
-    static const int once = hipFuncSetAttribute((const void*)attn_fwd_dma_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)
-                          + hipFuncSetAttribute((const void*)attn_fwd_dma_kernel<80>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)
-                          + hipFuncSetAttribute((const void*)attn_fwd_pipe_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)
+    static const int once = hipFuncSetAttribute((const void*)attn_fwd_pipe_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)
                           + hipFuncSetAttribute((const void*)attn_fwd_pipe_kernel<80>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     SP_REQUIRE(once == 0, SPACER_ELAUNCH, "attn_fwd: cannot raise the dynamic LDS limit to %d bytes", LDS);
     hipStream_t s = (hipStream_t)stream;
-    if (which == 2) {
+    if (!reg) {
         if (D == 128) hipLaunchKernelGGL(attn_fwd_pipe_kernel<128>, grid, dim3(256), LDS, s, a);
         else hipLaunchKernelGGL(attn_fwd_pipe_kernel<80>, grid, dim3(256), LDS, s, a);
-    } else if (which == 1) {
-        if (D == 128) hipLaunchKernelGGL(attn_fwd_dma_kernel<128>, grid, dim3(256), LDS, s, a);
-        else hipLaunchKernelGGL(attn_fwd_dma_kernel<80>, grid, dim3(256), LDS, s, a);
     } else if (D == 128) hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(attn_fwd_kernel<80>, grid, dim3(256), 0, s, a);
     SP_CHECK_LAUNCH();

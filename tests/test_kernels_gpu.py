@@ -347,7 +347,7 @@ def test_attention_fwd_bwd(dev, case):
 @pytest.mark.parametrize("case", [ATTN_CASES[1], ATTN_CASES[5]], ids=["vit_520", "shared_prefix_big"])
 def test_attention_kernel_forms_agree(dev, case, monkeypatch):
     """The register-staged kernels (SPACER_ATTN_FWD=reg / SPACER_ATTN_BWD=reg) and the LDS-DMA pipelined ones (default) share the
-    arithmetic: forward reg == dma bit for bit, pipe (lazy softmax reference) to a bf16 ulp of O; backward dQ bit for bit, dK / dV
+    arithmetic: forward pipe (lazy softmax reference) agrees with reg to a bf16 ulp of O; backward dQ bit for bit, dK / dV
     (fp32 atomics, a bf16 rounding of dS may flip) to rounding."""
     name, D, Hq, Hkv, causal, segs = case
     T = max(s[0] + s[1] for s in segs)
@@ -357,10 +357,9 @@ def test_attention_kernel_forms_agree(dev, case, monkeypatch):
     mq = max(s[1] for s in segs)
     d_o = rnd((T, Hq * D), dev, 12, 0.5)
     fwd = {}
-    for form in ("reg", "dma", "pipe"):
+    for form in ("reg", "pipe"):
         monkeypatch.setenv("SPACER_ATTN_FWD", form)
         fwd[form] = K.attn_fwd(q, k, v, sd, mq, Hq, Hkv, D, causal, D ** -0.5)
-    assert torch.equal(fwd["reg"][0], fwd["dma"][0]) and torch.equal(fwd["reg"][1], fwd["dma"][1]), f"{name}: dma form differs"
     # pipe: lazy softmax reference -> every P element is rounded to bf16 at another scale (<= 2^-8 relative each), so O agrees to a
     # bf16 ulp of the output scale; the LSE to fp32 rounding
     od = (fwd["reg"][0].float() - fwd["pipe"][0].float()).abs()
