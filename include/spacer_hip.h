@@ -208,6 +208,16 @@ int spacer_decode_qkv_finish(float* acc32, const void* bias, const float* cos_t,
                              void* tail_k, void* tail_v, const int* tail_len_dev, int B, int Hq, int Hkv, int D, int Cmax,
                              spacer_stream_t stream);
 int spacer_swiglu_f32_fwd(float* acc32, void* y, int B, int inter, spacer_stream_t stream);
+/* The decode q|k|v projection with the RMSNorm in front of it folded in (HF: input_layernorm + q/k/v_proj of one generate step):
+ *   normed GEMM:   C32[M,N] += bf16(X32[M,K]) . Wp^T  and  rowss[m] += sum_k X32[m,k]^2   (M <= 64, K % 256 == 0, N % 16 == 0),
+ *                  Wp = spacer_pack_weight_frag of W diag(w_norm) -- norm(x) W^T = rstd * (x (W diag(w))^T) exactly
+ *   normed finish: spacer_decode_qkv_finish with every sum scaled by rstd[b] = rsqrt(rowss[b] / norm_cols + eps) first;
+ *                  rowss_zero[0..B) (the sums of the NEXT normed GEMM) is cleared, B <= 256 */
+int spacer_gemm_skinny_packed_normed(const float* X32, long ldx, const void* Bpacked, float* C32, long ldc, float* rowss, int M,
+                                     int N, int K, spacer_stream_t stream);
+int spacer_decode_qkv_finish_normed(float* acc32, const void* bias, const float* cos_t, const float* sin_t, void* q_out,
+                                    void* tail_k, void* tail_v, const int* tail_len_dev, const float* rowss, float* rowss_zero,
+                                    int norm_cols, float eps, int B, int Hq, int Hkv, int D, int Cmax, spacer_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Element-wise pieces of the MLPs and residual stream.

@@ -73,6 +73,8 @@ SIGNATURES = {
     "spacer_sample_top_p": [_p, _l, _i, _i, _i, _f, _f, _u64, _p, _i, _i, _i, _p, _p, _p, _p, _l, _p],
     "spacer_decode_rope_table": [_p, _p, _f, _p, _p, _i, _i, _p],
     "spacer_decode_qkv_finish": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "spacer_decode_qkv_finish_normed": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _f, _i, _i, _i, _i, _i, _p],
+    "spacer_gemm_skinny_packed_normed": [_p, _l, _p, _p, _l, _p, _i, _i, _i, _p],
     "spacer_swiglu_f32_fwd": [_p, _p, _i, _i, _p],
     "spacer_gemm_swiglu_bf16": [_p, _l, _p, _l, _p, _p, _l, _p, _l, _i, _i, _i, _p],
     "spacer_resize_bicubic_aa_u8": [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _i, _p, _p],

@@ -33,13 +33,20 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 // whole-K blocks instead of after them); their partial sums meet in an fp32 scratch tile through agent-scope atomics, an
 // agent-scope ticket per column group counts arrivals, and the last arriver takes the totals back with atomic exchanges (read +
 // re-zero in one read-modify-write: both sides atomics on the same words, so no fence is needed) and applies the SwiGLU epilogue.
-template <bool PACKED, bool SWIGLU = false, int MT = 1>
+// NORMA (packed weights, MT = 1, K-split form): A is the fp32 residual stream x [M, K] itself and the RMSNorm in front of the
+// projection is folded in:  norm(x) W^T = rstd[m] * (bf16(x) (W diag(w))^T)  -- exact algebra; W diag(w) is folded into the packed
+// weights by the caller, the staging threads round x to bf16 on the way into LDS, and the workgroups of column group 0 also sum x^2 per
+// row into `rowss` (one fp32 atomic per row per K range) from which the finishing kernel forms rstd.  One ~6 us launch (the norm) less
+// per layer; the A slice costs twice the L2 -> CU bytes, which the q|k|v projection (33 MB of weights, latency-bound) does not
+// feel; on gate|up (592 column groups re-reading 64 x 3584 fp32) the same fold measured slower and is not used.
+template <bool PACKED, bool SWIGLU = false, int MT = 1, bool NORMA = false>
 __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __restrict__ A, long lda,
                                                              const bf16_t* __restrict__ B, long ldb,
                                                              float* __restrict__ C, long ldc, int M, int N, int K,
                                                              int slices_per_range, int mflush, int overwrite,
                                                              int split_groups = 0, int split_ranges = 1,
-                                                             float* __restrict__ scratch = nullptr, int* __restrict__ tickets = nullptr) {
+                                                             float* __restrict__ scratch = nullptr, int* __restrict__ tickets = nullptr,
+                                                             float* __restrict__ rowss = nullptr) {
     constexpr int KS = 256 / MT, ROWB = KS * 2;            // LDS row bytes (512 / 256); 16-byte chunk index ^= row & 15
     constexpr int NU = KS / 32, MF = 4 * MT;               // MFMA k-steps per slice, 16-row A fragments
     constexpr int CH = KS / 8, CHS = (MT == 1) ? 5 : 4;    // 16-byte chunks per LDS row and log2
@@ -68,19 +75,37 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __res
     // (a wave reads whole rows of the slice: 2 x 512 or 4 x 256 contiguous bytes per load instruction); 8 per thread
     const int ar0 = tid >> CHS, ach = tid & (CH - 1);
     uint4 areg[8];
+    float4 areg32[NORMA ? 8 : 1][2];                   // NORMA: the same 8 elements per row as fp32
+    float ss[NORMA ? 8 : 1];                           // NORMA, column group 0: running sum of x^2 of this thread's chunk of 8 rows
+    const bool sums = NORMA && blockIdx.x == 0;
+    if (NORMA) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss[NORMA ? j : 0] = 0.f;
+    }
     auto load_a = [&](int slice) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int row = ar0 + (256 / CH) * j;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (row < M) v = *(const uint4*)(A + (long)row * lda + slice * KS + ach * 8);
-            areg[j] = v;
+            if (NORMA) {
+                const float* p = (const float*)A + (long)row * lda + slice * KS + ach * 8;
+                areg32[NORMA ? j : 0][0] = row < M ? *(const float4*)p : make_float4(0.f, 0.f, 0.f, 0.f);
+                areg32[NORMA ? j : 0][1] = row < M ? *(const float4*)(p + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (row < M) v = *(const uint4*)(A + (long)row * lda + slice * KS + ach * 8);
+                areg[j] = v;
+            }
         }
     };
     auto store_a = [&](char* buf) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int row = ar0 + (256 / CH) * j;
+            if (NORMA) {
+                const float4 lo = areg32[NORMA ? j : 0][0], hi = areg32[NORMA ? j : 0][1];
+                if (sums) ss[NORMA ? j : 0] += lo.x * lo.x + lo.y * lo.y + lo.z * lo.z + lo.w * lo.w + hi.x * hi.x + hi.y * hi.y + hi.z * hi.z + hi.w * hi.w;
+                areg[j] = make_uint4(pack_bf2(lo.x, lo.y), pack_bf2(lo.z, lo.w), pack_bf2(hi.x, hi.y), pack_bf2(hi.z, hi.w));
+            }
             *(uint4*)(buf + row * ROWB + ((ach ^ (row & 15)) * 16)) = areg[j];
         }
     };
@@ -136,6 +161,17 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __res
         if (s + 1 < s_end) { load_a(s + 1); load_w(wa, s + 1); }
         compute(wb, smem[1]);
         if (++s >= s_end) break;
+    }
+    if (NORMA && sums) {
+        // the CH = 32 threads that share a row are one half wave: reduce, one atomic per row per K range
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = ss[NORMA ? j : 0];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            const int row = ar0 + (256 / CH) * j;
+            if (ach == 0 && row < M) atomicAdd(rowss + row, v);
+        }
     }
     // lane holds C[m = mf*16 + g*4 + r][n = n0 + l15]
     const int n = n0 + l15;
@@ -236,19 +272,25 @@ __global__ void decode_rope_table_kernel(const int* __restrict__ pos_base, const
 // =============================================================================== q/k/v finishing
 // acc32 [B, (Hq+2Hkv)*D] (fp32 split-K sums, re-zeroed here) + bias -> rotary(q), rotary(k) ->
 // q_out bf16 [B, Hq*D]; k, v appended to the tail cache at position *tail_len.
+// rowss != NULL (norm-folded projection): acc holds bf16(x) (W diag(w))^T; every value is scaled by rstd[b] =
+// rsqrt(rowss[b] / norm_cols + eps) first.  rowss_zero (the row sums the NEXT norm-folded launch will add into) is cleared here.
 __global__ __launch_bounds__(256) void decode_qkv_finish_kernel(float* __restrict__ acc, const bf16_t* __restrict__ bias,
                                                                 const float* __restrict__ cs, const float* __restrict__ sn,
                                                                 bf16_t* __restrict__ q_out, bf16_t* __restrict__ tail_k,
                                                                 bf16_t* __restrict__ tail_v, const int* __restrict__ tail_len,
-                                                                int B, int Hq, int Hkv, int D, int Cmax) {
+                                                                int B, int Hq, int Hkv, int D, int Cmax,
+                                                                const float* __restrict__ rowss, float* __restrict__ rowss_zero,
+                                                                int norm_cols, float eps) {
     const int half = D / 2, heads = Hq + 2 * Hkv;
     const int total = B * heads * half;
     const int pos = *tail_len;
+    if (rowss_zero && blockIdx.x == 0 && threadIdx.x < B) rowss_zero[threadIdx.x] = 0.f;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int j = i % half, hh = (i / half) % heads, b = i / (half * heads);
         float* a = acc + ((long)b * heads + hh) * D;
-        float x1 = a[j] + (bias ? bf2f(bias[hh * D + j]) : 0.f);
-        float x2 = a[j + half] + (bias ? bf2f(bias[hh * D + j + half]) : 0.f);
+        const float rs = rowss ? rsqrtf(rowss[b] / (float)norm_cols + eps) : 1.f;
+        float x1 = a[j] * rs + (bias ? bf2f(bias[hh * D + j]) : 0.f);
+        float x2 = a[j + half] * rs + (bias ? bf2f(bias[hh * D + j + half]) : 0.f);
         a[j] = 0.f; a[j + half] = 0.f;
         if (hh < Hq + Hkv) {   // rotary on q and k heads
             const float c1 = cs[b * D + j], s1 = sn[b * D + j], c2 = cs[b * D + j + half], s2 = sn[b * D + j + half];
@@ -906,6 +948,26 @@ extern "C" int spacer_gemm_skinny_packed_bf16(const void* A, long lda, const voi
     return launch_skinny(A, lda, Bpacked, 0, C, ldc, M, N, K, nullptr, true, (hipStream_t)stream);
 }
 
+// C32[M,N] += bf16(X32[M,K]) . Wp[N,K]^T and rowss[m] += sum_k X32[m,k]^2: the K-split decode projection with the RMSNorm in
+// front of it folded in (see gemm_skinny_kernel NORMA); Wp = packed W diag(w_norm).  M <= 64.
+extern "C" int spacer_gemm_skinny_packed_normed(const float* X32, long ldx, const void* Bpacked, float* C, long ldc, float* rowss,
+                                                int M, int N, int K, spacer_stream_t stream) {
+    SP_REQUIRE(X32 && Bpacked && C && rowss, SPACER_EINVAL, "gemm_skinny_normed: null operand");
+    SP_REQUIRE(M > 0 && M <= 64 && K % 256 == 0 && N % 16 == 0 && ldx % 4 == 0, SPACER_EINVAL,
+               "gemm_skinny_normed: need 0 < M <= 64, K %% 256 == 0, N %% 16 == 0, ldx %% 4 == 0 (M=%d N=%d K=%d)", M, N, K);
+    const int col_groups = cdiv(N, 64), slices = K / 256;
+    const char* tb = getenv("SPACER_SKINNY_BLOCKS");
+    const int target_blocks = tb ? atoi(tb) : 512;
+    int ranges = col_groups < 448 ? max(1, min(slices, target_blocks / col_groups)) : 1;
+    const int spr = cdiv(slices, ranges);
+    ranges = cdiv(slices, spr);
+    hipLaunchKernelGGL((gemm_skinny_kernel<true, false, 1, true>), dim3(col_groups, ranges), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)X32, ldx, (const bf16_t*)Bpacked, 0L, C, ldc, M, N, K, spr, M, 0, 0, 1, (float*)nullptr,
+                       (int*)nullptr, rowss);
+    SP_CHECK_LAUNCH();
+    return SPACER_OK;
+}
+
 extern "C" int spacer_gemm_skinny_packed_store_bf16(const void* A, long lda, const void* Bpacked, void* C, long ldc, int M, int N,
                                                     int K, spacer_stream_t stream) {
     return launch_skinny(A, lda, Bpacked, 0, C, ldc, M, N, K, nullptr, true, (hipStream_t)stream, true);
@@ -995,7 +1057,21 @@ extern "C" int spacer_decode_qkv_finish(float* acc32, const void* bias, const fl
     const int total = B * (Hq + 2 * Hkv) * (D / 2);
     hipLaunchKernelGGL(decode_qkv_finish_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, acc32,
                        (const bf16_t*)bias, cos_t, sin_t, (bf16_t*)q_out, (bf16_t*)tail_k, (bf16_t*)tail_v, tail_len_dev, B, Hq,
-                       Hkv, D, Cmax);
+                       Hkv, D, Cmax, (const float*)nullptr, (float*)nullptr, 0, 0.f);
+    SP_CHECK_LAUNCH();
+    return SPACER_OK;
+}
+
+extern "C" int spacer_decode_qkv_finish_normed(float* acc32, const void* bias, const float* cos_t, const float* sin_t, void* q_out,
+                                               void* tail_k, void* tail_v, const int* tail_len_dev, const float* rowss,
+                                               float* rowss_zero, int norm_cols, float eps, int B, int Hq, int Hkv, int D, int Cmax,
+                                               spacer_stream_t stream) {
+    SP_REQUIRE(rowss && norm_cols > 0 && B <= 256, SPACER_EINVAL, "decode_qkv_finish_normed: row sums missing or B=%d > 256", B);
+    if (B <= 0) return SPACER_OK;
+    const int total = B * (Hq + 2 * Hkv) * (D / 2);
+    hipLaunchKernelGGL(decode_qkv_finish_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, acc32,
+                       (const bf16_t*)bias, cos_t, sin_t, (bf16_t*)q_out, (bf16_t*)tail_k, (bf16_t*)tail_v, tail_len_dev, B, Hq,
+                       Hkv, D, Cmax, rowss, rowss_zero, norm_cols, eps);
     SP_CHECK_LAUNCH();
     return SPACER_OK;
 }

@@ -217,6 +217,16 @@ def gemm_skinny_packed_acc(a: torch.Tensor, bp: torch.Tensor, c32: torch.Tensor,
     return c32
 
 
+def gemm_skinny_packed_normed(x32: torch.Tensor, bp: torch.Tensor, c32: torch.Tensor, rowss: torch.Tensor, N: int) -> torch.Tensor:
+    """c32[M,N] (fp32) += bf16(x32[M,K]) @ Wp^T and rowss[m] += sum_k x32[m,k]^2: the decode projection with the RMSNorm in front
+    of it folded in (Wp = pack_weight_frag(W * w_norm)); decode_qkv_finish_normed applies rstd."""
+    M, K = x32.shape
+    assert bp.numel() == N * K and c32.dtype == torch.float32 and x32.dtype == torch.float32 and rowss.dtype == torch.float32
+    check(_lib.load().spacer_gemm_skinny_packed_normed(_ptr(x32), _rowmajor(x32), _ptr(bp), _ptr(c32), _rowmajor(c32), _ptr(rowss),
+                                                       M, N, K, _stream()), "gemm_skinny_packed_normed")
+    return c32
+
+
 def gemm_skinny_packed_store(a: torch.Tensor, bp: torch.Tensor, c32: torch.Tensor, N: int) -> torch.Tensor:
     """c32[M,N] (fp32) = a[M,K] @ W[N,K]^T (store, no accumulate) for wide N (lm_head): no zero fill of c32 needed."""
     M, K = a.shape
@@ -576,6 +586,14 @@ def decode_qkv_finish(acc32, bias, cos, sin, q_out, tail_k, tail_v, tail_len_dev
     check(_lib.load().spacer_decode_qkv_finish(_ptr(acc32), _ptr(bias), _ptr(cos), _ptr(sin), _ptr(q_out), _ptr(tail_k),
                                                _ptr(tail_v), _ptr(tail_len_dev), B, Hq, Hkv, D, tail_k.shape[1], _stream()),
           "decode_qkv_finish")
+
+
+def decode_qkv_finish_normed(acc32, bias, cos, sin, q_out, tail_k, tail_v, tail_len_dev, rowss, rowss_zero, norm_cols, eps, Hq, Hkv, D):
+    """decode_qkv_finish behind gemm_skinny_packed_normed: sums scaled by rsqrt(rowss / norm_cols + eps) first; clears rowss_zero."""
+    B = acc32.shape[0]
+    check(_lib.load().spacer_decode_qkv_finish_normed(_ptr(acc32), _ptr(bias), _ptr(cos), _ptr(sin), _ptr(q_out), _ptr(tail_k),
+                                                      _ptr(tail_v), _ptr(tail_len_dev), _ptr(rowss), _ptr(rowss_zero), norm_cols, eps,
+                                                      B, Hq, Hkv, D, tail_k.shape[1], _stream()), "decode_qkv_finish_normed")
 
 
 def swiglu_f32_fwd(acc32, out):

@@ -12,6 +12,8 @@ Sampling semantics: temperature -> top_k -> top_p -> multinomial (HF warper orde
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -54,6 +56,10 @@ class RolloutEngine:
         self.cfg = engine.cfg
         self.dev = engine.dev
         self._packed = None          # fragment-major copies of the LLM matmul weights for the skinny GEMMs
+        # decode: the input RMSNorm of every layer folded into its q|k|v projection (weights packed as W diag(w_ln1), the GEMM
+        # stages the fp32 residual stream itself and sums x^2, the finishing kernel applies rstd): one launch less per layer.
+        # SPACER_DECODE_NORM=separate keeps the norm kernel (A/B runs); batches of more than 64 rows always keep it.
+        self.fold_norm = os.environ.get("SPACER_DECODE_NORM", "fold") != "separate"
 
     # ------------------------------------------------------------------ decode-layout weights
     def invalidate(self) -> None:
@@ -67,6 +73,11 @@ class RolloutEngine:
             W, cfg = self.e.W, self.cfg
             names = [f"llm.{i}.{n}" for i in range(cfg.layers) for n in ("qkv_w", "o_w", "gu_w", "down_w")] + ["llm.lm_head"]
             self._packed = {n: (K.pack_weight_frag_swiglu(W[n]) if n.endswith("gu_w") else K.pack_weight_frag(W[n])) for n in names}
+            if self.fold_norm:           # q|k|v weights with the layer's input-norm weight folded in: W diag(w_ln1), rounded once to bf16
+                for i in range(cfg.layers):  # (the plain copy stays for batches of more than 64 rows: +33 MB per layer at 7B)
+                    wf = (W[f"llm.{i}.qkv_w"].float() * W[f"llm.{i}.ln1_w"].float()[None, :]).to(torch.bfloat16)
+                    self._packed[f"llm.{i}.qkv_wn"] = K.pack_weight_frag(wf)
+                    del wf
         return self._packed
 
     # ------------------------------------------------------------------ prefill
@@ -124,10 +135,18 @@ class RolloutEngine:
         scale = D ** -0.5
         for i in range(cfg.layers):
             p = f"llm.{i}."
-            h = K.rmsnorm_fwd(x, W[p + "ln1_w"], cfg.rms_eps, out=st["h"])
-            K.gemm_skinny_packed_acc(h, PW[p + "qkv_w"], st["acc_qkv"], cfg.qkv_dim)
-            K.decode_qkv_finish(st["acc_qkv"], W[p + "qkv_b"], st["cos"], st["sin"], st["q"], st["tk"][i], st["tv"][i],
-                                st["tail_len"], Hq, Hkv, D)
+            if self.fold_norm and B <= 64:
+                # norm(x) Wqkv^T = rstd * (bf16(x) (W diag(w))^T): the GEMM stages the fp32 stream and sums x^2 per row, the
+                # finishing kernel applies rstd (and clears the next layer's row sums)
+                rs = st["rowss"]
+                K.gemm_skinny_packed_normed(x, PW[p + "qkv_wn"], st["acc_qkv"], rs[i], cfg.qkv_dim)
+                K.decode_qkv_finish_normed(st["acc_qkv"], W[p + "qkv_b"], st["cos"], st["sin"], st["q"], st["tk"][i], st["tv"][i],
+                                           st["tail_len"], rs[i], rs[(i + 1) % cfg.layers], cfg.hidden, cfg.rms_eps, Hq, Hkv, D)
+            else:
+                h = K.rmsnorm_fwd(x, W[p + "ln1_w"], cfg.rms_eps, out=st["h"])
+                K.gemm_skinny_packed_acc(h, PW[p + "qkv_w"], st["acc_qkv"], cfg.qkv_dim)
+                K.decode_qkv_finish(st["acc_qkv"], W[p + "qkv_b"], st["cos"], st["sin"], st["q"], st["tk"][i], st["tv"][i],
+                                    st["tail_len"], Hq, Hkv, D)
             if st["shared_prefix"]:      # prompt keys scored once per prompt for its K rollouts
                 o = K.attn_decode_shared(st["q"], st["pk"][i], st["pv"][i], st["plen"], st["prompt_of"], st["tk"][i], st["tv"][i],
                                          st["tail_len"], st["Kn"], Hq, Hkv, D, scale, out=st["o"], workspace=st["attn_ws"])
@@ -186,6 +205,7 @@ class RolloutEngine:
             q=torch.empty(B, cfg.heads * D, device=dev, dtype=BF16), o=torch.empty(B, cfg.heads * D, device=dev, dtype=BF16),
             a=torch.empty(B, cfg.intermediate, device=dev, dtype=BF16),
             acc_qkv=torch.zeros(B, cfg.qkv_dim, device=dev, dtype=F32),
+            rowss=torch.zeros(cfg.layers, max(B, 1), device=dev, dtype=F32),     # per layer: sum of x^2 per row (norm-folded q|k|v)
             cos=torch.empty(B, D, device=dev, dtype=F32), sin=torch.empty(B, D, device=dev, dtype=F32),
             logits=torch.empty(B, cfg.vocab, device=dev, dtype=F32),
         )

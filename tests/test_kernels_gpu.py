@@ -460,6 +460,52 @@ def test_gemm_persistent_workgroups_match_one_item_per_workgroup(dev, monkeypatc
     assert_close(K.gemm_nt(a, b), a.float() @ b.float().t(), 2e-2, 2e-2, "persistent gemm vs fp32")
 
 
+def test_decode_qkv_projection_with_folded_rmsnorm(dev):
+    """gemm_skinny_packed_normed + decode_qkv_finish_normed (RMSNorm folded into the K-split decode projection:
+    rstd * (bf16(x) (W diag(w))^T)) against fp32 torch for norm(x) W^T + b with rotary, and against the three-launch path
+    (rmsnorm_fwd + gemm_skinny_packed_acc + decode_qkv_finish) to bf16 rounding; the row sums are re-zeroed by the protocol."""
+    D, Hq, Hkv, Hd, B, Cmax = 128, 6, 2, 768, 37, 8
+    heads = Hq + 2 * Hkv
+    x = torch.randn(B, Hd, device=dev, generator=torch.Generator(dev).manual_seed(1)) * 1.7
+    w = rnd((heads * D, Hd), dev, 2, 0.04)
+    lnw = (1.0 + 0.3 * torch.randn(Hd, device=dev, generator=torch.Generator(dev).manual_seed(3))).to(torch.bfloat16)
+    bias = rnd((heads * D,), dev, 4, 0.3)
+    eps = 1e-6
+    pos_base = torch.arange(B, dtype=torch.int32, device=dev) * 3 + 5
+    tld = torch.tensor([2], dtype=torch.int32, device=dev)
+    cos, sin = torch.empty(B, D, device=dev), torch.empty(B, D, device=dev)
+    K.decode_rope_table(pos_base, tld, 1e6, cos, sin)
+    # three launches
+    acc_a = torch.zeros(B, heads * D, device=dev)
+    h = K.rmsnorm_fwd(x, lnw, eps)
+    K.gemm_skinny_packed_acc(h, K.pack_weight_frag(w), acc_a, heads * D)
+    q_a = torch.empty(B, Hq * D, device=dev, dtype=torch.bfloat16)
+    tk_a, tv_a = torch.zeros(B, Cmax, Hkv, D, device=dev, dtype=torch.bfloat16), torch.zeros(B, Cmax, Hkv, D, device=dev, dtype=torch.bfloat16)
+    K.decode_qkv_finish(acc_a, bias, cos, sin, q_a, tk_a, tv_a, tld, Hq, Hkv, D)
+    # folded: two launches, twice in a row to exercise the row-sum hand-over (layer i clears layer i+1's sums)
+    wn = K.pack_weight_frag((w.float() * lnw.float()[None, :]).to(torch.bfloat16))
+    rowss = torch.zeros(2, B, device=dev)
+    for it in range(2):
+        acc_b = torch.zeros(B, heads * D, device=dev)
+        q_b = torch.empty_like(q_a)
+        tk_b, tv_b = torch.zeros_like(tk_a), torch.zeros_like(tv_a)
+        K.gemm_skinny_packed_normed(x, wn, acc_b, rowss[it], heads * D)
+        assert_close(rowss[it], (x.float() ** 2).sum(1), 1e-3 * Hd, 1e-5, "row sums of squares")
+        K.decode_qkv_finish_normed(acc_b, bias, cos, sin, q_b, tk_b, tv_b, tld, rowss[it], rowss[1 - it], Hd, eps, Hq, Hkv, D)
+        assert float(acc_b.abs().max()) == 0.0 and float(rowss[1 - it].abs().max()) == 0.0
+        for a, b, nm in ((q_a, q_b, "q"), (tk_a, tk_b, "k"), (tv_a, tv_b, "v")):
+            assert_close(b, a.float(), 3e-2, 2e-2, f"folded norm {nm} vs three launches (it {it})")
+        rowss[it].zero_()                     # (in the decode loop the other layer's finishing kernel does this)
+    # fp32 reference
+    xf = x.float()
+    y = (xf * torch.rsqrt((xf ** 2).mean(1, keepdim=True) + eps) * lnw.float()) @ w.float().t() + bias.float()
+    yq = y[:, :Hq * D].view(B, Hq, D)
+    c, s_ = cos[:, None, :], sin[:, None, :]
+    rot = torch.cat([-yq[..., D // 2:], yq[..., :D // 2]], -1)
+    assert_close(q_b.view(B, Hq, D), yq * c + rot * s_, 3e-2, 2e-2, "folded norm q vs fp32")
+    assert_close(tv_b[:, 2], y[:, (Hq + Hkv) * D:].view(B, Hkv, D), 3e-2, 2e-2, "folded norm v vs fp32")
+
+
 def test_gemm_swiglu_epilogue_is_the_two_step_path(dev):
     """gate|up GEMM with the SwiGLU in its epilogue == GEMM into gu + swiglu_fwd, bit for bit (ragged M, bias, no gu)."""
     for M, I, Kd, with_bias in ((3000, 2048, 512, False), (4160, 3456, 1280, True), (5498, 1024, 256, False), (1402, 18944, 3584, False)):
