@@ -55,7 +55,11 @@ struct GemmArgs {
 
 // workgroups of a persistent 256-tile launch: one per CU (SPACER_GEMM_PERSIST=0: one per work item, the round-1 form, for A/B runs)
 static unsigned persistent_grid(long items) {
-    static const int cus = [] { hipDeviceProp_t p; int d = 0; hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
+    static const int cus = [] {
+        hipDeviceProp_t p;
+        int d = 0;
+        return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) ? p.multiProcessorCount : 256;
+    }();
     const char* e = getenv("SPACER_GEMM_PERSIST");
     if (e && e[0] == '0') return (unsigned)items;
     return (unsigned)(items < cus ? items : cus);
