@@ -337,6 +337,67 @@ __global__ __launch_bounds__(320, 2) void skinny_ld(const bf16_t* __restrict__ A
         }
 }
 
+
+// Row-split variant: no K split and no atomics.  The 64 rows are cut into four groups of 16; a workgroup = 64 columns x 16 rows x ALL
+// of K (one MFMA row fragment per wave), so a column group's weights are streamed by four workgroups -- placed on ONE XCD (block ids
+// 8 apart, dispatched within 32 ids of each other) so that three of the four reads hit that XCD's L2 -- and every output element has
+// one owner: plain stores, any epilogue.  HBM traffic stays 1x, L2 -> CU traffic is 4x.
+__global__ __launch_bounds__(256, 4) void skinny_rs(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B,
+                                                    float* __restrict__ C, long ldc, int M, int N, int K, int dbg) {
+    constexpr int KS = 256, ROWB = 512, NU = 8;
+    __shared__ __attribute__((aligned(16))) char smem[2][16 * ROWB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
+    const int id = blockIdx.x, cg = (id >> 5) * 8 + (id & 7), rg = (id >> 3) & 3;       // column group, row group
+    if (cg * 64 >= N) return;
+    const int total = K / KS, n0 = cg * 64 + wave * 16, r0 = rg * 16;
+    const int arow = tid >> 5, ach = tid & 31;                 // 8 rows x 32 chunks per pass, 2 passes
+    uint4 areg[2];
+    auto load_a = [&](int slice) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = r0 + arow + 8 * j;
+            areg[j] = row < M ? *(const uint4*)(A + (long)row * lda + slice * KS + ach * 8) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_a = [&](char* buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = arow + 8 * j;
+            *(uint4*)(buf + row * ROWB + ((ach ^ (row & 15)) * 16)) = areg[j];
+        }
+        __syncthreads();
+    };
+    const bf16_t* bbase = B + ((long)(n0 >> 4) * (K >> 5)) * 512 + lane * 8;
+    auto load_w = [&](u32x4 (&w)[NU], int slice) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) w[u] = *(const u32x4*)(bbase + ((long)slice * NU + u) * 512);   // plain (L2-allocating): the other three row groups of this column group hit
+    };
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](const u32x4 (&w)[NU], const char* buf) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const bf16x8 af = *(const bf16x8*)(buf + l15 * ROWB + (((u * 4 + g) ^ l15) * 16));
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, w[u]), acc, 0, 0, 0);
+        }
+    };
+    u32x4 wa[NU], wb[NU], wc[NU];                               // three weight sets: two slices of prefetch
+    load_a(0); load_w(wa, 0);
+    if (1 < total) load_w(wb, 1);
+    for (int s = 0; s < total; s += 3) {
+        store_a(smem[0]); if (s + 1 < total) load_a(s + 1); if (s + 2 < total) load_w(wc, s + 2); compute(wa, smem[0]);
+        if (s + 1 >= total) break;
+        store_a(smem[1]); if (s + 2 < total) load_a(s + 2); if (s + 3 < total) load_w(wa, s + 3); compute(wb, smem[1]);
+        if (s + 2 >= total) break;
+        store_a(smem[0]); if (s + 3 < total) load_a(s + 3); if (s + 4 < total) load_w(wb, s + 4); compute(wc, smem[0]);
+    }
+    if (dbg & 8) { if (acc[0] + acc[1] + acc[2] + acc[3] == 1.2345e-30f) C[0] = acc[0]; return; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = r0 + g * 4 + r;
+        if (m < M) C[(long)m * ldc + n0 + l15] = acc[r];
+    }
+}
+
 // pure read with the GEMM's own access pattern (each wave: its 16-column fragment stream, 8 KiB per slice)
 __global__ __launch_bounds__(256, 2) void stream_only(const bf16_t* __restrict__ B, float* __restrict__ C, int K, int spr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -411,6 +472,21 @@ int main() {
                 if (d == 0) {
                     hipMemset(C, 0, (long)M * sh.N * 4);
                     hipLaunchKernelGGL(skinny_k2, dim3(groups, rr), dim3(512), 4 * 64 * 512, 0, A, (long)sh.K, W, C, (long)sh.N, M, sh.N, sh.K, spr2, 0);
+                    hipDeviceSynchronize();
+                    hipMemcpy(hc, C, (long)M * sh.N * 4, hipMemcpyDeviceToHost);
+                    long bad = 0; for (long i = 0; i < (long)M * sh.N; ++i) bad += (hc[i] != (float)sh.K);
+                    if (bad) printf("      WRONG: %ld of %ld elements != K\n", bad, (long)M * sh.N);
+                }
+            }
+        }
+        {
+            const int g8 = (groups + 7) / 8 * 8;
+            for (int d : {0, 8}) {
+                char nm[96]; snprintf(nm, 96, "row split (4 x 16 rows, whole K, no atomics)%s", d == 8 ? ", no epilogue" : "");
+                run(nm, [&](int r) { hipLaunchKernelGGL(skinny_rs, dim3(g8 * 4), dim3(256), 0, 0, A, (long)sh.K, W + (r % COPIES) * wstride, C, (long)sh.N, M, sh.N, sh.K, d); }, bytes);
+                if (d == 0) {
+                    hipMemset(C, 0, (long)M * sh.N * 4);
+                    hipLaunchKernelGGL(skinny_rs, dim3(g8 * 4), dim3(256), 0, 0, A, (long)sh.K, W, C, (long)sh.N, M, sh.N, sh.K, 0);
                     hipDeviceSynchronize();
                     hipMemcpy(hc, C, (long)M * sh.N * 4, hipMemcpyDeviceToHost);
                     long bad = 0; for (long i = 0; i < (long)M * sh.N; ++i) bad += (hc[i] != (float)sh.K);
