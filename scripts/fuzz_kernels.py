@@ -169,6 +169,19 @@ def fuzz_skinny(r):
         close(y, torch.nn.functional.silu(gu[:, :I]) * gu[:, I:], 2e-2, 1e-2, f"skinny swiglu {M}x{I}x{Kd}")
 
 
+def fuzz_skinny_normed(r):
+    """RMSNorm folded into the K-split decode projection: c += bf16(x) (W diag(w))^T with the row sums of x^2 beside it."""
+    M = r.randint(1, 64)
+    N, Kd = r.randint(1, 300) * 16, r.randint(1, 24) * 256
+    x = rnd((M, Kd), 1.5, torch.float32)
+    b = rnd((N, Kd), 0.05)
+    c0 = rnd((M, N), dtype=torch.float32)
+    c, ss = c0.clone(), torch.zeros(M, device=dev)
+    K.gemm_skinny_packed_normed(x, K.pack_weight_frag(b), c, ss, N)
+    close(ss, x.pow(2).sum(1), 1e-3 * Kd, 1e-5, f"skinny normed row sums {M}x{Kd}")
+    close(c, c0 + x.to(BF).float() @ b.float().t(), 5e-3, 3e-3, f"skinny normed {M}x{N}x{Kd}")
+
+
 def fuzz_norm(r):
     rows, cols = r.randint(1, 700), r.choice([256, 1280, 1536, 2048, 3584, 5120])
     f32 = bool(r.randint(0, 1))
@@ -190,7 +203,7 @@ def fuzz_norm(r):
 def run(budget: float, seed: int) -> dict:
     r = random.Random(seed)
     torch.manual_seed(seed)
-    fns = [fuzz_gemm, fuzz_gemm_trans, fuzz_swiglu, fuzz_attention, fuzz_decode_attention, fuzz_skinny, fuzz_norm, fuzz_resize]
+    fns = [fuzz_gemm, fuzz_gemm_trans, fuzz_swiglu, fuzz_attention, fuzz_decode_attention, fuzz_skinny, fuzz_skinny_normed, fuzz_norm, fuzz_resize]
     counts = {f.__name__: 0 for f in fns}
     t0 = time.time()
     while time.time() - t0 < budget:
