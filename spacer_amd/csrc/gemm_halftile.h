@@ -59,6 +59,20 @@ __device__ __forceinline__ void tile_of_256(int pid, const GemmArgs& g, int& tm,
 typedef __attribute__((ext_vector_type(4))) short gemm_s16x4;
 typedef __attribute__((ext_vector_type(8))) short gemm_s16x8;
 
+// 4 x 4 transpose of one dword per lane across the four 16-lane rows of a wave: in: x[j] = fragment j's dword of lane-row g; out:
+// lane-row r holds x[k] = fragment r's dword of (former) lane-row k.  With the accumulator layout of this kernel (fragment j = 16
+// columns, lane-row g = columns 4g .. 4g+3 of it) a lane then owns 16 CONSECUTIVE columns of its row, so the epilogue can write
+// 32 (bf16) / 64 (fp32) contiguous bytes per lane -- 128 / 256 B per row and instruction -- straight from registers, without the LDS
+// staging pass (v_permlane16_swap exchanges the odd rows of its first operand with the even rows of its second, v_permlane32_swap
+// rows {2,3} with rows {0,1}).
+__device__ __forceinline__ void xpose4_rows(uint32_t (&x)[4]) {
+    const auto a = __builtin_amdgcn_permlane16_swap(x[0], x[1], false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(x[2], x[3], false, false);
+    const auto c = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
+    const auto d = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
+    x[0] = c[0]; x[2] = c[1]; x[1] = d[0]; x[3] = d[1];
+}
+
 // STG16: bf16 staging epilogue + early prologue (bf16 output without a residual, SwiGLU); else the fp32 staging of round 1
 template <bool BALANCED, bool TA = false, bool TB = false, bool STG16 = false>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
@@ -311,8 +325,42 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
     if (more) { vb = nvb; setup(vb); }
     __syncthreads();                                                         // every wave is done with the operand images
     if (early) { stage(0, A_LO, 0); stage(0, B_LO, 0); stage(0, B_HI, 0); stage(0, A_HI, 0); }   // next item's K tile 0 -> parity 0
-    if constexpr (STG16) {
-        // bf16 staging in the parity-1 half: [128 rows][256 cols] bf16 = 64 KiB per pass; 8-byte chunk (4 columns) index ^= row & 15:
+    if (STG16 && !sw) {
+        // ---- direct form (bf16 output, no residual, no SwiGLU): alpha / bias / activation, ONE rounding, then the 4 x 4 lane-row
+        // transpose so that lane (l15, r) owns columns wc*64 + r*16 .. +15 of row wr*128 + i*16 + l15: two 16-byte stores per lane,
+        // 128 contiguous bytes per row and fragment row -- no LDS, no barrier
+        float bias16[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nb = cn0 + wc * 64 + j * 16 + (lane >> 4) * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bias16[j][q] = (e.bias && nb + q < e.N) ? bf2f(e.bias[nb + q]) : 0.f;
+        }
+        const int ncol = cn0 + wc * 64 + (lane >> 4) * 16;                   // first of this lane's 16 columns after the transpose
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            uint32_t lo[4], hi[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 v = acc[i][j] * e.alpha + (f32x4){bias16[j][0], bias16[j][1], bias16[j][2], bias16[j][3]};
+                if (e.act != SPACER_ACT_NONE) v = apply_act4(v, e.act);
+                lo[j] = pack_bf2(v[0], v[1]); hi[j] = pack_bf2(v[2], v[3]);
+            }
+            xpose4_rows(lo); xpose4_rows(hi);
+            const int m = cm0 + wr * 128 + i * 16 + (lane & 15);
+            if (m < e.M && ncol < e.N) {
+                bf16_t* c = (bf16_t*)e.C + (long)m * e.ldc + ncol;
+                if (ncol + 16 <= e.N && (e.ldc % 8) == 0 && ((uintptr_t)e.C % 16) == 0) {
+                    *(uint4*)c = make_uint4(lo[0], hi[0], lo[1], hi[1]);
+                    *(uint4*)(c + 8) = make_uint4(lo[2], hi[2], lo[3], hi[3]);
+                } else {
+                    const uint32_t w[8] = {lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], lo[3], hi[3]};
+                    for (int q = 0; q < 16 && ncol + q < e.N; ++q) c[q] = (bf16_t)((q & 1) ? (w[q >> 1] >> 16) : (w[q >> 1] & 0xffffu));
+                }
+            }
+        }
+    } else if constexpr (STG16) {
+        // bf16 staging in the parity-1 half (SwiGLU form: gate and up columns of one output sit in different waves): [128 rows][256 cols] bf16 = 64 KiB per pass; 8-byte chunk (4 columns) index ^= row & 15:
         // a fragment store (16 rows x one chunk per 16-lane group) and a row read (64 chunks of one row) are both conflict-free.
         // alpha / bias / activation and the ONE rounding happen on the way in (no residual in this form).
         char* stg = smem + 4 * HALF;
@@ -389,6 +437,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
             if (pass == 0) __syncthreads();
         }
     } else {
+    // (the direct, register-transposed form of the bf16 case was tried here too: 1175 -> 1162 TF/s for o / down and 1093 -> 1077 for dW in
+    // the step -- the residual read-modify-write wants whole 1 KiB rows per instruction; the LDS-staged form stays)
     // Two passes (wave row 0, then 1): [128 rows][256 cols] fp32 = the whole 128 KiB; 16-byte chunk index ^= row & 7 keeps
     // the fragment writes (8 rows per store group) and the row reads conflict-free.  alpha / bias / activation are applied
     // on the way in, residual + conversion on the way out (one rounding, as before).
