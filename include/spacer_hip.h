@@ -321,6 +321,36 @@ int spacer_adamw_step(float* master, void* shadow_bf16, float* m, float* v, cons
                       float beta1, float beta2, float eps, float weight_decay, float bias_c1, float bias_c2,
                       const float* sumsq_dev, float max_norm, float grad_scale, spacer_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Precise scoring mode (csrc/precise.hip): per-token log-probs within 1e-3 of an fp32 evaluation at full depth (TR:353-366;
+ * the north-star tolerance).  An activation is carried as a PAIR of bf16 arrays (hi = bf16(x), lo = bf16(x - hi)); a linear
+ * layer is two accumulate passes of spacer_gemm_bf16_nt (A_hi, then A_lo with residual == C) into an fp32 C.  These entries
+ * are the fp32 -> pair producers between the GEMMs and the attention on pair operands.  Forward only.
+ * ---------------------------------------------------------------------------------------------- */
+/* y_hi / y_lo [rows, ldy] bf16 <- x fp32 [rows, ldx] (cols, ldx, ldy multiples of 4) */
+int spacer_split_f32_pair(const float* x, long ldx, void* y_hi, void* y_lo, long ldy, int rows, int cols, spacer_stream_t stream);
+/* y = act(x) in fp32 (enum spacer_act), as a pair */
+int spacer_act_f32_pair(const float* x, long ldx, void* y_hi, void* y_lo, long ldy, int rows, int cols, int act,
+                        spacer_stream_t stream);
+/* gu fp32 [rows, 2*inter] = [gate | up] -> silu(gate) * up as a pair [rows, inter] */
+int spacer_swiglu_f32_pair(const float* gu, void* y_hi, void* y_lo, int rows, int inter, spacer_stream_t stream);
+/* RMSNorm (layer == 0, b ignored) or LayerNorm (layer != 0) of fp32 rows, bf16 weights, output as a pair */
+int spacer_norm_f32_pair(const float* x, const void* w, const void* b, void* y_hi, void* y_lo, int rows, int cols, float eps,
+                         int layer, spacer_stream_t stream);
+/* rotary on the first rot_heads heads of fp32 rows [tokens, heads, head_dim] (ldx floats between tokens), the other heads copied;
+ * output as a pair with token stride ldy */
+int spacer_rope_f32_pair(const float* x, long ldx, const float* cos_t, const float* sin_t, void* y_hi, void* y_lo, long ldy,
+                         int tokens, int rot_heads, int heads, int head_dim, spacer_stream_t stream);
+/* spacer_embed_fwd with fp32 vision rows */
+int spacer_embed_fwd_f32video(const int64_t* ids, const void* table, const float* video, const int* video_row_of_token, float* out,
+                              int T, int H, spacer_stream_t stream);
+/* spacer_attn_fwd on pair operands: S = Qh Kh + Qh Kl + Ql Kh, O = Ph Vh + Ph Vl + Pl Vh, fp32 softmax; O written as a pair.
+ * lse may be NULL. */
+int spacer_attn_fwd_pair(const void* q_hi, const void* q_lo, const void* k_hi, const void* k_lo, const void* v_hi, const void* v_lo,
+                         void* o_hi, void* o_lo, float* lse, long q_stride, long kv_stride, long o_stride,
+                         const spacer_attn_segment* segs_dev, int num_segs, int max_q_len, int T, int Hq, int Hkv, int D, int causal,
+                         float scale, spacer_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

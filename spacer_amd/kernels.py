@@ -523,6 +523,83 @@ def gather_frames(frames_u8: torch.Tensor, idx32: torch.Tensor, *, out=None) -> 
     return out
 
 
+# ----------------------------------------------------------------------------------------- precise scoring mode (csrc/precise.hip)
+def _pair_out(rows, cols, device):
+    return (torch.empty(rows, cols, device=device, dtype=BF16), torch.empty(rows, cols, device=device, dtype=BF16))
+
+
+def gemm_pair(a_hi, a_lo, w, *, bias=None, residual=None, out=None):
+    """fp32 out = (a_hi + a_lo) @ w^T + bias + residual: two accumulate passes of the production GEMM (weights are exactly
+    bf16, so only the activation operand is a pair).  ``out`` may alias ``residual`` (in-place update of the stream)."""
+    out = gemm_nt(a_hi, w, bias=bias, residual=residual, out=out, out_dtype=torch.float32)
+    return gemm_nt(a_lo, w, residual=out, out=out, out_dtype=torch.float32)
+
+
+def split_pair(x32):
+    rows, cols = x32.shape
+    hi, lo = _pair_out(rows, cols, x32.device)
+    check(_lib.load().spacer_split_f32_pair(_ptr(x32), _rowmajor(x32), _ptr(hi), _ptr(lo), cols, rows, cols, _stream()),
+          "split_f32_pair")
+    return hi, lo
+
+
+def act_pair(x32, act):
+    rows, cols = x32.shape
+    hi, lo = _pair_out(rows, cols, x32.device)
+    check(_lib.load().spacer_act_f32_pair(_ptr(x32), _rowmajor(x32), _ptr(hi), _ptr(lo), cols, rows, cols, act, _stream()),
+          "act_f32_pair")
+    return hi, lo
+
+
+def swiglu_pair(gu32):
+    rows, two_i = gu32.shape
+    assert gu32.is_contiguous() and gu32.dtype == torch.float32
+    hi, lo = _pair_out(rows, two_i // 2, gu32.device)
+    check(_lib.load().spacer_swiglu_f32_pair(_ptr(gu32), _ptr(hi), _ptr(lo), rows, two_i // 2, _stream()), "swiglu_f32_pair")
+    return hi, lo
+
+
+def norm_pair(x32, w, b=None, eps=1e-6):
+    """RMSNorm (b is None) or LayerNorm of fp32 rows with the output as a (hi, lo) pair."""
+    rows, cols = x32.shape
+    assert x32.is_contiguous() and x32.dtype == torch.float32
+    hi, lo = _pair_out(rows, cols, x32.device)
+    check(_lib.load().spacer_norm_f32_pair(_ptr(x32), _ptr(w), _ptr(b), _ptr(hi), _ptr(lo), rows, cols, eps, int(b is not None),
+                                           _stream()), "norm_f32_pair")
+    return hi, lo
+
+
+def rope_pair(x32, cos, sin, rot_heads, heads, head_dim):
+    """fp32 [tokens, heads*head_dim] -> rotary on the first rot_heads heads, every head split into a (hi, lo) pair."""
+    tokens = x32.shape[0]
+    assert x32.dtype == torch.float32 and x32.shape[1] == heads * head_dim
+    assert cos.dtype == torch.float32 and cos.shape == (tokens, head_dim) and cos.is_contiguous() and sin.is_contiguous()
+    hi, lo = _pair_out(tokens, heads * head_dim, x32.device)
+    check(_lib.load().spacer_rope_f32_pair(_ptr(x32), _rowmajor(x32), _ptr(cos), _ptr(sin), _ptr(hi), _ptr(lo), heads * head_dim,
+                                           tokens, rot_heads, heads, head_dim, _stream()), "rope_f32_pair")
+    return hi, lo
+
+
+def embed_fwd_f32video(ids, table, video32, video_row_of_token):
+    T, H = ids.shape[0], table.shape[1]
+    out = torch.empty(T, H, device=table.device, dtype=torch.float32)
+    check(_lib.load().spacer_embed_fwd_f32video(_ptr(ids), _ptr(table), _ptr(video32), _ptr(video_row_of_token), _ptr(out), T, H,
+                                                _stream()), "embed_fwd_f32video")
+    return out
+
+
+def attn_fwd_pair(q, k, v, segs, max_q_len, Hq, Hkv, D, causal, scale):
+    """attn_fwd on pair operands: q, k, v are (hi, lo) tuples of views with equal strides; returns the (hi, lo) pair of O."""
+    (qh, ql), (kh, kl), (vh, vl) = q, k, v
+    T = qh.shape[0]
+    oh, ol = _pair_out(T, Hq * D, qh.device)
+    assert qh.stride(0) == ql.stride(0) and kh.stride(0) == kl.stride(0) == vh.stride(0) == vl.stride(0)
+    check(_lib.load().spacer_attn_fwd_pair(_ptr(qh), _ptr(ql), _ptr(kh), _ptr(kl), _ptr(vh), _ptr(vl), _ptr(oh), _ptr(ol), None,
+                                           qh.stride(0), kh.stride(0), oh.stride(0), _ptr(segs), segs.shape[0], max_q_len, T, Hq, Hkv,
+                                           D, int(causal), scale, _stream()), "attn_fwd_pair")
+    return oh, ol
+
+
 # ----------------------------------------------------------------------------------------- loss
 def logprob_fwd(logits32, targets, *, logp=None, lse=None):
     rows, vocab = logits32.shape

@@ -302,8 +302,74 @@ class Qwen2VLEngine:
             ready(p)
         return dx
 
+    # ================================================================== precise scoring mode (forward only)
+    # csrc/precise.hip: every activation between operators is fp32 or a (hi, lo) bf16 pair, every linear layer is two
+    # accumulate passes of the production GEMM, attention runs on pair operands.  Same operator order as the fast path.
+    def _vit_forward_precise(self, pix: torch.Tensor, grids) -> torch.Tensor:
+        """pix bf16 [Np, patch_kpad] -> merged vision embeds fp32 [Np/4, hidden] (in merge-unit order)."""
+        cfg, W = self.cfg, self.W
+        D, Hh, hd = cfg.vit_dim, cfg.vit_heads, cfg.vit_head_dim
+        Np = pix.shape[0]
+        v25 = cfg.vit_kind == "qwen2_5"
+        cos, sin = POS.vit_tables(grids, cfg, self.dev)
+        frame_list = POS.vit_segments(grids)
+        frame_segs, max_frame = K.make_segments(frame_list, self.dev), max(s[1] for s in frame_list)
+        unit_perm = None
+        if v25:
+            unit_perm, row_perm, win_list = POS.vit_window_plan(grids, cfg)
+            rows_dev = row_perm.to(self.dev)
+            cos, sin = cos.index_select(0, rows_dev).contiguous(), sin.index_select(0, rows_dev).contiguous()
+            win_segs, max_win = K.make_segments(win_list, self.dev), max(s[1] for s in win_list)
+            pix = K.gather_rows(pix, rows_dev.int())
+        scale = hd ** -0.5
+        x = K.gemm_nt(pix, W["vit.patch_w"], out_dtype=F32)                # pixel rows are exactly bf16: one pass
+        for i in range(cfg.vit_depth):
+            p = f"vit.{i}."
+            segs, max_q = (frame_segs, max_frame) if (not v25 or i in cfg.vit_fullatt) else (win_segs, max_win)
+            h = K.norm_pair(x, W[p + "n1_w"], None if v25 else W[p + "n1_b"], 1e-6)
+            qkv32 = K.gemm_pair(*h, W[p + "qkv_w"], bias=W[p + "qkv_b"])
+            qh, ql = K.rope_pair(qkv32, cos, sin, 2 * Hh, 3 * Hh, hd)
+            del qkv32
+            o = K.attn_fwd_pair((qh[:, :D], ql[:, :D]), (qh[:, D:2 * D], ql[:, D:2 * D]), (qh[:, 2 * D:], ql[:, 2 * D:]),
+                                segs, max_q, Hh, Hh, hd, False, scale)
+            K.gemm_pair(*o, W[p + "proj_w"], bias=W[p + "proj_b"], residual=x, out=x)
+            h2 = K.norm_pair(x, W[p + "n2_w"], None if v25 else W[p + "n2_b"], 1e-6)
+            if v25:
+                a = K.swiglu_pair(K.gemm_pair(*h2, W[p + "gu_w"], bias=W[p + "gu_b"]))
+                K.gemm_pair(*a, W[p + "down_w"], bias=W[p + "down_b"], residual=x, out=x)
+            else:
+                a = K.act_pair(K.gemm_pair(*h2, W[p + "fc1_w"], bias=W[p + "fc1_b"]), K.SPACER_ACT_QUICK_GELU)
+                K.gemm_pair(*a, W[p + "fc2_w"], bias=W[p + "fc2_b"], residual=x, out=x)
+        hm = K.norm_pair(x, W["merger.ln_w"], None if v25 else W["merger.ln_b"], 1e-6)
+        m4 = cfg.merge ** 2
+        g = K.act_pair(K.gemm_pair(hm[0].view(Np // m4, m4 * D), hm[1].view(Np // m4, m4 * D), W["merger.m0_w"],
+                                   bias=W["merger.m0_b"]), K.SPACER_ACT_GELU_ERF)
+        merged = K.gemm_pair(*g, W["merger.m2_w"], bias=W["merger.m2_b"])
+        return merged, (None if unit_perm is None else torch.argsort(unit_perm).to(self.dev))
+
+    def _llm_forward_precise(self, x: torch.Tensor, cos, sin, segs, max_q: int) -> torch.Tensor:
+        """x fp32 [T, hidden], updated in place layer by layer -> the stream before the final norm."""
+        cfg, W = self.cfg, self.W
+        Hq, Hkv, D = cfg.heads, cfg.kv_heads, cfg.head_dim
+        qd, kd = Hq * D, Hkv * D
+        scale = D ** -0.5
+        for i in range(cfg.layers):
+            p = f"llm.{i}."
+            h = K.norm_pair(x, W[p + "ln1_w"], None, cfg.rms_eps)
+            qkv32 = K.gemm_pair(*h, W[p + "qkv_w"], bias=W[p + "qkv_b"])
+            qh, ql = K.rope_pair(qkv32, cos, sin, Hq + Hkv, Hq + 2 * Hkv, D)
+            del qkv32
+            o = K.attn_fwd_pair((qh[:, :qd], ql[:, :qd]), (qh[:, qd:qd + kd], ql[:, qd:qd + kd]), (qh[:, qd + kd:], ql[:, qd + kd:]),
+                                segs, max_q, Hq, Hkv, D, True, scale)
+            K.gemm_pair(*o, W[p + "o_w"], residual=x, out=x)
+            h2 = K.norm_pair(x, W[p + "ln2_w"], None, cfg.rms_eps)
+            a = K.swiglu_pair(K.gemm_pair(*h2, W[p + "gu_w"]))
+            K.gemm_pair(*a, W[p + "down_w"], residual=x, out=x)
+        return x
+
     # ================================================================== embeddings
-    def embed(self, ids: torch.Tensor, video: Optional[torch.Tensor], placeholder_scopes: Optional[Sequence[Tuple[int, int]]] = None):
+    def embed(self, ids: torch.Tensor, video: Optional[torch.Tensor], placeholder_scopes: Optional[Sequence[Tuple[int, int]]] = None,
+              unit_rev: Optional[torch.Tensor] = None):
         """ids int64 [T] (device); video bf16 [Nv, hidden] rows replace placeholder tokens in order.  Only tokens inside
         ``placeholder_scopes`` ([start, end) ranges: the prompts) can be placeholders: a SAMPLED completion token that happens
         to be <|video_pad|> / <|image_pad|> (random-init policies do emit them) is an ordinary token with its own embedding row
@@ -319,6 +385,10 @@ class Qwen2VLEngine:
                 is_vis &= inside
             vrow = torch.where(is_vis, torch.cumsum(is_vis.int(), 0, dtype=torch.int32) - 1,
                                torch.full_like(ids, -1, dtype=torch.int32)).int().contiguous()
+            if unit_rev is not None:       # vision rows still in the window order of the Qwen2.5 tower: row i lives at unit_rev[i]
+                vrow = torch.where(vrow >= 0, unit_rev.int()[vrow.clamp(min=0).long()], vrow).int().contiguous()
+        if video is not None and video.dtype == F32:                        # precise scoring mode
+            return K.embed_fwd_f32video(ids, self.W["llm.embed"], video, vrow), vrow
         return K.embed_fwd(ids, self.W["llm.embed"], video, vrow), vrow
 
     # ================================================================== group scoring (policy / reference logps)
@@ -331,13 +401,15 @@ class Qwen2VLEngine:
         return segs, sel.reshape(-1).int()
 
     def score_group(self, prompt_ids: torch.Tensor, completion_ids: torch.Tensor, pix: Optional[torch.Tensor], grids,
-                    *, tape: Optional[dict] = None, era_rule: bool = False) -> torch.Tensor:
+                    *, tape: Optional[dict] = None, era_rule: bool = False, precise: bool = False) -> torch.Tensor:
         """Per-token log-probs [K, C] of K completions of one prompt (SG_RLVR_trainer.py:353-366,527-528),
-        computed with the prompt shared: the prompt runs once and every rollout attends its keys."""
-        return self.score_groups([(prompt_ids, pix, grids)], [completion_ids], tape=tape, era_rule=era_rule)
+        computed with the prompt shared: the prompt runs once and every rollout attends its keys.  ``precise=True``: the
+        forward-only mode that holds the north-star's 1e-3 against an fp32 evaluation at full depth (csrc/precise.hip)."""
+        return self.score_groups([(prompt_ids, pix, grids)], [completion_ids], tape=tape, era_rule=era_rule, precise=precise)
 
     def score_groups(self, prompts: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor], Optional[Sequence]]],
-                     completions: Sequence[torch.Tensor], *, tape: Optional[dict] = None, era_rule: bool = False) -> torch.Tensor:
+                     completions: Sequence[torch.Tensor], *, tape: Optional[dict] = None, era_rule: bool = False,
+                     precise: bool = False) -> torch.Tensor:
         """``score_group`` for SEVERAL prompt groups in ONE token-packed pass: prompts[g] = (prompt_ids, pix, grids),
         completions[g] int64 [K, C] (same K, C for all g); returns [G*K, C] in group order.  Groups are independent (their
         segments never see each other), so the numbers are the single-group ones; what changes is the launch shape: every GEMM
@@ -348,12 +420,16 @@ class Qwen2VLEngine:
         assert all(tuple(c.shape) == (Kn, C) for c in completions) and len(prompts) == len(completions)
         with_video = [g for g, (_, pix, _) in enumerate(prompts) if pix is not None]
         assert len(with_video) in (0, len(prompts)), "groups of one pass either all carry vision inputs or none does"
+        assert not (precise and tape is not None), "the precise scoring mode is forward only"
         vit_tape = {} if tape is not None else None
-        video, all_grids = None, []
+        video, all_grids, unit_rev = None, [], None
         if with_video:
             all_grids = [g for _, _, gr in prompts for g in gr]
             pix_all = prompts[0][1] if len(prompts) == 1 else torch.cat([p[1] for p in prompts], 0)
-            video = self.vit_forward(pix_all, all_grids, vit_tape)
+            if precise:
+                video, unit_rev = self._vit_forward_precise(pix_all, all_grids)
+            else:
+                video = self.vit_forward(pix_all, all_grids, vit_tape)
         ids_parts, pos_parts, seg_list, sel_parts, scope = [], [], [], [], []
         off = 0
         for (prompt_ids, _, grids), comp in zip(prompts, completions):
@@ -369,18 +445,24 @@ class Qwen2VLEngine:
             off += P + Kn * C
         T = off
         ids = torch.cat(ids_parts)
-        x0, vrow = self.embed(ids, video, placeholder_scopes=scope)
         cos, sin = POS.mrope_tables(torch.cat(pos_parts, dim=1), cfg, self.dev)
         segs = K.make_segments(seg_list, self.dev)
         sel = torch.cat(sel_parts).to(self.dev)
         max_q = max(s[1] for s in seg_list)
+        targets = torch.cat([c.reshape(-1) for c in completions]).contiguous()
+        if precise:
+            x0 = self.embed(ids, video, placeholder_scopes=scope, unit_rev=unit_rev)[0]
+            x = self._llm_forward_precise(x0, cos, sin, segs, max_q)
+            hn = K.norm_pair(x, self.W["llm.norm_w"], None, cfg.rms_eps)
+            logits = K.gemm_pair(K.gather_rows(hn[0], sel), K.gather_rows(hn[1], sel), self.W["llm.lm_head"])
+            return K.logprob_fwd(logits, targets)[0].view(len(prompts) * Kn, C)
+        x0, vrow = self.embed(ids, video, placeholder_scopes=scope)
         llm_tape = [] if tape is not None else None
         x = self.llm_forward(x0, cos, sin, segs, max_q, tape=llm_tape)
         rstd_f = self._empty(T)
         hn = K.rmsnorm_fwd(x, self.W["llm.norm_w"], cfg.rms_eps, rstd=rstd_f)
         hsel = K.gather_rows(hn, sel)
         logits = K.gemm_nt(hsel, self.W["llm.lm_head"], out_dtype=F32)
-        targets = torch.cat([c.reshape(-1) for c in completions]).contiguous()
         logp, lse = K.logprob_fwd(logits, targets)
         if tape is not None:
             tape.update(vit=vit_tape, llm=llm_tape, ids=ids, vrow=vrow, cos=cos, sin=sin, segs=segs, max_q=max_q, sel=sel,
