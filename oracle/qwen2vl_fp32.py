@@ -306,7 +306,7 @@ def mrope_tables(pos3: torch.Tensor, cfg: dict):
 # --------------------------------------------------------------------------------------
 def llm_forward(w: Weights, cfg: dict, embeds: torch.Tensor, pos3: torch.Tensor,
                 attn_mask: Optional[torch.Tensor] = None, *, return_hidden: bool = False,
-                collect: Optional[dict] = None) -> torch.Tensor:
+                collect: Optional[dict] = None, final_norm: bool = True) -> torch.Tensor:
     """embeds (S, hidden) for ONE sequence (or a packed layout with ``attn_mask``).
 
     ``attn_mask`` is an (S, S) boolean "may attend" matrix; default = causal.
@@ -340,6 +340,8 @@ def llm_forward(w: Weights, cfg: dict, embeds: torch.Tensor, pos3: torch.Tensor,
         h = rms_norm(x, w[p + "post_attention_layernorm.weight"], cfg["rms_eps"])
         g = F.silu(h @ w[p + "mlp.gate_proj.weight"].float().t()) * (h @ w[p + "mlp.up_proj.weight"].float().t())
         x = x + g @ w[p + "mlp.down_proj.weight"].float().t()
+    if not final_norm:                 # layer-local parity tests: the residual stream itself (tests/test_layer_local_gpu.py)
+        return x
     x = rms_norm(x, w["model.norm.weight"], cfg["rms_eps"])
     if return_hidden:
         return x

@@ -459,16 +459,42 @@ class Qwen2VLEngine:
         x0, vrow = self.embed(ids, video, placeholder_scopes=scope)
         llm_tape = [] if tape is not None else None
         x = self.llm_forward(x0, cos, sin, segs, max_q, tape=llm_tape)
-        rstd_f = self._empty(T)
+        logp = self.head_forward(x, sel, targets, tape)
+        if tape is not None:
+            tape.update(vit=vit_tape, llm=llm_tape, ids=ids, vrow=vrow, cos=cos, sin=sin, segs=segs, max_q=max_q, T=T,
+                        has_video=video is not None)
+        return logp.view(len(prompts) * Kn, C)
+
+    # ================================================================== head: final norm -> lm_head -> log-prob of the targets
+    def head_forward(self, x: torch.Tensor, sel: torch.Tensor, targets: torch.Tensor, tape: Optional[dict] = None) -> torch.Tensor:
+        """x fp32 [T, hidden] (pre-final-norm stream); rows ``sel`` (int32) predict ``targets`` (int64): the reference's
+        ``log_softmax(logits)[token]`` (TR:353-366) on the completion rows only.  Returns logp fp32 [len(sel)]."""
+        cfg = self.cfg
+        rstd_f = self._empty(x.shape[0])
         hn = K.rmsnorm_fwd(x, self.W["llm.norm_w"], cfg.rms_eps, rstd=rstd_f)
         hsel = K.gather_rows(hn, sel)
         logits = K.gemm_nt(hsel, self.W["llm.lm_head"], out_dtype=F32)
         logp, lse = K.logprob_fwd(logits, targets)
         if tape is not None:
-            tape.update(vit=vit_tape, llm=llm_tape, ids=ids, vrow=vrow, cos=cos, sin=sin, segs=segs, max_q=max_q, sel=sel,
-                        x_final=x, rstd_f=rstd_f, hsel=hsel, logits=logits, targets=targets, lse=lse, T=T,
-                        has_video=video is not None)
-        return logp.view(len(prompts) * Kn, C)
+            tape.update(sel=sel, x_final=x, rstd_f=rstd_f, hsel=hsel, logits=logits, targets=targets, lse=lse)
+        return logp
+
+    def head_backward(self, tape: dict, dlogp: torch.Tensor, G: FlatParams) -> torch.Tensor:
+        """d loss / d logp (fp32 [rows]) -> gradient of the pre-final-norm stream (fp32 [T, hidden]); lm_head and final-norm
+        gradients accumulate into G."""
+        cfg, W = self.cfg, self.W
+        T, H = tape["x_final"].shape[0], cfg.hidden
+        dlogits = K.logprob_bwd(tape["logits"], tape["targets"], tape["lse"], dlogp.reshape(-1).contiguous())
+        tape["logits"] = None
+        d_hsel = self._dx(dlogits, "llm.lm_head")
+        self._dw(G["llm.lm_head"], dlogits, tape["hsel"])
+        del dlogits
+        d_hn32 = self._zeros(T, H)
+        K.scatter_add_rows_(d_hsel, tape["sel"], d_hn32)
+        d_hn = K.cast_bf16(d_hn32)
+        dx = d_hn32                                                     # reuse the buffer for the stream gradient
+        K.rmsnorm_bwd(tape["x_final"], W["llm.norm_w"], d_hn, tape["rstd_f"], dx, G["llm.norm_w"], accumulate=False)
+        return dx
 
     def score_sequence(self, ids: torch.Tensor, pix: Optional[torch.Tensor], grids, *, tape: Optional[dict] = None,
                        era_rule: bool = False, second_per_grid_ts=None) -> torch.Tensor:
@@ -486,16 +512,10 @@ class Qwen2VLEngine:
         segs = K.make_segments([(0, S, 0, 0)], self.dev)
         llm_tape = [] if tape is not None else None
         x = self.llm_forward(x0, cos, sin, segs, S, tape=llm_tape)
-        rstd_f = self._empty(S)
-        hn = K.rmsnorm_fwd(x, self.W["llm.norm_w"], cfg.rms_eps, rstd=rstd_f)
         sel = torch.arange(S - 1, device=self.dev, dtype=torch.int32)
-        hsel = hn[:S - 1]
-        logits = K.gemm_nt(hsel, self.W["llm.lm_head"], out_dtype=F32)
-        targets = ids[1:].contiguous()
-        logp, lse = K.logprob_fwd(logits, targets)
+        logp = self.head_forward(x, sel, ids[1:].contiguous(), tape)
         if tape is not None:
-            tape.update(vit=vit_tape, llm=llm_tape, ids=ids, vrow=vrow, cos=cos, sin=sin, segs=segs, max_q=S, sel=sel,
-                        x_final=x, rstd_f=rstd_f, hsel=hsel, logits=logits, targets=targets, lse=lse, T=S,
+            tape.update(vit=vit_tape, llm=llm_tape, ids=ids, vrow=vrow, cos=cos, sin=sin, segs=segs, max_q=S, T=S,
                         has_video=video is not None)
         return logp
 
@@ -505,17 +525,8 @@ class Qwen2VLEngine:
         cfg, W = self.cfg, self.W
         ready = on_ready or (lambda prefix: None)
         tied = cfg.tie_embeddings
-        T, H = tape["T"], cfg.hidden
-        dlogits = K.logprob_bwd(tape["logits"], tape["targets"], tape["lse"], dlogp.reshape(-1).contiguous())
-        tape["logits"] = None
-        d_hsel = self._dx(dlogits, "llm.lm_head")
-        self._dw(G["llm.lm_head"], dlogits, tape["hsel"])
-        del dlogits
-        d_hn32 = self._zeros(T, H)
-        K.scatter_add_rows_(d_hsel, tape["sel"], d_hn32)
-        d_hn = K.cast_bf16(d_hn32)
-        dx = d_hn32                                                     # reuse the buffer for the stream gradient
-        K.rmsnorm_bwd(tape["x_final"], W["llm.norm_w"], d_hn, tape["rstd_f"], dx, G["llm.norm_w"], accumulate=False)
+        H = cfg.hidden
+        dx = self.head_backward(tape, dlogp, G)
         ready("llm.norm_w")
         if not tied:
             ready("llm.lm_head")
@@ -528,3 +539,11 @@ class Qwen2VLEngine:
         ready("llm.embed")
         if d_video is not None:
             self.vit_backward(tape["vit"], K.cast_bf16(d_video), G, on_ready)
+        else:
+            # a text-only last micro-batch: the vision gradients accumulated by earlier micro-batches are final too.  Report them in
+            # the order vit_backward does, so that the data-parallel reducer issues the SAME sequence of collectives on every rank
+            # whatever its data (a rank with a vision row and a rank without would otherwise disagree on bucket boundaries)
+            ready("merger.")
+            for i in reversed(range(cfg.vit_depth)):
+                ready(f"vit.{i}.")
+            ready("vit.patch_w")

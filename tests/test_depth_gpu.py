@@ -7,10 +7,12 @@ completions of 24 tokens.  The fp32 oracle (oracle/qwen2vl_fp32.py) runs the sam
 Tolerances (DESIGN.md section 4 has the per-operator table they come from):
   * log-probs: the bf16-operand floor at 28 layers is rms ~1e-2 / max ~2-3e-2 (CPU emulation of the engine's rounding points,
     oracle/qwen2vl_engine_emul.py; scripts/logp_error_budget.py 2b: 8.7e-3 / 1.9e-2 on its sample); the reference's own
-    bf16-eager numerics give rms 2.7e-2 / max 5.7e-2.  Asserted: the engine's rms error <= 1.5x the emulation's rms error ON THE
-    SAME TOKENS (the emulation runs on the host beside the oracle), and the absolute caps rms <= 2e-2, max <= 5e-2.
-    The north-star's 1e-3 needs hi+lo operand pairs on EVERY matmul operand incl. attention (emulated: 5e-5), i.e. 2-3x the
-    MFMA work; not built.
+    bf16-eager numerics give rms 2.7e-2 / max 5.7e-2.  Asserted for the FAST path: (i) LAYER BY LAYER, the rms error of the fp32
+    residual stream entering each of the 28 decoder layers <= 1.1x the emulation's at the same layer (a kernel that loses more
+    than its operand rounding shows at the layer where it happens); (ii) the log-prob rms error <= 1.5x the emulation's on the
+    same tokens, absolute caps rms <= 2e-2, max <= 5e-2.  The north-star's 1e-3 is held by the PRECISE scoring mode (hi+lo
+    operand pairs on every matmul operand incl. attention, csrc/precise.hip): tests/test_precise_gpu.py asserts it on this
+    same model (measured 3e-5).
   * gradients of selected tensors (first / middle / last decoder layer, the tied embedding table, final norm, first / last
     vision block, merger): relative Frobenius error <= 6 % against oracle autograd.
 """
@@ -77,7 +79,33 @@ def test_logps_and_gradients_match_oracle_at_2b_depth(depth):
     G = params.like(torch.float32)
     tape = {}
     lp = eng.score_group(pr.ids, comps, pr.pix, pr.grids, tape=tape)
+    eng_x = [t["x_in"].cpu() for t in tape["llm"]]             # the fp32 residual stream entering every decoder layer
     eng.backward_group(tape, dlogp.to(comps.device), G)
+    # ---- per-layer bound: engine vs the CPU emulation of its own rounding points, both against the fp32 stream, LAYER BY LAYER on
+    # the packed group layout.  A kernel that loses more than its operand rounding shows up at the layer where it happens -- before
+    # depth amplification blurs it -- as rms(engine - fp32) > rms(emulation - fp32).
+    from oracle import cpu_path as CP
+    with torch.no_grad():
+        P = pr.ids.numel()
+        ids = torch.cat([pr.ids.cpu(), comps.cpu().reshape(-1)])
+        pos3, delta = O.mrope_position_ids(pr.ids.cpu().tolist(), [d["grid"]], d["ocfg"])
+        pos = torch.cat([pos3] + [(P + delta + torch.arange(C)).view(1, C).expand(3, C)] * Kn, 1)
+        mask = CP.group_mask(P, Kn, C)
+        streams = {}
+        for tag, R in (("fp32", E.Rounder((), ())), ("emu", E.Rounder())):
+            ve = E.vit_forward(d["w"], d["ocfg"], d["rows"], [d["grid"]], R)
+            col = []
+            E.llm_hidden(d["w"], d["ocfg"], O.embed_with_video(d["w"], d["ocfg"], ids, ve), pos, R, mask, collect=col)
+            streams[tag] = [c["x_in"] for c in col]
+    rmsf = lambda t: float(t.double().pow(2).mean().sqrt())                              # noqa: E731
+    ratios = []
+    for i, (xe, xm, xf) in enumerate(zip(eng_x, streams["emu"], streams["fp32"])):
+        r_eng, r_emu = rmsf(xe - xf), rmsf(xm - xf)
+        ratios.append(r_eng / max(r_emu, 1e-12))
+        if i in (0, 1, 2, 7, 14, 21, 27):
+            print(f"   layer {i:2d} input stream: rms err engine {r_eng:.3e}  emulation {r_emu:.3e}  ratio {ratios[-1]:.2f}  (stream rms {rmsf(xf):.2e})")
+    print(f"   per-layer engine / emulation error ratio: max {max(ratios):.2f} at layer {ratios.index(max(ratios))}, mean {sum(ratios) / len(ratios):.2f}")
+    assert max(ratios) <= 1.1, ratios                     # measured 1.00 at every layer
     err = lp.cpu() - want
     rms, mx = float(err.pow(2).mean().sqrt()), float(err.abs().max())
     print(f"Qwen2-VL-2B depth: |logp - fp32 oracle| rms {rms:.2e} max {mx:.2e} over {err.numel()} tokens "

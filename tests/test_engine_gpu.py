@@ -205,3 +205,20 @@ def test_sft_loss_and_gradients_match_oracle(setup):
         if err > 0.04 * scale + 2e-4:
             bad.append((name, err, scale))
     assert not bad, bad
+
+
+def test_ready_sequence_does_not_depend_on_the_data(setup):
+    """Data-parallel overlap (grpo.GradReducer): every rank must issue the same sequence of collectives.  The parameter ranges
+    reported as final during the last backward are therefore the same for a prompt WITH vision input and a text-only one (SFT
+    'messages' rows, non-image / video rows): a text-only rank still reports the merger / vision ranges, which are final."""
+    s, g = setup, setup["g"]
+    dev = s["pix"].device
+    seqs = []
+    for pix, grids, prompt in ((s["pix"], [s["grid"]], g["prompt"]), (None, None, g["prompt"][-9:])):
+        G = s["params"].like(torch.float32)
+        tape, seen = {}, []
+        lp = s["eng"].score_group(prompt.to(dev), g["completions"].to(dev), pix, grids, tape=tape)
+        s["eng"].backward_group(tape, torch.ones_like(lp), G, on_ready=seen.append)
+        seqs.append(seen)
+    assert seqs[0] == seqs[1] and "vit.patch_w" in seqs[1] and "merger." in seqs[1]
+    assert len(set(seqs[0])) == len(seqs[0])                      # every range reported exactly once
