@@ -155,6 +155,67 @@ def pmc_traffic(workload: str, kernel: str, live: bool):
     return None, err
 
 
+def through_trainer(ge, cfg, params, frames, dev, *, groups, Kgen, C, n_text, gpp, steps, use_graph):
+    """samples/s of the workload driven through ``SGRLVRTrainer.train()`` (the reference's entry point, TR:384-686 under HF
+    Trainer): one optimizer step = ``groups`` dataset rows as gradient-accumulation micro-batches."""
+    import tempfile
+    from spacer_amd.open_r1.config import GRPOConfig, GRPOScriptArguments
+    from spacer_amd.open_r1.rewards import accuracy_reward, format_reward
+    from spacer_amd.open_r1.trainer import SGRLVRTrainer
+    from spacer_amd.synthetic import SyntheticProcessor, synthetic_video_row
+    proc = SyntheticProcessor(cfg)
+    host_frames = [f.cpu().pin_memory() for f in frames]
+    rows = [synthetic_video_row(cfg, i, host_frames[i % groups], n_text, proc) for i in range(groups * (steps + 1))]
+    out_dir = tempfile.mkdtemp(prefix="spacer_bench_trainer_")
+    targs = GRPOConfig(output_dir=out_dir, max_completion_length=C, num_generations=Kgen, gradient_accumulation_steps=groups,
+                       max_steps=steps + 1, logging_steps=1, save_steps=0, groups_per_pass=gpp, seed=1234, use_decode_graph=use_graph)
+    os.environ.pop("DEBUG_MODE", None)               # the reward functions' per-completion debug file is not part of the path
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):
+        tr = SGRLVRTrainer(model=params, reward_funcs=[accuracy_reward, format_reward], args=targs,
+                           script_args=GRPOScriptArguments(temporal=False, len_control=True), train_dataset=rows, processing_class=proc,
+                           device=dev, engine=ge)
+    tr.suppress_eos = True                           # fixed-length rollouts, as the headline (BASELINE.md section 2)
+    with contextlib.redirect_stdout(sys.stderr):     # the trainer prints its own log lines; stdout carries the bench line only
+        tr.train()
+    torch.cuda.synchronize()
+    with open(os.path.join(out_dir, "trainer_log.jsonl")) as f:
+        logs = [json.loads(line) for line in f]
+    times = [lg["step_time"] for lg in logs[1:]]     # the first step carries the prefetch warm-up
+    dt = sum(times) / len(times)
+    return {"samples_per_s": round(groups * Kgen / dt, 3), "ms_per_step": round(1e3 * dt, 1), "steps": len(times),
+            "gradient_accumulation_steps": groups, "groups_per_pass": gpp, "reward_funcs": ["accuracy_reward", "format_reward"],
+            "frames": "host-resident uint8, uploaded per step", "mean_reward": round(logs[-1].get("reward", 0.0), 4),
+            "kl": logs[-1].get("kl"), "completion_length": logs[-1].get("completion_length")}
+
+
+def precise_scoring(ge, cfg, frames, dev, *, F, Hpx, Wpx, n_text, Kgen, C, gpp):
+    """What the north-star's 1e-3 log-prob tolerance costs: the scoring forward of ``gpp`` prompt groups (reference-model
+    log-probs, no tape) on the fast bf16-operand path and in the precise mode (csrc/precise.hip: (hi, lo) operand pairs, two-pass
+    GEMMs, pair attention), same inputs."""
+    from spacer_amd.synthetic import make_prompt
+    prompts = [make_prompt(cfg, g, F, Hpx, Wpx, n_text, dev, frames_u8=frames[g])[0] for g in range(gpp)]
+    gen = torch.Generator().manual_seed(5)
+    comps = [torch.randint(1000, min(150000, cfg.vocab), (Kgen, C), generator=gen).to(dev) for _ in range(gpp)]
+    entries = [(p.ids, p.pix, p.grids) for p in prompts]
+    ge.roll.invalidate()
+    res = {}
+    for name, precise in (("fast", False), ("precise", True)):
+        lp = ge.ref_engine.score_groups(entries, comps, precise=precise)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 2
+        for _ in range(n):
+            lp = ge.ref_engine.score_groups(entries, comps, precise=precise)
+        torch.cuda.synchronize()
+        res[name] = ((time.perf_counter() - t0) / n, lp)
+    diff = (res["fast"][1] - res["precise"][1]).abs()
+    return {"groups": gpp, "fast_ms": round(1e3 * res["fast"][0], 1), "precise_ms": round(1e3 * res["precise"][0], 1),
+            "ratio": round(res["precise"][0] / res["fast"][0], 2),
+            "max_abs_logp_diff_fast_vs_precise": round(float(diff.max()), 5), "rms_logp_diff": round(float(diff.pow(2).mean().sqrt()), 5),
+            "note": "precise mode holds max |logp - fp32 oracle| 3e-5 at Qwen2-VL-2B depth (tests/test_precise_gpu.py); forward only"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -335,6 +396,24 @@ def main():
                                   "max_new_tokens": kw["sp"].max_new_tokens if "sp" in kw else C}
             except Exception as exc:                                   # e.g. out of memory on a smaller part: report, do not die
                 variants[name] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+                torch.cuda.empty_cache()
+        # ---- the same workload THROUGH the drop-in surface: SGRLVRTrainer.train() on the engine above, gradient_accumulation_steps =
+        # groups, dataset rows around host-resident frames (uploaded per step: PCIe included), the GPU front end, the real
+        # accuracy_reward / format_reward on decoded text, metrics + logging; step time = wall time between the trainer's own log lines
+        if args.workload in ("cfg3", "tiny"):
+            try:
+                variants["through_trainer"] = through_trainer(ge, cfg, params, frames, dev, groups=groups, Kgen=Kgen, C=C, n_text=n_text,
+                                                              gpp=max(1, min(gpp_default, groups)), steps=2, use_graph=not args.no_graph)
+                if "ms_per_step" in variants["through_trainer"]:
+                    variants["through_trainer"]["vs_headline"] = round(variants["through_trainer"]["samples_per_s"] / (groups * Kgen * args.steps / elapsed), 4)
+            except Exception as exc:
+                variants["through_trainer"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+                torch.cuda.empty_cache()
+            try:
+                variants["precise_scoring"] = precise_scoring(ge, cfg, frames, dev, F=F, Hpx=Hpx, Wpx=Wpx, n_text=n_text, Kgen=Kgen, C=C,
+                                                              gpp=max(1, min(gpp_default, groups)))
+            except Exception as exc:
+                variants["precise_scoring"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
                 torch.cuda.empty_cache()
         roll_stats.clear()
         roll_stats.update(main_stats)

@@ -261,6 +261,9 @@ class GRPOEngine:
             ref_lp = self.ref_engine.score_group(prompt.ids, completion_ids, prompt.pix, prompt.grids, era_rule=era_rule)
             tape: dict = {}
             lp = self.engine.score_group(prompt.ids, completion_ids, prompt.pix, prompt.grids, tape=tape, era_rule=era_rule)
+            if callable(advantages):           # lazy: the host shapes the rewards while the two forwards run (see _multi)
+                advantages = advantages()
+                advantages = (advantages[0] if isinstance(advantages, (list, tuple)) else advantages).to(self.dev)
             loss, kl, dlogp = K.grpo_loss(lp, ref_lp, advantages, mask, self.h.beta)
             if grad_scale != 1.0:
                 dlogp.mul_(grad_scale)
@@ -272,7 +275,10 @@ class GRPOEngine:
                                  grad_scale: float = 1.0, *, era_rule: bool = False, last_group: bool = False) -> Dict[str, torch.Tensor]:
         """``score_and_backward`` for several prompt groups in ONE scoring pass each for the reference and the policy and ONE
         backward (Qwen2VLEngine.score_groups): the same gradients as calling it group by group -- the loss is the mean over
-        groups, each group's rows enter the loss kernel with 1/len(prompts) -- with G x the rows per kernel launch."""
+        groups, each group's rows enter the loss kernel with 1/len(prompts) -- with G x the rows per kernel launch.
+        ``advantages`` may be a CALLABLE returning the list: it is invoked after both forward passes have been queued on the
+        stream, so host-side reward functions (decode text -> regex / map scoring, TR:576-593) run while the GPU scores --
+        the reference leaves the GPU idle there."""
         cfg, Gn = self.cfg, len(prompts)
         Kn, C = completions[0].shape
         # the rollouts of this step are done: the fragment-major decode copies of the weights (1x the LLM, 14 GB at 7B) are
@@ -285,8 +291,10 @@ class GRPOEngine:
             ref_lp = self.ref_engine.score_groups(entries, completions, era_rule=era_rule)
             tape: dict = {}
             lp = self.engine.score_groups(entries, completions, tape=tape, era_rule=era_rule)
+            if callable(advantages):
+                advantages = advantages()
             # the loss kernel averages over its rows: G groups of K rows -> mean over G*K rows = (1/G) * sum of group means
-            loss, kl, dlogp = K.grpo_loss(lp, ref_lp, torch.cat(advantages).to(self.dev), mask, self.h.beta)
+            loss, kl, dlogp = K.grpo_loss(lp, ref_lp, torch.cat(list(advantages)).to(self.dev), mask, self.h.beta)
             if grad_scale * Gn != 1.0:
                 dlogp.mul_(grad_scale * Gn)
             hook = self.reducer.ready if (last_group and self.reducer is not None and self.h.overlap_comm) else None

@@ -149,7 +149,7 @@ class SGRLVRTrainer:
                  eval_dataset=None, processing_class=None, reward_processing_classes=None, callbacks=None,
                  optimizers=(None, None), peft_config=None, max_pixels: Optional[int] = 12845056,
                  min_pixels: Optional[int] = 3136, attn_implementation: str = "flash_attention_2", *,
-                 model_config: Optional[Qwen2VLConfig] = None, device=None, process_group=None):
+                 model_config: Optional[Qwen2VLConfig] = None, device=None, process_group=None, engine: Optional[GRPOEngine] = None):
         if args is None:
             name = model if isinstance(model, str) else "model"
             args = GRPOConfig(output_dir=f"{name.split('/')[-1]}-GRPO")
@@ -208,7 +208,13 @@ class SGRLVRTrainer:
                           len_control=self.len_control, lr_scheduler_type=args.lr_scheduler_type, total_steps=total_steps,
                           warmup_steps=args.warmup_steps)
         self.total_steps = total_steps
-        self.engine = GRPOEngine(cfg, params, hyper, process_group=process_group)
+        # ``engine``: an existing GRPOEngine over ``model`` (bench.py times the trainer on the engine it already holds: a second
+        # copy of master weights + Adam state would not fit)
+        self.engine = engine if engine is not None else GRPOEngine(cfg, params, hyper, process_group=process_group)
+        # micro-batches of a gradient-accumulation step scored / back-propagated per token-packed pass (GRPOEngine.
+        # score_and_backward_multi): 2 = what 288 GB holds at 7B with 16-frame prompts and 512-token rollouts
+        self.groups_per_pass = max(1, int(getattr(args, "groups_per_pass", 2)))
+        self.suppress_eos = False            # bench.py's throughput mode: fixed-length rollouts
         self._metrics: Dict[str, list] = defaultdict(list)
         self.global_step = 0
         self._sample_seed = args.seed * 1000003 + self.rank
@@ -289,7 +295,7 @@ class SGRLVRTrainer:
 
     def _run_rewards(self, inputs, prompts, completion_ids, n, video_path=None) -> torch.Tensor:
         """TR:576-593 (and the shuffled twin :554-572): decode, wrap, call every reward function."""
-        texts = self.processing_class.batch_decode(completion_ids, skip_special_tokens=True)
+        texts = self.processing_class.batch_decode(completion_ids.cpu(), skip_special_tokens=True)
         completions = [[{"role": "assistant", "content": t}] for t in texts] if is_conversational(inputs[0]) else texts
         rep_prompts = [p for p in prompts for _ in range(n)]
         out = torch.zeros(len(rep_prompts), len(self.reward_funcs), dtype=torch.float32)
@@ -338,7 +344,7 @@ class SGRLVRTrainer:
         not a second decode loop.  Returns per sample dict(prompt, completion_ids [G, C], shuffled_ids [G/2, C] or None)."""
         G = self.num_generations
         sp = SamplingParams(max_new_tokens=self.max_completion_length, top_k=self.args.top_k, top_p=0.95, temperature=1.0,
-                            seed=self._sample_seed + 7919 * self.global_step, era_rule=self.era_rule)
+                            seed=self._sample_seed + 7919 * self.global_step, era_rule=self.era_rule, suppress_eos=self.suppress_eos)
         prompts, slots = [], []
         for prep in preps:
             slots.append((len(prompts), prep["sproc"] is not None))
@@ -346,51 +352,111 @@ class SGRLVRTrainer:
             if prep["sproc"] is not None:
                 prompts.append(self._prompt_input(prep["sproc"]))
         ids = self._generate(prompts, G, sp)
+        host = ids.cpu()       # ONE device-to-host copy for the step, taken when the decode loop has just ended: the reward
+        #                        functions read it while the scoring passes run (no sync inside the scoring phase)
         out = []
         for at, twin in slots:
-            shuffled = ids[(at + 1) * G:(at + 1) * G + self.shuffled_num_generations] if twin else None
-            out.append(dict(prompt=prompts[at], completion_ids=ids[at * G:(at + 1) * G], shuffled_ids=shuffled))
+            sl = slice((at + 1) * G, (at + 1) * G + self.shuffled_num_generations)
+            out.append(dict(prompt=prompts[at], completion_ids=ids[at * G:(at + 1) * G], completion_host=host[at * G:(at + 1) * G],
+                            shuffled_ids=ids[sl] if twin else None, shuffled_host=host[sl] if twin else None))
         return out
+
+    def _shape(self, inputs, prep: dict, rolled: dict) -> dict:
+        """Host half of TR:554-638 for one sample: decode -> reward functions (and the shuffled twin's) -> T-GRPO / length bonus
+        -> group advantages.  Reads only the host copy of the ids."""
+        G = self.num_generations
+        prompts = [x["prompt"] for x in inputs]
+        comp = rolled.get("completion_host")
+        comp = comp if comp is not None else rolled["completion_ids"].cpu()
+        shuf = rolled.get("shuffled_host")
+        if shuf is None and rolled.get("shuffled_ids") is not None:
+            shuf = rolled["shuffled_ids"].cpu()
+        shuffled_rpf = None
+        if shuf is not None:                                                                 # T-GRPO (TR:442-481, :554-572)
+            shuffled_rpf = self._run_rewards(inputs, prompts, shuf, self.shuffled_num_generations)
+        rewards_per_func = self._run_rewards(inputs, prompts, comp, G, video_path=inputs[0]["path"])
+        rewards, temporal_reward = temporal_bonus(rewards_per_func, shuffled_rpf, self.temporal, prep["has_video"])
+        eos = getattr(self.processing_class, "eos_token_id", self.cfg.eos_token_id)
+        is_eos = comp == eos
+        lengths = torch.where(is_eos.any(1), is_eos.int().argmax(1) + 1, torch.full((G,), comp.shape[1]))
+        rewards = length_bonus(rewards, rewards_per_func, lengths, self.len_control)
+        adv, std = group_advantages(rewards, G)
+        return dict(adv=adv, std=std, lengths=lengths, rewards_per_func=rewards_per_func, rewards=rewards,
+                    temporal_reward=temporal_reward)
+
+    def _record_metrics(self, shaped: List[dict], kls: List[torch.Tensor]) -> None:
+        """TR:650-683 for every micro-batch of the step at once: ONE device sync for the KL values and ONE packed all-gather
+        (the reference: nine gathers per micro-batch); the logged means are the same as recording them one by one."""
+        kl_host = torch.stack([k.reshape(()) for k in kls]).float().cpu()
+        packed = torch.stack([pack_metrics(sh["lengths"], sh["rewards_per_func"], sh["rewards"], sh["temporal_reward"], sh["std"],
+                                           float(kl_host[i])) for i, sh in enumerate(shaped)])                   # [n, SLOTS]
+        if self.pg is not None:
+            src = packed.to(self.device) if torch.distributed.get_backend(self.pg) == "nccl" else packed
+            buf = [torch.zeros_like(src) for _ in range(self.world)]
+            torch.distributed.all_gather(buf, src, group=self.pg)
+            stacked = torch.stack(buf).cpu()                                                                   # [world, n, SLOTS]
+        else:
+            stacked = packed.unsqueeze(0)
+        names = [getattr(f, "__name__", str(f)) for f in self.reward_funcs]
+        for j in range(stacked.shape[1]):
+            for k, v in reduce_metrics(stacked[:, j], names, self.temporal).items():
+                self._metrics[k].append(v)
 
     def compute_loss(self, model, inputs, return_outputs=False, num_items_in_batch=None, *, grad_scale: float = 1.0,
                      prepared: Optional[dict] = None, rolled: Optional[dict] = None, last_micro_batch: bool = False):
         if return_outputs:
             raise ValueError("The GRPOTrainer does not support returning outputs")
-        eng, G = self.engine, self.num_generations
-        prompts = [x["prompt"] for x in inputs]
-        video_path = inputs[0]["path"]
+        eng = self.engine
         prep = prepared if prepared is not None else self._prepare(inputs, self._sample_seed + 104729 * self.global_step)
-        has_video = prep["has_video"]
         if rolled is None:                      # stand-alone call: this sample's rollouts only
             rolled = self._rollout([prep])[0]
-        prompt, completion_ids = rolled["prompt"], rolled["completion_ids"]
-        shuffled_rpf = None
-        if rolled["shuffled_ids"] is not None:                                               # T-GRPO (TR:442-481, :554-572)
-            shuffled_rpf = self._run_rewards(inputs, prompts, rolled["shuffled_ids"], self.shuffled_num_generations)
+        shaped = []
 
-        rewards_per_func = self._run_rewards(inputs, prompts, completion_ids, G, video_path=video_path)
-        rewards, temporal_reward = temporal_bonus(rewards_per_func, shuffled_rpf, self.temporal, has_video)
-        eos = getattr(self.processing_class, "eos_token_id", self.cfg.eos_token_id)
-        is_eos = (completion_ids == eos).cpu()
-        lengths = torch.where(is_eos.any(1), is_eos.int().argmax(1) + 1, torch.full((G,), completion_ids.shape[1]))
-        rewards = length_bonus(rewards, rewards_per_func, lengths, self.len_control)
-        adv, std = group_advantages(rewards, G)
+        def advantages():                       # runs after both forward passes are queued: rewards overlap the scoring
+            shaped.append(self._shape(inputs, prep, rolled))
+            return [shaped[0]["adv"]]
         # last_micro_batch: finished layer ranges of this backward go to the data-parallel reducer while it still runs
-        res = eng.score_and_backward(prompt, completion_ids, adv.to(self.device), grad_scale=grad_scale, era_rule=self.era_rule,
-                                     last_group=last_micro_batch)
-
-        packed = pack_metrics(lengths, rewards_per_func, rewards, temporal_reward, std, float(res["kl"]))
-        if self.pg is not None:
-            src = packed.to(self.device) if torch.distributed.get_backend(self.pg) == "nccl" else packed
-            buf = [torch.zeros_like(src) for _ in range(self.world)]
-            torch.distributed.all_gather(buf, src, group=self.pg)       # ONE collective (reference: nine, TR:650-683)
-            stacked = torch.stack(buf).cpu()
-        else:
-            stacked = packed.unsqueeze(0)
-        names = [getattr(f, "__name__", str(f)) for f in self.reward_funcs]
-        for k, v in reduce_metrics(stacked, names, self.temporal).items():
-            self._metrics[k].append(v)
+        res = eng.score_and_backward(rolled["prompt"], rolled["completion_ids"], advantages, grad_scale=grad_scale,
+                                     era_rule=self.era_rule, last_group=last_micro_batch)
+        self._record_metrics(shaped, [res["kl"]])
         return res["loss"]
+
+    def _accumulate(self, rows: List[dict], preps: List[dict], rolled: List[dict]) -> float:
+        """The gradient-accumulation micro-batches of ONE optimizer step (TR:384-686 called ``acc`` times by HF Trainer), on the
+        path bench.py measures: ``groups_per_pass`` micro-batches per token-packed scoring pass, reward functions of a pass
+        computed on the host while its forwards run, NO device sync until the step's backward passes are all queued (the KL /
+        loss read-back and the metric all-gather happen once per optimizer step).  Returns the mean loss."""
+        eng, acc = self.engine, len(rows)
+        gpp = max(1, min(self.groups_per_pass, acc))
+        shaped: List[Optional[dict]] = [None] * acc
+        kls: List[Optional[torch.Tensor]] = [None] * acc
+        losses = []
+        for j0 in range(0, acc, gpp):
+            js = list(range(j0, min(acc, j0 + gpp)))
+
+            def advantages(js=js):
+                for j in js:
+                    shaped[j] = self._shape([rows[j]], preps[j], rolled[j])
+                return [shaped[j]["adv"] for j in js]
+            last = js[-1] == acc - 1
+            if len(js) == 1:
+                res = eng.score_and_backward(rolled[j0]["prompt"], rolled[j0]["completion_ids"], advantages, grad_scale=1.0 / acc,
+                                             era_rule=self.era_rule, last_group=last)
+            else:
+                res = eng.score_and_backward_multi([rolled[j]["prompt"] for j in js], [rolled[j]["completion_ids"] for j in js],
+                                                   advantages, grad_scale=len(js) / acc, era_rule=self.era_rule, last_group=last)
+            for j in js:
+                kls[j] = res["kl"]              # a pass's KL is the mean over its groups: the logged step mean is unchanged
+                rolled[j] = None
+            losses.append((len(js), res["loss"]))
+        self._pending_step = (shaped, kls, losses, acc)
+        return 0.0
+
+    def _finish_step(self) -> float:
+        shaped, kls, losses, acc = self._pending_step
+        self._pending_step = None
+        self._record_metrics(shaped, kls)
+        return sum(n * float(l) for n, l in losses) / acc
 
     # ------------------------------------------------------------------ loop / logging / checkpoints
     def log(self, logs: Dict[str, float], start_time: Optional[float] = None) -> None:
@@ -439,13 +505,10 @@ class SGRLVRTrainer:
                 # the next optimizer step's host work (chat template, frame decode + resize, patchify) overlaps this one's GPU work
                 pending = submit(starts[n + 1]) if n + 1 < len(starts) else None
                 rolled = self._rollout(preps)        # ONE decode batch for all micro-batches of the step (same weights)
-                loss = 0.0
-                for j in range(acc):
-                    loss += float(self.compute_loss(None, [self.train_dataset[idx[s + j]]], grad_scale=1.0 / acc, prepared=preps[j],
-                                                    rolled=rolled[j], last_micro_batch=j == acc - 1)) / acc
-                    rolled[j] = None
+                self._accumulate([self.train_dataset[idx[s + j]] for j in range(acc)], preps, rolled)
                 self.engine.reduce_gradients()
                 lr = self.engine.optimizer_step(self.world)
+                loss = self._finish_step()           # the step's only read-back: losses, KL values, one packed metric gather
                 self.global_step += 1
                 if self.global_step % a.logging_steps == 0:
                     self.log({"loss": loss, "learning_rate": lr, "grad_norm": self.engine.grad_norm(self.world),

@@ -47,3 +47,82 @@ def synthetic_rewards(step: int, prompt_idx: int, num_generations: int) -> torch
     acc = torch.where(acc < 0.6, torch.zeros_like(acc), acc)       # some wrong answers, as real groups have
     fmt = (torch.rand(num_generations, generator=g) > 0.3).float()
     return torch.stack([acc, fmt], dim=1)
+
+
+# ------------------------------------------------------------------------------------- a processor for synthetic text
+class SyntheticTokenizer:
+    """``processor.tokenizer`` surface over whitespace "words": special markers map to the model's special ids (one id per
+    <|video_pad|> / <|image_pad|>), every other word hashes into the ordinary vocabulary."""
+
+    def __init__(self, cfg: Qwen2VLConfig):
+        self.cfg = cfg
+        self.special = {"<|vision_start|>": cfg.vision_start_id, "<|vision_end|>": cfg.vision_end_id,
+                        "<|video_pad|>": cfg.video_token_id, "<|image_pad|>": cfg.image_token_id}
+
+    def word_id(self, word: str) -> int:
+        h = 2166136261
+        for ch in word.encode():
+            h = ((h ^ ch) * 16777619) & 0xFFFFFFFF
+        lo = min(1000, self.cfg.vocab // 2)
+        hi = min(150000, self.cfg.vocab)
+        return lo + h % (hi - lo)
+
+    def __call__(self, text, add_special_tokens=False):
+        import re
+        out = []
+        for t in text:
+            ids = []
+            for piece in re.split(r"(<\|vision_start\|>|<\|vision_end\|>|<\|video_pad\|>|<\|image_pad\|>)", t):
+                if piece in self.special:
+                    ids.append(self.special[piece])
+                else:
+                    ids += [self.word_id(w) for w in piece.split()]
+            out.append(ids)
+        return {"input_ids": out}
+
+
+class SyntheticProcessor:
+    """The slice of the AutoProcessor surface SGRLVRTrainer uses on video rows with the GPU front end (TR:227-229, 576):
+    ``tokenizer``, ``batch_decode``, ``eos_token_id`` / ``pad_token_id``.  Decoded text is what a policy "says" for the reward
+    functions: ids map to a small closed vocabulary of words that the SpaceR reward functions parse (think / answer tags,
+    option letters, numbers), so ``accuracy_reward`` / ``format_reward`` do real work on every completion."""
+
+    WORDS = ["<think>", "</think>", "<answer>", "</answer>", "A", "B", "C", "D", "the", "chair", "is", "left", "of", "table",
+             "3.2", "meters", "about", "2", "objects", "behind", "sofa", "and", "door", "[", "]", ",", "1", "5", "so"]
+
+    def __init__(self, cfg: Qwen2VLConfig):
+        self.cfg = cfg
+        self.eos_token_id, self.pad_token_id = cfg.eos_token_id, cfg.pad_token_id
+        self.tokenizer = SyntheticTokenizer(cfg)
+
+    def batch_decode(self, ids, skip_special_tokens=True):
+        W, n = self.WORDS, len(self.WORDS)
+        out = []
+        for row in ids.tolist():
+            toks = [t for t in row if not (skip_special_tokens and t in (self.eos_token_id, self.pad_token_id))]
+            out.append(" ".join(W[t % n] for t in toks))
+        return out
+
+
+def synthetic_video_row(cfg: Qwen2VLConfig, prompt_idx: int, frames_u8: torch.Tensor, n_text: int, proc: SyntheticProcessor) -> dict:
+    """One SpaceR-151k-shaped dataset row (SG-RLVR.py:319-352) around pre-decoded frames: a multiple-choice question whose
+    rendered chat prompt tokenises to exactly ``n_text`` text tokens (template words included), so the trainer sees the
+    benchmark's prompt length.  ``source_fps`` 2.0 makes the frame sampler keep every frame (QU:145-182)."""
+    from .open_r1.trainer.SG_RLVR_trainer import qwen2vl_chat_template
+    g = torch.Generator().manual_seed(2000 + prompt_idx)
+
+    def row(n_words: int) -> dict:
+        words = [f"w{int(v)}" for v in torch.randint(0, 100000, (n_words,), generator=torch.Generator().manual_seed(2000 + prompt_idx))]
+        return dict(prompt=[{"role": "user", "content": [{"type": "video", "source_fps": 2.0}, {"type": "text", "text": " ".join(words)}]}],
+                    path=frames_u8, data_type="video", problem_type="multiple choice", solution="<answer>A</answer>",
+                    problem_id=prompt_idx, options=["A. left", "B. right", "C. behind", "D. front"], data_source="synthetic")
+    del g
+
+    def n_tokens(r: dict) -> int:            # text tokens of the rendered prompt: everything but the start / pad / end markers
+        return len(proc.tokenizer([qwen2vl_chat_template(r["prompt"])])["input_ids"][0]) - 3
+    n = max(0, n_text - n_tokens(row(0)))
+    r = row(n)
+    while n_tokens(r) != n_text:             # words glued to a template marker by the renderer shift the count by one or two
+        n += n_text - n_tokens(r)
+        r = row(n)
+    return r
