@@ -230,6 +230,9 @@ def main():
     ap.add_argument("--groups-per-pass", type=int, default=None,
                     help="prompt groups scored / back-propagated in one token-packed pass (default: 2 where 288 GB holds two groups' "
                          "activations -- cfg3 peaks at 254 GB -- else 1 = group by group as in round 1)")
+    ap.add_argument("--recompute", action="store_true",
+                    help="selective activation recompute in the policy backward (--gradient_checkpointing true of the shipped script): "
+                         "MLP intermediates and lm_head logits are recomputed, which makes room for more groups per pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--grad-comm", choices=("fp32", "bf16"), default="bf16",
@@ -289,7 +292,7 @@ def main():
     C = args.completion_len or C
     cfg = PRESETS[preset]
     hyper = GRPOHyper(num_generations=Kgen, temporal=False, len_control=True, total_steps=1000, grad_comm_bf16=args.grad_comm == "bf16",
-                      overlap_comm=not args.no_overlap)
+                      overlap_comm=not args.no_overlap, recompute=args.recompute)
     params = FlatParams.empty(cfg, dev)
     random_init_(params, seed=1234)
     ge = GRPOEngine(cfg, params, hyper, process_group=pg)
@@ -449,7 +452,7 @@ def main():
                                    f"(rollout+ref/policy scoring+backward+AdamW)",
                        "global_batch": groups * Kgen * world, "parallelism": f"dp{world}", "decode_graph": not args.no_graph,
                        "grad_comm": args.grad_comm, "overlap_comm": not args.no_overlap, "backend": args.backend, "groups_per_pass": max(1, min(gpp_default, groups)),
-                       "rccl_world": world,
+                       "rccl_world": world, "recompute": bool(args.recompute),
                        "devices": [torch.cuda.get_device_name(local)] if world == 1 else f"{world} x {torch.cuda.get_device_name(local)}"},
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": round(gemm["tflops"], 2),
                          "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gemm["tflops"] / MFMA_PEAK_TFLOPS, 4),

@@ -289,6 +289,17 @@ int spacer_logprob_fwd(const float* logits, long ld, const int64_t* targets, flo
 int spacer_logprob_bwd(const float* logits, long ld, const int64_t* targets, const float* lse, const float* g,
                        void* dlogits, long ldd, int rows, int vocab, spacer_stream_t stream);
 
+/* The same over VOCABULARY CHUNKS: the lm_head GEMM runs over row ranges [col0, col0 + cols) of lm_head and each
+ * chunk of fp32 logits [rows, cols] updates the running (max, sum-exp, target logit) of every row -- the [rows, vocab] logits of
+ * TR:357-366 are never materialised.  first != 0 initialises the running state.  spacer_lse_finish: logp = target - lse.
+ * spacer_logprob_bwd_chunk = spacer_logprob_bwd restricted to the chunk's columns (dlogits [rows, cols] bf16). */
+int spacer_lse_chunk(const float* logits, long ld, const int64_t* targets, int col0, int cols, float* m_run, float* s_run,
+                     float* t_run, int rows, int first, spacer_stream_t stream);
+int spacer_lse_finish(const float* m_run, const float* s_run, const float* t_run, float* logp, float* lse, int rows,
+                      spacer_stream_t stream);
+int spacer_logprob_bwd_chunk(const float* logits, long ld, const int64_t* targets, int col0, const float* lse, const float* g,
+                             void* dlogits, long ldd, int rows, int cols, spacer_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * GRPO loss (TR:551-552, 640-643, 682): per-token k3 KL, clipped-free ratio loss, masked row means.
  * logp/ref_logp fp32 [G, C], mask int32 [G, C], adv fp32 [G].  Writes loss[0], mean_kl[0] and

@@ -68,6 +68,9 @@ SIGNATURES = {
     "spacer_patchify": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "spacer_logprob_fwd": [_p, _l, _p, _p, _p, _i, _i, _p],
     "spacer_logprob_bwd": [_p, _l, _p, _p, _p, _p, _l, _i, _i, _p],
+    "spacer_lse_chunk": [_p, _l, _p, _i, _i, _p, _p, _p, _i, _i, _p],
+    "spacer_lse_finish": [_p, _p, _p, _p, _p, _i, _p],
+    "spacer_logprob_bwd_chunk": [_p, _l, _p, _i, _p, _p, _p, _l, _i, _i, _p],
     "spacer_grpo_loss": [_p, _p, _p, _p, _f, _p, _p, _p, _i, _i, _p],
     "spacer_completion_mask": [_p, _i, _p, _p, _i, _i, _p],
     "spacer_sample_top_p": [_p, _l, _i, _i, _i, _f, _f, _u64, _p, _i, _i, _i, _p, _p, _p, _p, _l, _p],

@@ -60,6 +60,74 @@ __global__ __launch_bounds__(NT) void logprob_bwd_kernel(const float* __restrict
     }
 }
 
+// ------------------------------------------------------------------ the same over VOCABULARY CHUNKS
+// The lm_head GEMM runs chunk by chunk over the vocabulary (rows of lm_head); a chunk's fp32 logits [rows, cols] update the running
+// (max, sum-exp, target logit) of every row and are then dead -- the [rows, vocab] logits tensor (2.5 GB per 7B prompt group, the
+// reference's is 4.6 GB bf16 over all positions, TR:357-366) never exists.  One workgroup per row, as logprob_fwd_kernel.
+__global__ __launch_bounds__(NT) void lse_chunk_kernel(const float* __restrict__ logits, long ld, const int64_t* __restrict__ tgt,
+                                                       int col0, int cols, float* __restrict__ m_run, float* __restrict__ s_run,
+                                                       float* __restrict__ t_run, int rows, int first) {
+    __shared__ float red[32];
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        const float* p = logits + (long)row * ld;
+        float m = -INFINITY, s = 0.f;
+        const int v4 = cols >> 2;
+        for (int i = threadIdx.x; i < v4; i += NT) {
+            const float4 x = *(const float4*)(p + i * 4);
+            const float mx = fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w));
+            if (mx > m) { s *= __expf(m - mx); m = mx; }
+            s += __expf(x.x - m) + __expf(x.y - m) + __expf(x.z - m) + __expf(x.w - m);
+        }
+        for (int i = v4 * 4 + threadIdx.x; i < cols; i += NT) {
+            const float x = p[i];
+            if (x > m) { s *= __expf(m - x); m = x; }
+            s += __expf(x - m);
+        }
+        const float M = block_max(m, red);
+        const float S = block_sum(m == -INFINITY ? 0.f : s * __expf(m - M), red);
+        if (threadIdx.x == 0) {
+            const float m0 = first ? -INFINITY : m_run[row], s0 = first ? 0.f : s_run[row];
+            const float mn = fmaxf(m0, M);
+            s_run[row] = (m0 == -INFINITY ? 0.f : s0 * __expf(m0 - mn)) + S * __expf(M - mn);
+            m_run[row] = mn;
+            const long t = tgt[row] - col0;
+            if (t >= 0 && t < cols) t_run[row] = p[t];
+        }
+    }
+}
+__global__ __launch_bounds__(NT) void lse_finish_kernel(const float* __restrict__ m_run, const float* __restrict__ s_run,
+                                                        const float* __restrict__ t_run, float* __restrict__ logp,
+                                                        float* __restrict__ lse_out, int rows) {
+    const int r = blockIdx.x * NT + threadIdx.x;
+    if (r < rows) {
+        const float lse = m_run[r] + logf(s_run[r]);
+        if (lse_out) lse_out[r] = lse;
+        logp[r] = t_run[r] - lse;
+    }
+}
+// logprob_bwd_kernel on the column chunk [col0, col0 + cols) of the vocabulary: dl [rows, cols] bf16
+__global__ __launch_bounds__(NT) void logprob_bwd_chunk_kernel(const float* __restrict__ logits, long ld,
+                                                               const int64_t* __restrict__ tgt, int col0, const float* __restrict__ lse,
+                                                               const float* __restrict__ g, bf16_t* __restrict__ dl, long ldd,
+                                                               int rows, int cols) {
+    const int v4 = cols >> 2;
+    for (int row = blockIdx.y; row < rows; row += gridDim.y) {
+        const float* p = logits + (long)row * ld;
+        bf16_t* o = dl + (long)row * ldd;
+        const float L = lse[row], gr = -g[row];
+        const long tl = tgt[row] - col0;
+        const int t = (tl >= 0 && tl < cols) ? (int)tl : -1;
+        for (int i = blockIdx.x * NT + threadIdx.x; i < v4; i += gridDim.x * NT) {
+            const float4 x = *(const float4*)(p + i * 4);
+            float d[4] = {__expf(x.x - L), __expf(x.y - L), __expf(x.z - L), __expf(x.w - L)};
+            if (t >= 0 && (t >> 2) == i) d[t & 3] -= 1.f;
+            *(uint2*)(o + i * 4) = make_uint2(pack_bf2(d[0] * gr, d[1] * gr), pack_bf2(d[2] * gr, d[3] * gr));
+        }
+        if (blockIdx.x == 0)
+            for (int i = v4 * 4 + threadIdx.x; i < cols; i += NT) o[i] = f2bf((__expf(p[i] - L) - (i == t ? 1.f : 0.f)) * gr);
+    }
+}
+
 // ------------------------------------------------------------------ first-EOS mask
 __global__ __launch_bounds__(NT) void completion_mask_kernel(const int64_t* __restrict__ ids, int eos, int* __restrict__ mask,
                                                              int* __restrict__ lengths, int G, int C) {
@@ -169,6 +237,32 @@ extern "C" int spacer_logprob_bwd(const float* logits, long ld, const int64_t* t
     const int gx = max(1, min(16, cdiv(vocab / 4, NT)));
     hipLaunchKernelGGL(logprob_bwd_kernel, dim3(gx, min(rows, 8192)), dim3(NT), 0, (hipStream_t)stream, logits, ld,
                        targets, lse, g, (bf16_t*)dlogits, ldd, rows, vocab);
+    SP_CHECK_LAUNCH();
+    return SPACER_OK;
+}
+extern "C" int spacer_lse_chunk(const float* logits, long ld, const int64_t* targets, int col0, int cols, float* m_run,
+                                float* s_run, float* t_run, int rows, int first, spacer_stream_t stream) {
+    SP_REQUIRE(ld % 4 == 0 && cols > 0, SPACER_EINVAL, "lse_chunk: ld must be a multiple of 4, cols > 0");
+    if (rows <= 0) return SPACER_OK;
+    hipLaunchKernelGGL(lse_chunk_kernel, dim3(min(rows, 4096)), dim3(NT), 0, (hipStream_t)stream, logits, ld, targets, col0, cols,
+                       m_run, s_run, t_run, rows, first);
+    SP_CHECK_LAUNCH();
+    return SPACER_OK;
+}
+extern "C" int spacer_lse_finish(const float* m_run, const float* s_run, const float* t_run, float* logp, float* lse, int rows,
+                                 spacer_stream_t stream) {
+    if (rows <= 0) return SPACER_OK;
+    hipLaunchKernelGGL(lse_finish_kernel, dim3(cdiv(rows, NT)), dim3(NT), 0, (hipStream_t)stream, m_run, s_run, t_run, logp, lse, rows);
+    SP_CHECK_LAUNCH();
+    return SPACER_OK;
+}
+extern "C" int spacer_logprob_bwd_chunk(const float* logits, long ld, const int64_t* targets, int col0, const float* lse,
+                                        const float* g, void* dlogits, long ldd, int rows, int cols, spacer_stream_t stream) {
+    SP_REQUIRE(ld % 4 == 0 && ldd % 4 == 0, SPACER_EINVAL, "logprob_bwd_chunk: ld must be a multiple of 4");
+    if (rows <= 0 || cols <= 0) return SPACER_OK;
+    const int gx = max(1, min(16, cdiv(cols / 4, NT)));
+    hipLaunchKernelGGL(logprob_bwd_chunk_kernel, dim3(gx, min(rows, 8192)), dim3(NT), 0, (hipStream_t)stream, logits, ld, targets,
+                       col0, lse, g, (bf16_t*)dlogits, ldd, rows, cols);
     SP_CHECK_LAUNCH();
     return SPACER_OK;
 }

@@ -42,6 +42,10 @@ class GRPOHyper:
     # (local_scripts/zero3.json:14-33 "bf16": {"enabled": "auto"}); fp32 values on the wire when False
     grad_comm_bf16: bool = True
     overlap_comm: bool = True         # zero3.json:26 "overlap_comm": true -- reduce layer ranges while the backward still runs
+    # --gradient_checkpointing true (run_SpaceR_SG_RLVR.sh:28): selective activation recompute in the policy's backward
+    # (Qwen2VLEngine.recompute: MLP intermediates + lm_head logits; bit-identical gradients, -20 GB of saved activations per 7B
+    # prompt group for one more gate|up and lm_head GEMM).  Off by default: 288 GB holds two groups per pass without it.
+    recompute: bool = False
 
 
 # ------------------------------------------------------------------------------------- reward shaping (host)
@@ -231,7 +235,7 @@ class GRPOEngine:
         self.policy = policy
         self.ref = ref if ref is not None else FlatParams(cfg, policy.flat.clone(), policy.specs)   # create_reference_model
         # W^T copies for the dX GEMMs are kept for the whole optimizer step (all prompt groups reuse them): +1x weights
-        self.engine = Qwen2VLEngine(cfg, self.policy, cache_wT=cache_wT)
+        self.engine = Qwen2VLEngine(cfg, self.policy, cache_wT=cache_wT, recompute=hyper.recompute)
         self.ref_engine = Qwen2VLEngine(cfg, self.ref)
         self.roll = RolloutEngine(self.engine)
         self.master = FlatParams(cfg, policy.flat.float(), policy.specs)

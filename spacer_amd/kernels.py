@@ -621,6 +621,30 @@ def logprob_bwd(logits32, targets, lse, g, *, out=None):
     return out
 
 
+def lse_chunk_(logits32, targets, col0, state, first):
+    """Running (max, sum-exp, target logit) of every row (state fp32 [3, rows]) updated with the vocabulary chunk
+    [col0, col0 + cols) whose fp32 logits are ``logits32`` [rows, cols] (a view with any row stride)."""
+    rows, cols = logits32.shape
+    check(_lib.load().spacer_lse_chunk(_ptr(logits32), _rowmajor(logits32), _ptr(targets), col0, cols, _ptr(state[0]), _ptr(state[1]),
+                                       _ptr(state[2]), rows, int(first), _stream()), "lse_chunk")
+
+
+def lse_finish(state):
+    rows = state.shape[1]
+    logp = torch.empty(rows, device=state.device, dtype=torch.float32)
+    lse = torch.empty(rows, device=state.device, dtype=torch.float32)
+    check(_lib.load().spacer_lse_finish(_ptr(state[0]), _ptr(state[1]), _ptr(state[2]), _ptr(logp), _ptr(lse), rows, _stream()),
+          "lse_finish")
+    return logp, lse
+
+
+def logprob_bwd_chunk(logits32, targets, col0, lse, g, out):
+    rows, cols = logits32.shape
+    check(_lib.load().spacer_logprob_bwd_chunk(_ptr(logits32), _rowmajor(logits32), _ptr(targets), col0, _ptr(lse), _ptr(g), _ptr(out),
+                                               _rowmajor(out), rows, cols, _stream()), "logprob_bwd_chunk")
+    return out
+
+
 def grpo_loss(logp, ref_logp, adv, mask, beta):
     G, Cc = logp.shape
     dev = logp.device

@@ -1,7 +1,8 @@
 """Flag surface of the launch script (run_SpaceR_SG_RLVR.sh:15-39): the three dataclasses the reference parses with
 ``TrlParser((GRPOScriptArguments, GRPOConfig, ModelConfig))`` (SG-RLVR.py:389-392), restated without trl / HF Trainer.
 Every flag of the shipped script is accepted; the ones that configure machinery this engine does not have
-(--deepspeed, --attn_implementation, --gradient_checkpointing, --report_to) are accepted and ignored with a log line.
+(--deepspeed, --attn_implementation, --report_to) are accepted and ignored with a log line; --gradient_checkpointing selects
+the engine's selective activation recompute.
 """
 from __future__ import annotations
 
@@ -58,7 +59,7 @@ class GRPOConfig:                              # the trl.GRPOConfig / TrainingAr
     save_steps: int = 1000
     save_only_model: bool = True
     bf16: bool = True
-    gradient_checkpointing: bool = True
+    gradient_checkpointing: bool = False       # HF TrainingArguments default; the shipped script passes true (SC:28) -> GRPOHyper.recompute
     seed: int = 42
     data_seed: Optional[int] = None
     resume_from_checkpoint: Optional[str] = None

@@ -206,7 +206,10 @@ class SGRLVRTrainer:
                           weight_decay=args.weight_decay, adam_beta1=args.adam_beta1, adam_beta2=args.adam_beta2,
                           adam_eps=args.adam_epsilon, max_grad_norm=args.max_grad_norm, temporal=self.temporal,
                           len_control=self.len_control, lr_scheduler_type=args.lr_scheduler_type, total_steps=total_steps,
-                          warmup_steps=args.warmup_steps)
+                          warmup_steps=args.warmup_steps, recompute=bool(getattr(args, "gradient_checkpointing", False)))
+        if hyper.recompute:
+            self._note("--gradient_checkpointing true: selective activation recompute (MLP intermediates + lm_head logits are "
+                       "recomputed in the backward; gradients are bit-identical to the stored path)")
         self.total_steps = total_steps
         # ``engine``: an existing GRPOEngine over ``model`` (bench.py times the trainer on the engine it already holds: a second
         # copy of master weights + Adam state would not fit)

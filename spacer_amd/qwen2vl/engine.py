@@ -24,10 +24,18 @@ BF16, F32 = torch.bfloat16, torch.float32
 
 
 class Qwen2VLEngine:
-    def __init__(self, cfg: Qwen2VLConfig, params: FlatParams, cache_wT: bool = False):
+    HEAD_CHUNK = 8192      # vocabulary rows of lm_head per head chunk (fp32 chunk logits: 268 MB at 8192 completion rows)
+
+    def __init__(self, cfg: Qwen2VLConfig, params: FlatParams, cache_wT: bool = False, recompute: bool = False):
         self.cfg = cfg
         self.W = params
         self.dev = params.flat.device
+        # activation recompute (the reference trains with --gradient_checkpointing true, run_SpaceR_SG_RLVR.sh:28; here a
+        # SELECTIVE policy): the MLP's wide intermediates (gate|up, act: 2/3 of a decoder layer's saved bytes; fc1 / act of the
+        # vision blocks) and the lm_head logits are not kept for the backward pass but recomputed from the saved GEMM input
+        # by the SAME kernel launch as in the forward -- bit-identical gradients (tests/test_recompute_gpu.py), one more
+        # gate|up GEMM per layer and one more lm_head GEMM.  17.5 + 2.5 of the 27 + 2.5 GB per 5.5k-token 7B group.
+        self.recompute = recompute
         self.cache_wT = cache_wT          # kept for callers; unused since the backward GEMMs read W / dY / X in place
         self._wT: Dict[str, torch.Tensor] = {}
 
@@ -80,8 +88,9 @@ class Qwen2VLEngine:
             a = K.act_fwd(f1, K.SPACER_ACT_QUICK_GELU)
             x_out = K.gemm_nt(a, W[p + "fc2_w"], bias=W[p + "fc2_b"], residual=x_mid, out_dtype=F32)
             if tape is not None:
+                keep = not self.recompute
                 blocks.append(dict(x_in=x, mean1=mean1, rstd1=rstd1, h=h, qkv=qkv, o=o, lse=lse, x_mid=x_mid, mean2=mean2,
-                                   rstd2=rstd2, h2=h2, f1=f1, a=a))
+                                   rstd2=rstd2, h2=h2, f1=f1 if keep else None, a=a if keep else None))
             x = x_out
         mean, rstd = self._empty(Np), self._empty(Np)
         hm = K.layernorm_fwd(x, W["merger.ln_w"], W["merger.ln_b"], 1e-6, mean=mean, rstd=rstd)
@@ -119,6 +128,9 @@ class Qwen2VLEngine:
         for i in reversed(range(cfg.vit_depth)):
             p = f"vit.{i}."
             t = tape["blocks"][i]
+            if t["a"] is None:                                           # recompute policy: the forward's own two launches
+                t["f1"] = K.gemm_nt(t["h2"], W[p + "fc1_w"], bias=W[p + "fc1_b"])
+                t["a"] = K.act_fwd(t["f1"], K.SPACER_ACT_QUICK_GELU)
             dyb = K.cast_bf16(dx)
             d_a = self._dx(dyb, p + "fc2_w")
             self._dw(G[p + "fc2_w"], dyb, t["a"]); K.bias_grad_(dyb, G[p + "fc2_b"])
@@ -176,11 +188,12 @@ class Qwen2VLEngine:
             rstd2 = self._empty(Np)
             h2 = K.rmsnorm_fwd(x_mid, W[p + "n2_w"], 1e-6, rstd=rstd2)
             # [gate (Ip) | up (Ip)], padding columns are 0; SwiGLU in the GEMM epilogue, gate|up kept only for a backward pass
-            a, gu = K.gemm_swiglu(h2, W[p + "gu_w"], bias=W[p + "gu_b"], keep_gu=tape is not None)
+            keep = tape is not None and not self.recompute
+            a, gu = K.gemm_swiglu(h2, W[p + "gu_w"], bias=W[p + "gu_b"], keep_gu=keep)
             x_out = K.gemm_nt(a, W[p + "down_w"], bias=W[p + "down_b"], residual=x_mid, out_dtype=F32)
             if tape is not None:
-                blocks.append(dict(x_in=x, rstd1=rstd1, h=h, qkv=qkv, o=o, lse=lse, x_mid=x_mid, rstd2=rstd2, h2=h2, gu=gu, a=a,
-                                   segs=segs, max_q=max_q))
+                blocks.append(dict(x_in=x, rstd1=rstd1, h=h, qkv=qkv, o=o, lse=lse, x_mid=x_mid, rstd2=rstd2, h2=h2, gu=gu,
+                                   a=a if keep else None, segs=segs, max_q=max_q))
             x = x_out
         rstd = self._empty(Np)
         hm = K.rmsnorm_fwd(x, W["merger.ln_w"], 1e-6, rstd=rstd)
@@ -214,6 +227,8 @@ class Qwen2VLEngine:
         for i in reversed(range(cfg.vit_depth)):
             p = f"vit.{i}."
             t = tape["blocks"][i]
+            if t["a"] is None:                                           # recompute policy
+                t["a"], t["gu"] = K.gemm_swiglu(t["h2"], W[p + "gu_w"], bias=W[p + "gu_b"], keep_gu=True)
             dyb = K.cast_bf16(dx)
             d_a = self._dx(dyb, p + "down_w")
             self._dw(G[p + "down_w"], dyb, t["a"]); K.bias_grad_(dyb, G[p + "down_b"])
@@ -260,10 +275,12 @@ class Qwen2VLEngine:
             x_mid = K.gemm_nt(o, W[p + "o_w"], residual=x, out_dtype=F32)
             rstd2 = self._empty(T)
             h2 = K.rmsnorm_fwd(x_mid, W[p + "ln2_w"], cfg.rms_eps, rstd=rstd2)
-            a, gu = K.gemm_swiglu(h2, W[p + "gu_w"], keep_gu=tape is not None)       # SwiGLU in the gate|up GEMM's epilogue
+            keep = tape is not None and not self.recompute
+            a, gu = K.gemm_swiglu(h2, W[p + "gu_w"], keep_gu=keep)                   # SwiGLU in the gate|up GEMM's epilogue
             x_out = K.gemm_nt(a, W[p + "down_w"], residual=x_mid, out_dtype=F32)
             if tape is not None:
-                tape.append(dict(x_in=x, rstd1=rstd1, h=h, qkv=qkv, o=o, lse=lse, x_mid=x_mid, rstd2=rstd2, h2=h2, gu=gu, a=a))
+                tape.append(dict(x_in=x, rstd1=rstd1, h=h, qkv=qkv, o=o, lse=lse, x_mid=x_mid, rstd2=rstd2, h2=h2, gu=gu,
+                                 a=a if keep else None))
             x = x_out
         return x
 
@@ -278,6 +295,8 @@ class Qwen2VLEngine:
         for i in reversed(range(cfg.layers)):
             p = f"llm.{i}."
             t = tape[i]
+            if t["a"] is None:              # recompute policy: gate|up + SwiGLU again from the saved h2, same launch, same bits
+                t["a"], t["gu"] = K.gemm_swiglu(t["h2"], W[p + "gu_w"], keep_gu=True)
             dyb = K.cast_bf16(dx)
             d_a = self._dx(dyb, p + "down_w")
             self._dw(G[p + "down_w"], dyb, t["a"])
@@ -473,8 +492,22 @@ class Qwen2VLEngine:
         rstd_f = self._empty(x.shape[0])
         hn = K.rmsnorm_fwd(x, self.W["llm.norm_w"], cfg.rms_eps, rstd=rstd_f)
         hsel = K.gather_rows(hn, sel)
-        logits = K.gemm_nt(hsel, self.W["llm.lm_head"], out_dtype=F32)
-        logp, lse = K.logprob_fwd(logits, targets)
+        del hn
+        # lm_head over vocabulary chunks with an online log-sum-exp: a chunk's fp32 logits update the running
+        # (max, sum-exp, target logit) of every row and are dead afterwards.  Only a taped pass WITHOUT the recompute policy keeps
+        # them (column slices of one [rows, vocab] buffer) for the backward.
+        Wlm = self.W["llm.lm_head"]
+        rows, V, ch = hsel.shape[0], Wlm.shape[0], self.HEAD_CHUNK
+        store = tape is not None and not self.recompute
+        logits = self._empty(rows, V) if store else None
+        buf = None if store else self._empty(rows, min(ch, V))
+        state = self._empty(3, rows)
+        for c0 in range(0, V, ch):
+            c1 = min(V, c0 + ch)
+            lg = logits[:, c0:c1] if store else buf[:, :c1 - c0]
+            K.gemm_nt(hsel, Wlm[c0:c1], out=lg, out_dtype=F32)
+            K.lse_chunk_(lg, targets, c0, state, first=c0 == 0)
+        logp, lse = K.lse_finish(state)
         if tape is not None:
             tape.update(sel=sel, x_final=x, rstd_f=rstd_f, hsel=hsel, logits=logits, targets=targets, lse=lse)
         return logp
@@ -484,11 +517,28 @@ class Qwen2VLEngine:
         gradients accumulate into G."""
         cfg, W = self.cfg, self.W
         T, H = tape["x_final"].shape[0], cfg.hidden
-        dlogits = K.logprob_bwd(tape["logits"], tape["targets"], tape["lse"], dlogp.reshape(-1).contiguous())
+        # chunk by chunk over the vocabulary (SURVEY K18): dlogits of a chunk (from the stored chunk logits, or from logits
+        # recomputed by the forward's own GEMM launch under the recompute policy) feed that chunk's dX / dW GEMMs and are dead;
+        # neither [rows, vocab] tensor exists.  dX accumulates over chunks in fp32.
+        Wlm, Glm = W["llm.lm_head"], G["llm.lm_head"]
+        hsel, targets, lse, logits = tape["hsel"], tape["targets"], tape["lse"], tape["logits"]
+        rows, V, ch = hsel.shape[0], Wlm.shape[0], self.HEAD_CHUNK
+        g = dlogp.reshape(-1).contiguous()
+        buf = None if logits is not None else self._empty(rows, min(ch, V))
+        dl_buf = self._empty(rows, min(ch, V), dtype=BF16)
+        d_hsel32 = self._empty(rows, H)
+        for c0 in range(0, V, ch):
+            c1 = min(V, c0 + ch)
+            if logits is not None:
+                lg = logits[:, c0:c1]
+            else:
+                lg = K.gemm_nt(hsel, Wlm[c0:c1], out=buf[:, :c1 - c0], out_dtype=F32)
+            dl = K.logprob_bwd_chunk(lg, targets, c0, lse, g, dl_buf[:, :c1 - c0])
+            K.gemm(dl, Wlm[c0:c1], trans_b=True, out=d_hsel32, residual=d_hsel32 if c0 else None, out_dtype=F32)
+            self._dw(Glm[c0:c1], dl, hsel)
         tape["logits"] = None
-        d_hsel = self._dx(dlogits, "llm.lm_head")
-        self._dw(G["llm.lm_head"], dlogits, tape["hsel"])
-        del dlogits
+        d_hsel = K.cast_bf16(d_hsel32)
+        del d_hsel32, dl_buf, buf
         d_hn32 = self._zeros(T, H)
         K.scatter_add_rows_(d_hsel, tape["sel"], d_hn32)
         d_hn = K.cast_bf16(d_hn32)
