@@ -322,6 +322,15 @@ int spacer_sample_top_p(const float* logits, long ld, int B, int vocab, int top_
                         int64_t* out_ids, float* out_logp, void* workspace, long workspace_bytes,
                         spacer_stream_t stream);
 long spacer_sample_workspace_bytes(int B, int vocab);
+/* Decode-loop form: the Philox step is *step_dev + step_bias, and the token is also written to out_matrix[b * out_ld + step]
+ * (the [B, C] completion matrix HF generate returns, TR:463) -- no per-step copy on the host side.  spacer_decode_embed is the
+ * step's first launch: token-embedding gather of the previous step's tokens (fp32 rows) + advance of the device-side step
+ * counters (*counter0 += 1, *counter1 += 1 when non-NULL), so a whole decode step is library launches only. */
+int spacer_sample_top_p_step(const float* logits, long ld, int B, int vocab, int top_k, float top_p, float temperature, uint64_t seed,
+                             const int* step_dev, int step_bias, int eos_id, int pad_id, int suppress_eos, int* finished,
+                             int64_t* out_ids, int64_t* out_matrix, long out_ld, spacer_stream_t stream);
+int spacer_decode_embed(const int64_t* ids, const void* table, float* out, int B, int H, int* counter0, int* counter1,
+                        spacer_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimizer: global grad-norm (sum of squares into acc[0]) and fused AdamW on fp32 master weights with

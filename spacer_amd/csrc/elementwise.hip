@@ -194,7 +194,10 @@ __global__ __launch_bounds__(NT) void f32_to_bf16_strided_kernel(const float* __
 // ------------------------------------------------------------------ embedding gather / scatter
 __global__ __launch_bounds__(NT) void embed_fwd_kernel(const int64_t* __restrict__ ids, const bf16_t* __restrict__ table,
                                                        const bf16_t* __restrict__ video, const int* __restrict__ vrow,
-                                                       float* __restrict__ out, int T, int H) {
+                                                       float* __restrict__ out, int T, int H, int* __restrict__ inc0 = nullptr,
+                                                       int* __restrict__ inc1 = nullptr) {
+    // decode loop: the step's first kernel advances the device-side step counters (nobody reads them during this kernel)
+    if (inc0 && blockIdx.x == 0 && threadIdx.x == 0) { *inc0 += 1; if (inc1) *inc1 += 1; }
     const int per = H >> 3;
     const long total = (long)T * per;
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
@@ -410,7 +413,16 @@ extern "C" int spacer_embed_fwd(const int64_t* ids, const void* table, const voi
     SP_REQUIRE(H % 8 == 0, SPACER_EINVAL, "embed: H must be a multiple of 8");
     if (T <= 0) return SPACER_OK;
     hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid_for((long)T * H / 8)), dim3(NT), 0, (hipStream_t)stream, ids,
-                       (const bf16_t*)table, (const bf16_t*)video, video_row_of_token, out, T, H);
+                       (const bf16_t*)table, (const bf16_t*)video, video_row_of_token, out, T, H, (int*)nullptr, (int*)nullptr);
+    SP_CHECK_LAUNCH();
+    return SPACER_OK;
+}
+extern "C" int spacer_decode_embed(const int64_t* ids, const void* table, float* out, int B, int H, int* counter0, int* counter1,
+                                   spacer_stream_t stream) {
+    SP_REQUIRE(H % 8 == 0 && counter0, SPACER_EINVAL, "decode_embed: H must be a multiple of 8, counter0 non-null");
+    if (B <= 0) return SPACER_OK;
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid_for((long)B * H / 8)), dim3(NT), 0, (hipStream_t)stream, ids,
+                       (const bf16_t*)table, (const bf16_t*)nullptr, (const int*)nullptr, out, B, H, counter0, counter1);
     SP_CHECK_LAUNCH();
     return SPACER_OK;
 }

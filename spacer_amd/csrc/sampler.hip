@@ -50,7 +50,8 @@ __global__ __launch_bounds__(SNT) void sample_kernel(const float* __restrict__ l
                                                      float top_p, float inv_temp, uint64_t seed,
                                                      const int* __restrict__ step_dev, int eos, int pad, int suppress_eos,
                                                      int* __restrict__ finished, int64_t* __restrict__ out_ids,
-                                                     float* __restrict__ out_logp) {
+                                                     float* __restrict__ out_logp, int step_bias, int64_t* __restrict__ out_mat,
+                                                     long out_ld) {
     __shared__ int hist[256];
     __shared__ int sel_bin, sel_k, ncand;
     __shared__ float cval[CAP];
@@ -59,7 +60,11 @@ __global__ __launch_bounds__(SNT) void sample_kernel(const float* __restrict__ l
     __shared__ float red[32];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     if (finished && finished[b]) {
-        if (tid == 0) { out_ids[b] = pad; if (out_logp) out_logp[b] = 0.f; }
+        if (tid == 0) {
+            out_ids[b] = pad;
+            if (out_logp) out_logp[b] = 0.f;
+            if (out_mat) out_mat[(long)b * out_ld + (*step_dev + step_bias)] = pad;
+        }
         return;
     }
     const float* row = logits + (long)b * ld;
@@ -208,7 +213,8 @@ __global__ __launch_bounds__(SNT) void sample_kernel(const float* __restrict__ l
     const float exk = block_excl_scan(pk, wsum, Zk);
 
     // ---- 4. draw
-    const float u = philox_uniform(seed, (uint32_t)*step_dev, (uint32_t)b) * Zk;
+    const int step_now = *step_dev + step_bias;
+    const float u = philox_uniform(seed, (uint32_t)step_now, (uint32_t)b) * Zk;
     __shared__ int chosen;
     if (tid == 0) chosen = -1;
     __syncthreads();
@@ -234,6 +240,7 @@ __global__ __launch_bounds__(SNT) void sample_kernel(const float* __restrict__ l
     }
     if (tid == 0) {
         out_ids[b] = tok;
+        if (out_mat) out_mat[(long)b * out_ld + step_now] = tok;      // column = decode step: no per-step copy kernel on the host side
         if (finished && tok == eos) finished[b] = 1;
     }
 }
@@ -242,18 +249,33 @@ __global__ __launch_bounds__(SNT) void sample_kernel(const float* __restrict__ l
 
 extern "C" long spacer_sample_workspace_bytes(int B, int vocab) { (void)B; (void)vocab; return 0; }
 
-extern "C" int spacer_sample_top_p(const float* logits, long ld, int B, int vocab, int top_k, float top_p,
-                                   float temperature, uint64_t seed, const int* step_dev, int eos_id, int pad_id,
-                                   int suppress_eos, int* finished, int64_t* out_ids, float* out_logp, void* workspace,
-                                   long workspace_bytes, spacer_stream_t stream) {
-    (void)workspace; (void)workspace_bytes;
+static int sample_launch(const float* logits, long ld, int B, int vocab, int top_k, float top_p, float temperature, uint64_t seed,
+                         const int* step_dev, int step_bias, int eos_id, int pad_id, int suppress_eos, int* finished, int64_t* out_ids,
+                         float* out_logp, int64_t* out_mat, long out_ld, spacer_stream_t stream) {
     SP_REQUIRE(top_k >= 1 && top_k <= CAP, SPACER_EINVAL,
                "sample_top_p: top_k=%d must be in 1..%d (full-vocabulary nucleus, top_k=0, is not implemented yet)", top_k, CAP);
     SP_REQUIRE(top_p > 0.f && top_p <= 1.f && temperature > 0.f, SPACER_EINVAL, "sample_top_p: bad top_p/temperature");
     SP_REQUIRE(vocab >= top_k, SPACER_EINVAL, "sample_top_p: vocab < top_k");
     if (B <= 0) return SPACER_OK;
     hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(SNT), 0, (hipStream_t)stream, logits, ld, vocab, top_k, top_p,
-                       1.f / temperature, seed, step_dev, eos_id, pad_id, suppress_eos, finished, out_ids, out_logp);
+                       1.f / temperature, seed, step_dev, eos_id, pad_id, suppress_eos, finished, out_ids, out_logp, step_bias, out_mat,
+                       out_ld);
     SP_CHECK_LAUNCH();
     return SPACER_OK;
+}
+
+extern "C" int spacer_sample_top_p(const float* logits, long ld, int B, int vocab, int top_k, float top_p,
+                                   float temperature, uint64_t seed, const int* step_dev, int eos_id, int pad_id,
+                                   int suppress_eos, int* finished, int64_t* out_ids, float* out_logp, void* workspace,
+                                   long workspace_bytes, spacer_stream_t stream) {
+    (void)workspace; (void)workspace_bytes;
+    return sample_launch(logits, ld, B, vocab, top_k, top_p, temperature, seed, step_dev, 0, eos_id, pad_id, suppress_eos, finished,
+                         out_ids, out_logp, nullptr, 0, stream);
+}
+
+extern "C" int spacer_sample_top_p_step(const float* logits, long ld, int B, int vocab, int top_k, float top_p, float temperature,
+                                        uint64_t seed, const int* step_dev, int step_bias, int eos_id, int pad_id, int suppress_eos,
+                                        int* finished, int64_t* out_ids, int64_t* out_matrix, long out_ld, spacer_stream_t stream) {
+    return sample_launch(logits, ld, B, vocab, top_k, top_p, temperature, seed, step_dev, step_bias, eos_id, pad_id, suppress_eos,
+                         finished, out_ids, nullptr, out_matrix, out_ld, stream);
 }

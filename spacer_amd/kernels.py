@@ -676,6 +676,25 @@ def sample_top_p(logits32, step_dev, *, top_k=50, top_p=0.95, temperature=1.0, s
     return out_ids
 
 
+def sample_top_p_step(logits32, step_dev, step_bias, out_matrix, *, top_k=50, top_p=0.95, temperature=1.0, seed=0, eos_id=-1, pad_id=0,
+                      suppress_eos=False, finished=None, out_ids=None):
+    """sample_top_p for the decode loop: Philox step = *step_dev + step_bias; the token also lands in out_matrix[:, step]."""
+    B, vocab = logits32.shape
+    assert out_matrix.dtype == torch.int64 and out_matrix.stride(1) == 1
+    check(_lib.load().spacer_sample_top_p_step(_ptr(logits32), _rowmajor(logits32), B, vocab, top_k, top_p, temperature, seed,
+                                               _ptr(step_dev), step_bias, eos_id, pad_id, int(suppress_eos), _ptr(finished),
+                                               _ptr(out_ids), _ptr(out_matrix), out_matrix.stride(0), _stream()), "sample_top_p_step")
+    return out_ids
+
+
+def decode_embed(ids, table, out, counter0, counter1=None):
+    """First launch of a decode step: out[b] = table[ids[b]] (fp32) and *counter0 += 1 (*counter1 += 1)."""
+    B, H = ids.shape[0], table.shape[1]
+    check(_lib.load().spacer_decode_embed(_ptr(ids), _ptr(table), _ptr(out), B, H, _ptr(counter0), _ptr(counter1), _stream()),
+          "decode_embed")
+    return out
+
+
 def decode_rope_table(pos_base, step_dev, theta, cos, sin):
     B, D = cos.shape
     check(_lib.load().spacer_decode_rope_table(_ptr(pos_base), _ptr(step_dev), theta, _ptr(cos), _ptr(sin), B, D, _stream()),

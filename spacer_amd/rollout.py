@@ -130,7 +130,9 @@ class RolloutEngine:
         cfg, W, PW = self.cfg, self.e.W, st["packed"]
         Hq, Hkv, D, I = cfg.heads, cfg.kv_heads, cfg.head_dim, cfg.intermediate
         B = st["B"]
-        x = K.embed_fwd(st["cur_tok"], W["llm.embed"], None, None, out=st["x"])
+        # the step's first launch also advances the device-side counters (they hold "completed steps - 1" between steps): the
+        # whole step is library launches, no torch element-wise kernels
+        x = K.decode_embed(st["cur_tok"], W["llm.embed"], st["x"], st["step"], st["tail_len"])
         K.decode_rope_table(st["pos_base"], st["step"], cfg.rope_theta, st["cos"], st["sin"])
         scale = D ** -0.5
         for i in range(cfg.layers):
@@ -163,11 +165,10 @@ class RolloutEngine:
         else:
             st["logits"].zero_()
             K.gemm_skinny_packed_acc(hn, PW["llm.lm_head"], st["logits"], cfg.vocab)
-        st["step"].add_(1)
-        st["tail_len"].add_(1)
-        K.sample_top_p(st["logits"], st["step"], top_k=sp.top_k, top_p=sp.top_p, temperature=sp.temperature, seed=sp.seed,
-                       eos_id=cfg.eos_token_id, pad_id=cfg.pad_token_id, suppress_eos=sp.suppress_eos,
-                       finished=st["finished"], out_ids=st["cur_tok"])
+        # Philox step / output column = counter + 1 = index of the token being drawn
+        K.sample_top_p_step(st["logits"], st["step"], 1, st["out"], top_k=sp.top_k, top_p=sp.top_p, temperature=sp.temperature, seed=sp.seed,
+                            eos_id=cfg.eos_token_id, pad_id=cfg.pad_token_id, suppress_eos=sp.suppress_eos,
+                            finished=st["finished"], out_ids=st["cur_tok"])
 
     # ------------------------------------------------------------------ public
     @torch.no_grad()
@@ -199,7 +200,7 @@ class RolloutEngine:
             prompt_of=torch.arange(B, dtype=torch.int32, device=dev) // Kn,
             pos_base=torch.tensor(pos_base, dtype=torch.int32, device=dev).repeat_interleave(Kn).contiguous(),
             tk=torch.zeros(L, B, C, Hkv, D, device=dev, dtype=BF16), tv=torch.zeros(L, B, C, Hkv, D, device=dev, dtype=BF16),
-            tail_len=torch.zeros(1, dtype=torch.int32, device=dev), step=torch.zeros(1, dtype=torch.int32, device=dev),
+            tail_len=torch.full((1,), -1, dtype=torch.int32, device=dev), step=torch.full((1,), -1, dtype=torch.int32, device=dev),
             finished=torch.zeros(B, dtype=torch.int32, device=dev), cur_tok=torch.empty(B, dtype=torch.int64, device=dev),
             x=torch.empty(B, H, device=dev, dtype=F32), h=torch.empty(B, H, device=dev, dtype=BF16),
             q=torch.empty(B, cfg.heads * D, device=dev, dtype=BF16), o=torch.empty(B, cfg.heads * D, device=dev, dtype=BF16),
@@ -209,13 +210,12 @@ class RolloutEngine:
             cos=torch.empty(B, D, device=dev, dtype=F32), sin=torch.empty(B, D, device=dev, dtype=F32),
             logits=torch.empty(B, cfg.vocab, device=dev, dtype=F32),
         )
-        out = torch.full((B, C), cfg.pad_token_id, dtype=torch.int64, device=dev)
+        out = st["out"] = torch.full((B, C), cfg.pad_token_id, dtype=torch.int64, device=dev)
         # token 0 of every rollout comes from the prompt's last-position logits (K independent draws per prompt)
         st["logits"].copy_(first_logits.repeat_interleave(Kn, 0))
-        K.sample_top_p(st["logits"], st["step"], top_k=sp.top_k, top_p=sp.top_p, temperature=sp.temperature, seed=sp.seed,
-                       eos_id=cfg.eos_token_id, pad_id=cfg.pad_token_id, suppress_eos=sp.suppress_eos,
-                       finished=st["finished"], out_ids=st["cur_tok"])
-        out[:, 0].copy_(st["cur_tok"])
+        K.sample_top_p_step(st["logits"], st["step"], 1, out, top_k=sp.top_k, top_p=sp.top_p, temperature=sp.temperature, seed=sp.seed,
+                            eos_id=cfg.eos_token_id, pad_id=cfg.pad_token_id, suppress_eos=sp.suppress_eos,
+                            finished=st["finished"], out_ids=st["cur_tok"])
         graph = None
         n_steps = 0
         for s in range(1, C):
@@ -230,7 +230,6 @@ class RolloutEngine:
                 graph.replay()
             else:
                 self._decode_step(st, sp)
-            out[:, s].copy_(st["cur_tok"])
             n_steps += 1
             if not sp.suppress_eos and s % 32 == 0 and bool(st["finished"].all()):
                 break
