@@ -412,6 +412,16 @@ def main():
             except Exception as exc:
                 variants["through_trainer"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
                 torch.cuda.empty_cache()
+            try:      # the decode loop at the reference's own launch shape (cfg4: ONE prompt group per GPU, 8 rows): 80 % of that step
+                rs = {}
+                one = [make_prompt(cfg, rank * groups, F, Hpx, Wpx, n_text, dev, frames_u8=frames[0])[0]]
+                ge.roll.generate(one, Kgen, sp, use_graph=not args.no_graph, stats=rs)
+                torch.cuda.synchronize()
+                dec8 = sum(b.elapsed_time(c) for _, b, c in rs["events"]) * 1e-3
+                variants["decode_cfg4_rows"] = {"rows": Kgen, "ms_per_token_step": round(1e3 * dec8 / max(1, rs["decode_steps"]), 3),
+                                                "weight_stream_tbps": round(DECODE_WEIGHT_GB.get(preset, 0.0) * rs["decode_steps"] / dec8 / 1e3, 3)}
+            except Exception as exc:
+                variants["decode_cfg4_rows"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
             try:
                 variants["precise_scoring"] = precise_scoring(ge, cfg, frames, dev, F=F, Hpx=Hpx, Wpx=Wpx, n_text=n_text, Kgen=Kgen, C=C,
                                                               gpp=max(1, min(gpp_default, groups)))
