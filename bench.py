@@ -237,6 +237,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--grad-comm", choices=("fp32", "bf16"), default="bf16",
                     help="wire format of the gradient all-reduce (N > 1): bf16 as the reference's DeepSpeed bf16 mode sends them, or fp32")
+    ap.add_argument("--grad-algo", choices=("allreduce", "rs_ag"), default="allreduce",
+                    help="N > 1: bucketed all-reduce overlapped with the last backward + replicated AdamW (default), or reduce-scatter + "
+                         "AdamW on the rank's 1/N shard + all-gather of the bf16 weights (SURVEY section 5)")
     ap.add_argument("--no-overlap", action="store_true", help="exchange gradients after the last backward instead of during it")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="gloo: every rank on cuda:0, gradients staged through the host -- exercises the multi-rank control flow on a "
@@ -292,7 +295,7 @@ def main():
     C = args.completion_len or C
     cfg = PRESETS[preset]
     hyper = GRPOHyper(num_generations=Kgen, temporal=False, len_control=True, total_steps=1000, grad_comm_bf16=args.grad_comm == "bf16",
-                      overlap_comm=not args.no_overlap, recompute=args.recompute)
+                      overlap_comm=not args.no_overlap, recompute=args.recompute, grad_algo=args.grad_algo)
     params = FlatParams.empty(cfg, dev)
     random_init_(params, seed=1234)
     ge = GRPOEngine(cfg, params, hyper, process_group=pg)
@@ -461,7 +464,7 @@ def main():
                                    f"K={Kgen}, C={C} (EOS suppressed), {groups} prompt groups/GPU, full step "
                                    f"(rollout+ref/policy scoring+backward+AdamW)",
                        "global_batch": groups * Kgen * world, "parallelism": f"dp{world}", "decode_graph": not args.no_graph,
-                       "grad_comm": args.grad_comm, "overlap_comm": not args.no_overlap, "backend": args.backend, "groups_per_pass": max(1, min(gpp_default, groups)),
+                       "grad_comm": args.grad_comm, "grad_algo": args.grad_algo, "overlap_comm": not args.no_overlap, "backend": args.backend, "groups_per_pass": max(1, min(gpp_default, groups)),
                        "rccl_world": world, "recompute": bool(args.recompute),
                        "devices": [torch.cuda.get_device_name(local)] if world == 1 else f"{world} x {torch.cuda.get_device_name(local)}"},
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": round(gemm["tflops"], 2),

@@ -46,6 +46,12 @@ class GRPOHyper:
     # (Qwen2VLEngine.recompute: MLP intermediates + lm_head logits; bit-identical gradients, -20 GB of saved activations per 7B
     # prompt group for one more gate|up and lm_head GEMM).  Off by default: 288 GB holds two groups per pass without it.
     recompute: bool = False
+    # data-parallel gradient exchange: "allreduce" = bucketed all-reduce of the flat gradient, overlapped with the last backward, then
+    # the SAME AdamW on every replica; "rs_ag" = reduce-scatter of the gradient, AdamW on the rank's 1/world shard of the
+    # parameters only, all-gather of the updated bf16 weights (on the xGMI mesh every GPU talks to its 7 peers
+    # directly, so the reduce-scatter + all-gather pair moves (n-1)/n x 2 bytes per parameter in bf16 instead of the all-reduce's
+    # (n-1)/n x 4, and the optimizer's 16 B/param of HBM traffic shrinks by world x).  Replicas end bit-identical either way.
+    grad_algo: str = "allreduce"
 
 
 # ------------------------------------------------------------------------------------- reward shaping (host)
@@ -224,6 +230,74 @@ class GradReducer:
         self.reset()
 
 
+class ShardedExchange:
+    """``grad_algo = "rs_ag"``: reduce-scatter the flat gradient (rank r keeps the SUM of shard r), and after the sharded AdamW
+    all-gather the updated bf16 weights.  Shard r = elements [r S, (r + 1) S) with S = ceil(n / world) rounded up to 64 elements
+    (the last shard is short).  The gradient travels in buckets of ``bucket`` elements per rank: one contiguous [world, bucket]
+    wire buffer (bf16 by default) per collective, so the xGMI links carry world x bucket x 2 bytes per call.  gloo (CPU tests) has
+    no reduce-scatter: there the same sums are formed by one ``reduce`` per destination rank."""
+
+    def __init__(self, n: int, pg, *, wire_dtype: Optional[torch.dtype], bucket: int = 1 << 26):
+        import torch.distributed as dist
+        self.pg, self.wire_dtype, self.bucket = pg, wire_dtype, bucket
+        self.world, self.rank = dist.get_world_size(pg), dist.get_rank(pg)
+        self.n = n
+        self.S = ((n + self.world - 1) // self.world + 63) // 64 * 64
+        self.lo, self.hi = min(n, self.rank * self.S), min(n, (self.rank + 1) * self.S)
+        self.native = dist.get_backend(pg) == "nccl"
+
+    def shard(self, flat: torch.Tensor) -> torch.Tensor:
+        return flat[self.lo:self.hi]
+
+    def reduce_scatter_(self, flat: torch.Tensor) -> None:
+        """flat[lo:hi] <- sum over ranks of flat[lo:hi] (the other shards of ``flat`` are left as they are: stale)."""
+        import torch.distributed as dist
+        W, S, n = self.world, self.S, self.n
+        wd = self.wire_dtype or flat.dtype
+        dev = flat.device if self.native else torch.device("cpu")
+        for b0 in range(0, S, self.bucket):
+            bl = min(self.bucket, S - b0)
+            wire = torch.zeros(W, bl, device=dev, dtype=wd)
+            for r in range(W):                                  # piece [b0, b0 + bl) of every rank's shard, clipped at n
+                a, e = min(n, r * S + b0), min(n, r * S + b0 + bl)
+                if e > a:
+                    wire[r, :e - a].copy_(flat[a:e])
+            if self.native:
+                out = torch.empty(bl, device=dev, dtype=wd)
+                dist.reduce_scatter_tensor(out, wire.view(-1), group=self.pg)
+            else:
+                works = [dist.reduce(wire[r], dst=dist.get_global_rank(self.pg, r), group=self.pg, async_op=True) for r in range(W)]
+                for w in works:
+                    w.wait()
+                out = wire[self.rank]
+            a, e = min(n, self.rank * S + b0), min(n, self.rank * S + b0 + bl)
+            if e > a:
+                flat[a:e].copy_(out[:e - a])
+
+    def all_gather_(self, flat: torch.Tensor) -> None:
+        """Every rank's [lo, hi) slice of ``flat`` (bf16 weights, or any state tensor) -> all ranks."""
+        import torch.distributed as dist
+        W, S, n = self.world, self.S, self.n
+        dev = flat.device if self.native else torch.device("cpu")
+        for b0 in range(0, S, self.bucket):
+            bl = min(self.bucket, S - b0)
+            mine = torch.zeros(bl, device=dev, dtype=flat.dtype)
+            a, e = min(n, self.rank * S + b0), min(n, self.rank * S + b0 + bl)
+            if e > a:
+                mine[:e - a].copy_(flat[a:e])
+            full = torch.empty(W, bl, device=dev, dtype=flat.dtype)
+            if self.native:
+                dist.all_gather_into_tensor(full.view(-1), mine, group=self.pg)
+            else:
+                parts = [torch.empty_like(mine) for _ in range(W)]
+                dist.all_gather(parts, mine, group=self.pg)
+                full = torch.stack(parts)
+            for r in range(W):
+                a, e = min(n, r * S + b0), min(n, r * S + b0 + bl)
+                if e > a and r != self.rank:
+                    flat[a:e].copy_(full[r, :e - a])
+
+
 # ------------------------------------------------------------------------------------- the step engine
 class GRPOEngine:
     """Owns policy + frozen reference weights, fp32 master / Adam state / gradients, and runs the step phases."""
@@ -245,10 +319,15 @@ class GRPOEngine:
         self.step_count = 0
         self.pg = process_group
         self._sumsq = torch.zeros(1, device=self.dev, dtype=F32)
-        self.reducer = None
+        self.reducer, self.sharded = None, None
+        if hyper.grad_algo not in ("allreduce", "rs_ag"):
+            raise ValueError(f"grad_algo {hyper.grad_algo!r}: allreduce or rs_ag")
         if process_group is not None:
-            self.reducer = GradReducer(self.G.flat, self.G.specs, process_group,
-                                       wire_dtype=torch.bfloat16 if hyper.grad_comm_bf16 else None)
+            wire = torch.bfloat16 if hyper.grad_comm_bf16 else None
+            if hyper.grad_algo == "rs_ag":
+                self.sharded = ShardedExchange(self.G.flat.numel(), process_group, wire_dtype=wire)
+            else:
+                self.reducer = GradReducer(self.G.flat, self.G.specs, process_group, wire_dtype=wire)
 
     # -------------------------------------------------------------- phases
     def rollout(self, prompts: List[PromptInput], sp: SamplingParams, stats: Optional[dict] = None) -> torch.Tensor:
@@ -325,6 +404,8 @@ class GRPOEngine:
         waited for; the rest is sent now.  The mean is folded into the optimizer's grad_scale."""
         if self.reducer is not None:
             self.reducer.finish()
+        if self.sharded is not None:
+            self.sharded.reduce_scatter_(self.G.flat)
 
     def optimizer_step(self, world_size: int = 1) -> float:
         """Global-norm clip (max_grad_norm) + AdamW on fp32 master, bf16 policy refreshed in the same kernel."""
@@ -333,14 +414,35 @@ class GRPOEngine:
         self.step_count += 1
         gscale = 1.0 / world_size
         self._sumsq.zero_()
-        K.sumsq_(self.G.flat, self._sumsq)
-        K.adamw_step_(self.master.flat, self.policy.flat, self.m, self.v, self.G.flat, lr=lr, beta1=h.adam_beta1,
-                      beta2=h.adam_beta2, eps=h.adam_eps, weight_decay=h.weight_decay, step=self.step_count,
-                      sumsq=self._sumsq, max_norm=h.max_grad_norm, grad_scale=gscale)
+        if self.sharded is not None:
+            # rs_ag: this rank holds the summed gradient of ITS shard only -> global norm = all-reduce of the shards' sums of squares,
+            # AdamW on the shard (master / moments of the other shards are never touched on this rank), all-gather of the bf16 weights
+            import torch.distributed as dist
+            sh = self.sharded
+            K.sumsq_(sh.shard(self.G.flat), self._sumsq)
+            tot = self._sumsq if sh.native else self._sumsq.cpu()
+            dist.all_reduce(tot, group=self.pg)
+            self._sumsq.copy_(tot)
+            K.adamw_step_(sh.shard(self.master.flat), sh.shard(self.policy.flat), sh.shard(self.m), sh.shard(self.v), sh.shard(self.G.flat),
+                          lr=lr, beta1=h.adam_beta1, beta2=h.adam_beta2, eps=h.adam_eps, weight_decay=h.weight_decay,
+                          step=self.step_count, sumsq=self._sumsq, max_norm=h.max_grad_norm, grad_scale=gscale)
+            sh.all_gather_(self.policy.flat)
+        else:
+            K.sumsq_(self.G.flat, self._sumsq)
+            K.adamw_step_(self.master.flat, self.policy.flat, self.m, self.v, self.G.flat, lr=lr, beta1=h.adam_beta1,
+                          beta2=h.adam_beta2, eps=h.adam_eps, weight_decay=h.weight_decay, step=self.step_count,
+                          sumsq=self._sumsq, max_norm=h.max_grad_norm, grad_scale=gscale)
         self.G.flat.zero_()
         self.engine.invalidate_cache()
         self.roll.invalidate()
         return lr
+
+    def gather_optimizer_state(self) -> None:
+        """rs_ag keeps fp32 master weights and Adam moments current only in the owner's shard; before they are saved (or the
+        algorithm is switched) every rank collects the other shards."""
+        if self.sharded is not None:
+            for t in (self.master.flat, self.m, self.v):
+                self.sharded.all_gather_(t)
 
     def grad_norm(self, world_size: int = 1) -> float:
         return float(self._sumsq.sqrt()) / world_size

@@ -206,7 +206,8 @@ class SGRLVRTrainer:
                           weight_decay=args.weight_decay, adam_beta1=args.adam_beta1, adam_beta2=args.adam_beta2,
                           adam_eps=args.adam_epsilon, max_grad_norm=args.max_grad_norm, temporal=self.temporal,
                           len_control=self.len_control, lr_scheduler_type=args.lr_scheduler_type, total_steps=total_steps,
-                          warmup_steps=args.warmup_steps, recompute=bool(getattr(args, "gradient_checkpointing", False)))
+                          warmup_steps=args.warmup_steps, recompute=bool(getattr(args, "gradient_checkpointing", False)),
+                          grad_algo=getattr(args, "grad_algo", "allreduce"))
         if hyper.recompute:
             self._note("--gradient_checkpointing true: selective activation recompute (MLP intermediates + lm_head logits are "
                        "recomputed in the backward; gradients are bit-identical to the stored path)")
@@ -530,6 +531,8 @@ class SGRLVRTrainer:
         """What HF ``Trainer.save_model`` leaves for the reference (open_r1/SG-RLVR.py:377-384): bf16 safetensors in the
         original Qwen2-VL / Qwen2.5-VL tensor names + config.json + tokenizer / processor files, loadable with
         ``from_pretrained`` (qwen2vl/checkpoint.py), plus the step counter for --resume_from_checkpoint."""
+        if not self.args.save_only_model:
+            self.engine.gather_optimizer_state()        # collective (grad_algo rs_ag keeps master / moments per shard): every rank
         if self.rank != 0:
             return
         output_dir = output_dir or self.args.output_dir
@@ -553,9 +556,15 @@ class SGRLVRTrainer:
             self.engine.step_count = self.global_step
         opt = os.path.join(path, "optimizer.pt")
         if os.path.exists(opt):
-            st = torch.load(opt, map_location="cpu")
+            # mmap: the file holds 12 bytes per parameter (100 GB at 7B); every rank maps it and copies tensor by tensor instead of
+            # materialising a private host copy of the whole file
+            st = torch.load(opt, map_location="cpu", mmap=True)
             e = self.engine
-            e.master.flat.copy_(st["master"]); e.m.copy_(st["m"]); e.v.copy_(st["v"])
+            for name, dst in (("master", e.master.flat), ("m", e.m), ("v", e.v)):
+                if st[name].numel() != dst.numel():
+                    raise ValueError(f"{opt}: '{name}' has {st[name].numel()} elements, this model's flat layout has {dst.numel()} "
+                                     "(checkpoint of another architecture / layout version)")
+                dst.copy_(st[name])
             e.step_count = int(st["step_count"])
         self.engine.engine.invalidate_cache()
         self.engine.roll.invalidate()

@@ -19,12 +19,9 @@ def _free_port():
 
 def _worker(rank, world, port, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    from golden_util import load_tiny
-    from spacer_amd import kernels as K
-    from spacer_amd.grpo import GradReducer, GRPOEngine, GRPOHyper, allreduce_flat_, group_advantages
+    from spacer_amd.grpo import GradReducer, allreduce_flat_
     from spacer_amd.qwen2vl.config import TINY
-    from spacer_amd.qwen2vl.weights import FlatParams, load_state_dict, param_specs, total_numel
-    from spacer_amd.rollout import PromptInput, SamplingParams
+    from spacer_amd.qwen2vl.weights import param_specs, total_numel
     dev = torch.device("cuda", rank)
     torch.cuda.set_device(dev)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -49,24 +46,63 @@ def _worker(rank, world, port, ret):
         torch.cuda.synchronize()
         ok = ok and torch.allclose(flat.cpu(), want, **tol)
     # one data-parallel GRPO step on the tiny model: different prompts' completions per rank, identical replicas afterwards
-    g = load_tiny()
-    params = FlatParams.empty(TINY, dev)
-    load_state_dict(params, g["w"])
-    ge = GRPOEngine(TINY, params, GRPOHyper(num_generations=3, learning_rate=1e-3), process_group=pg)
-    pix, grid = K.patchify(g["frames"].to(dev), kpad=TINY.patch_kpad)
-    prompt = PromptInput(g["prompt"].to(dev), pix, [tuple(grid)])
-    comp = ge.rollout([prompt], SamplingParams(max_new_tokens=8, seed=1 + rank))
-    adv, _ = group_advantages(torch.tensor([2.0, 0.0, 1.0]), 3)
-    ge.score_and_backward(prompt, comp, adv.to(dev), last_group=True)
-    ge.reduce_gradients()
-    ge.optimizer_step(world)
-    torch.cuda.synchronize()
-    mine = ge.policy.flat.float().cpu()
-    both = [torch.zeros_like(mine) for _ in range(world)]
-    dist.all_gather_object(both, mine)
-    ok = ok and all(torch.equal(both[0], b) for b in both) and not torch.equal(mine, ge.ref.flat.float().cpu())
+    ok = ok and _dp_step(rank, world, pg, dev)
     ret[rank] = ok
     dist.destroy_process_group()
+
+
+def _dp_step(rank, world, pg, dev):
+    """Two optimizer steps of a data-parallel GRPO job under BOTH exchange algorithms (grpo.GRPOHyper.grad_algo): replicas
+    bit-identical after every step, and the two algorithms agree with each other to the wire's rounding."""
+    from golden_util import load_tiny
+    from spacer_amd import kernels as K
+    from spacer_amd.grpo import GRPOEngine, GRPOHyper, group_advantages
+    from spacer_amd.qwen2vl.config import TINY
+    from spacer_amd.qwen2vl.weights import FlatParams, load_state_dict
+    from spacer_amd.rollout import PromptInput, SamplingParams
+    g = load_tiny()
+    ok, finals = True, {}
+    for algo in ("allreduce", "rs_ag"):
+        params = FlatParams.empty(TINY, dev)
+        load_state_dict(params, g["w"])
+        ge = GRPOEngine(TINY, params, GRPOHyper(num_generations=3, learning_rate=1e-3, grad_algo=algo), process_group=pg)
+        pix, grid = K.patchify(g["frames"].to(dev), kpad=TINY.patch_kpad)
+        prompt = PromptInput(g["prompt"].to(dev), pix, [tuple(grid)])
+        for step in range(2):
+            comp = ge.rollout([prompt], SamplingParams(max_new_tokens=8, seed=1 + rank + 10 * step))
+            adv, _ = group_advantages(torch.tensor([2.0, 0.0, 1.0]), 3)
+            ge.score_and_backward(prompt, comp, adv.to(dev), last_group=True)
+            ge.reduce_gradients()
+            ge.optimizer_step(world)
+            torch.cuda.synchronize()
+            mine = ge.policy.flat.float().cpu()
+            both = [None] * world
+            dist.all_gather_object(both, mine, group=pg)
+            ok = ok and all(torch.equal(both[0], b) for b in both) and not torch.equal(mine, ge.ref.flat.float().cpu())
+        ge.gather_optimizer_state()
+        masters = [None] * world
+        dist.all_gather_object(masters, ge.master.flat.cpu(), group=pg)
+        ok = ok and all(torch.equal(masters[0], m) for m in masters)        # after the gather the fp32 state is replicated too
+        finals[algo] = ge.master.flat.cpu()
+        del ge, params
+    d = (finals["allreduce"] - finals["rs_ag"]).abs().max()
+    return bool(ok and float(d) < 5e-3)          # same sums up to the bf16 wire's rounding order; lr 1e-3 x 2 steps bounds the drift
+
+
+def _gloo_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda", 0)                 # both ranks share the box's one GPU; gradients are staged through the host
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ret[rank] = _dp_step(rank, world, dist.group.WORLD, dev)
+    dist.destroy_process_group()
+
+
+def test_data_parallel_step_both_exchange_algorithms_one_gpu():
+    """The multi-rank control flow of a data-parallel step on a ONE-GPU box: two processes on cuda:0 over gloo."""
+    ret = mp.Manager().dict()
+    mp.spawn(_gloo_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert ret[0] and ret[1]
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs (RCCL over xGMI)")

@@ -204,3 +204,42 @@ def test_overlapped_gradient_reducer_world2():
     ret = mp.Manager().dict()
     mp.spawn(_reducer_worker, args=(2, port, ret), nprocs=2, join=True)
     assert ret[0] and ret[1]
+
+
+def _sharded_worker(rank, world, port, ret):
+    """grad_algo = "rs_ag" (grpo.ShardedExchange) on gloo/CPU tensors: after the reduce-scatter rank r holds the sum of shard r; an
+    "optimizer" that touches only the own shard followed by the all-gather leaves every replica with the same full vector, equal to
+    what the all-reduce algorithm computes (to fp32 summation order on an fp32 wire, to bf16 rounding on a bf16 wire)."""
+    from spacer_amd.grpo import ShardedExchange
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 10_007                                                     # not a multiple of world or of the 64-element shard granule
+    out = {}
+    for wire in (None, torch.bfloat16):
+        contrib = [torch.randn(n, generator=torch.Generator().manual_seed(7 + r)) for r in range(world)]
+        grad = contrib[rank].clone()
+        sh = ShardedExchange(n, dist.group.WORLD, wire_dtype=wire, bucket=1000)
+        sh.reduce_scatter_(grad)
+        want = sum(c.to(wire).float() if wire is not None else c for c in contrib)
+        tol = dict(atol=3e-2, rtol=2e-2) if wire is not None else dict(atol=1e-6, rtol=1e-6)     # fp32: summation order only
+        ok = torch.allclose(grad[sh.lo:sh.hi], want[sh.lo:sh.hi], **tol)
+        weights = torch.zeros(n)
+        weights[sh.lo:sh.hi] = -0.1 * grad[sh.lo:sh.hi]            # the sharded "optimizer step"
+        sh.all_gather_(weights)
+        ref = contrib[rank].clone()
+        allreduce_flat_(ref, dist.group.WORLD, bucket_elems=3000, wire_dtype=wire)
+        ok = ok and torch.allclose(weights, -0.1 * ref, **(dict(atol=5e-3, rtol=2e-2) if wire is not None else dict(atol=1e-6, rtol=1e-6)))
+        out[str(wire)] = (ok, weights)
+    ret[rank] = out
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_reduce_scatter_all_gather_exchange_leaves_identical_replicas(world):
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_sharded_worker, args=(world, port, ret), nprocs=world, join=True)
+    for wire in ("None", "torch.bfloat16"):
+        assert all(ret[r][wire][0] for r in range(world))
+        for r in range(1, world):
+            assert torch.equal(ret[0][wire][1], ret[r][wire][1])    # replicas bit-identical
