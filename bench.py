@@ -71,19 +71,24 @@ def cpu_gemm_rate(cfg, seconds_budget: float = 4.0):
 def cpu_baseline(cfg, workload):
     """The reference path's CPU stand-in (SURVEY 8(d) "CPU baseline"): ONE prompt group through the WHOLE step on the host
     (oracle/cpu_path.py: ViT + prefill, KV-cache decode, reference + policy scoring with the prompt shared, GRPO loss,
-    autograd backward; fp32 torch) on a BOUNDED sample of the workload: the model's real widths with the depth cut to 2
-    decoder layers + 2 vision blocks and an 8192-row vocabulary, the workload's real frames / prompt length, K = 2 rollouts
-    of 8 tokens.  Every phase is then scaled to the full depth, K and C by its own cost law (stated in "extrapolation")."""
+    autograd backward; fp32 torch) on a BOUNDED sample of the workload: the model's real widths and REAL VOCABULARY with the depth
+    cut to 2 decoder layers + 2 vision blocks, the workload's real frames / prompt length, K = 2 rollouts of 8 tokens.  Every phase
+    is then scaled to the full depth, K and C by its own cost law (stated in "extrapolation"); the lm_head, which does not scale
+    with depth, is timed on its own and scaled by rows only.  The FULL-DEPTH run of the same group at C = 32
+    (scripts/run_cpu_fulldepth.py, minutes of host time) and BASELINE configs[0] in full (scripts/run_cfg1_cpu.py) are recorded
+    files under profiles/, attached as "full_depth_C32" / "cfg1" with their source named -- they are not re-measured here."""
     from oracle import cpu_path as CP
     from oracle import qwen2vl_fp32 as O
     preset, F, Hpx, Wpx, n_text, Kgen, C, groups = workload
     # fp32 torch GEMMs on this host peak at 16-32 threads and collapse when all 256 hardware threads are used
     threads = min(32, os.cpu_count() or 1)
     torch.set_num_threads(threads)
-    Ls, Vs, Ks, Cs, vocab_s = 2, 2, 2, 8, 8192
+    Ls, Vs, Ks, Cs = 2, 2, 2, 8
+    vocab_s = cfg.vocab
     oc = O.make_config(hidden=cfg.hidden, layers=Ls, heads=cfg.heads, kv_heads=cfg.kv_heads, intermediate=cfg.intermediate,
                        vocab=vocab_s, vit_dim=cfg.vit_dim, vit_depth=Vs, vit_heads=cfg.vit_heads, vit_mlp=cfg.vit_mlp,
-                       head_dim=cfg.head_dim, tie_embeddings=cfg.tie_embeddings, video_token_id=vocab_s - 1, image_token_id=vocab_s - 2)
+                       head_dim=cfg.head_dim, tie_embeddings=cfg.tie_embeddings, video_token_id=cfg.video_token_id,
+                       image_token_id=cfg.image_token_id)
     if cfg.vit_kind != "qwen2":
         return None
     w_ref = O.random_weights(oc, seed=1234)
@@ -91,36 +96,67 @@ def cpu_baseline(cfg, workload):
     frames = torch.randint(0, 256, (F, 3, Hpx, Wpx), generator=g, dtype=torch.uint8)
     rows, grid = O.patchify_frames(frames, oc)
     nv = grid[0] * grid[1] * grid[2] // 4
-    prompt = torch.cat([torch.tensor([vocab_s - 4]), torch.full((nv,), oc["video_token_id"]), torch.tensor([vocab_s - 3]),
-                        torch.randint(5, vocab_s - 8, (n_text,), generator=g)])
+    lo = min(1000, vocab_s // 2)
+    prompt = torch.cat([torch.tensor([cfg.vision_start_id]), torch.full((nv,), oc["video_token_id"]), torch.tensor([cfg.vision_end_id]),
+                        torch.randint(lo, min(150000, vocab_s), (n_text,), generator=g)])
     w = {k: v.clone().requires_grad_(True) for k, v in w_ref.items()}
-    out = CP.grpo_group_step(w, w_ref, oc, prompt, rows, [tuple(grid)], num_generations=Ks, max_new_tokens=Cs, eos_token_id=7, seed=1)
-    sec = out["seconds"]
+    out = CP.grpo_group_step(w, w_ref, oc, prompt, rows, [tuple(grid)], num_generations=Ks, max_new_tokens=Cs, eos_token_id=cfg.eos_token_id, seed=1)
+    sec = dict(out["seconds"])
     P = prompt.numel()
+    # the lm_head alone (depth-independent): Ks rows per decode step, Ks * Cs rows per scoring forward; backward = 2 GEMMs of the same size
+    Wl = O.lm_head_weight(w_ref, oc).float()
+    with torch.no_grad():
+        x1, xs = torch.randn(Ks, cfg.hidden), torch.randn(Ks * Cs, cfg.hidden)
+        x1 @ Wl.t(); xs @ Wl.t()
+        t0 = time.perf_counter(); n1 = 0
+        while time.perf_counter() - t0 < 0.5:
+            x1 @ Wl.t(); n1 += 1
+        t_head_step = (time.perf_counter() - t0) / n1
+        t0 = time.perf_counter(); ns = 0
+        while time.perf_counter() - t0 < 0.5:
+            xs @ Wl.t(); ns += 1
+        t_head_score = (time.perf_counter() - t0) / ns
+    del w, Wl
     # scale each phase from the sample (Ls layers, Vs blocks, Ks x Cs tokens) to the workload (full depth, K x C tokens):
-    #   vit+prefill: ViT part ~ depth, prefill ~ layers (split by their FLOPs);  decode: per token-step time (memory-bound weight
-    #   streaming, batch-independent up to K=8) x layers x C;  scoring / backward: ~ layers x tokens (P + K*C) (+ ViT ~ depth)
+    #   vit+prefill: ViT part ~ depth, prefill ~ layers (split by their FLOPs);  decode: per token-step time minus the lm_head
+    #   (memory-bound weight streaming, batch-independent up to K = 8) x layers, plus the lm_head, x C;  scoring / backward: the
+    #   layer part ~ layers x tokens (P + K*C) (+ ViT ~ depth), the lm_head part ~ completion rows K*C
     Lr, Vr = cfg.layers / Ls, cfg.vit_depth / Vs
     vit_f = 2.0 * grid[0] * grid[1] * grid[2] * (12 * cfg.vit_dim ** 2 + 2 * 0) * Vs      # rough split only
     pre_f = 2.0 * P * (cfg.hidden * cfg.qkv_dim + cfg.heads * cfg.head_dim * cfg.hidden + 3 * cfg.hidden * cfg.intermediate) * Ls
     fv = vit_f / (vit_f + pre_f)
     tok_s, tok_r = P + Ks * Cs, P + Kgen * C
+    rows_r = Kgen * C / (Ks * Cs)
+    step_s = sec["decode"] / max(1, Cs - 1)
+
+    def scored(t, head_mult):
+        body = max(0.0, t - head_mult * t_head_score)
+        return body * (fv * Vr + (1 - fv) * Lr * tok_r / tok_s) + head_mult * t_head_score * rows_r
     full = {
         "vit+prefill": sec["vit+prefill"] * (fv * Vr + (1 - fv) * Lr),
-        "decode": sec["decode"] / max(1, Cs - 1) * Lr * (C - 1),
-        "ref scoring": sec["ref scoring"] * (fv * Vr + (1 - fv) * Lr * tok_r / tok_s),
-        "policy scoring": sec["policy scoring"] * (fv * Vr + (1 - fv) * Lr * tok_r / tok_s),
-        "loss+backward": sec["loss+backward"] * (fv * Vr + (1 - fv) * Lr * tok_r / tok_s),
+        "decode": (max(0.0, step_s - t_head_step) * Lr + t_head_step) * (C - 1),
+        "ref scoring": scored(sec["ref scoring"], 1.0),
+        "policy scoring": scored(sec["policy scoring"], 1.0),
+        "loss+backward": scored(sec["loss+backward"], 2.0),
     }
     t_group = sum(full.values())
-    return {"value": Kgen / t_group, "unit": "samples/s", "cores": threads, "kind": "port",
-            "sample": f"one prompt group through oracle/cpu_path.py at the model's widths, {Ls} decoder layers + {Vs} vision blocks, "
-                      f"vocab {vocab_s}, {F} frames {Hpx}x{Wpx}, P={P}, K={Ks}, C={Cs}: {out['total_seconds']:.1f} s measured",
-            "measured_phase_seconds": {k: round(v, 3) for k, v in sec.items()},
-            "measured_decode_tokens_per_s_at_sample_depth": round(Ks * (Cs - 1) / sec["decode"], 2),
-            "extrapolation": f"phases scaled to {cfg.layers} layers / {cfg.vit_depth} vision blocks, K={Kgen}, C={C}: "
-                             + ", ".join(f"{k} {v:.0f} s" for k, v in full.items()) + f" = {t_group:.0f} s per group",
-            "cpu_gemm_rate_gflops": round(1e3 * cpu_gemm_rate(cfg), 1)}
+    res = {"value": Kgen / t_group, "unit": "samples/s", "cores": threads, "kind": "port",
+           "sample": f"one prompt group through oracle/cpu_path.py at the model's widths and vocabulary ({vocab_s}), {Ls} decoder layers + {Vs} "
+                     f"vision blocks, {F} frames {Hpx}x{Wpx}, P={P}, K={Ks}, C={Cs}: {out['total_seconds']:.1f} s measured",
+           "measured_phase_seconds": {k: round(v, 3) for k, v in sec.items()},
+           "measured_lm_head_seconds": {"decode_step": round(t_head_step, 4), "scoring_rows": round(t_head_score, 4)},
+           "measured_decode_tokens_per_s_at_sample_depth": round(Ks * (Cs - 1) / sec["decode"], 2),
+           "extrapolation": f"phases scaled to {cfg.layers} layers / {cfg.vit_depth} vision blocks, K={Kgen}, C={C} (lm_head scaled by rows only): "
+                            + ", ".join(f"{k} {v:.0f} s" for k, v in full.items()) + f" = {t_group:.0f} s per group",
+           "cpu_gemm_rate_gflops": round(1e3 * cpu_gemm_rate(cfg), 1)}
+    for key, fname in (("full_depth_C32", "r03_cpu_fulldepth_7b.json"), ("cfg1", "r03_cfg1_cpu.json")):
+        path = os.path.join(ROOT, "profiles", fname)
+        if os.path.exists(path) and preset == "Qwen2-VL-7B":
+            with open(path) as f:
+                rec = json.load(f)
+            rec["source"] = f"profiles/{fname}: recorded on an MI355X box's host, NOT re-measured in this run"
+            res[key] = rec
+    return res
 
 
 def pmc_traffic(workload: str, kernel: str, live: bool):

@@ -44,164 +44,8 @@ __device__ __forceinline__ KeyTile key_tile(const spacer_attn_segment& seg, int 
     return kt;
 }
 
-// ================================================================================================ forward
-template <int D>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
-    constexpr int DC = (D + 31) / 32;      // 32-wide contraction chunks for QK^T (D=80 -> 3, zero padded)
-    constexpr int DF = D / 16;             // 16-wide d blocks of O^T
-    __shared__ __attribute__((aligned(16))) char smem[2 * AT_RM_BYTES];    // K and V tiles, both row-major
-    char* k_lds = smem;
-    char* v_lds = smem + AT_RM_BYTES;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // longest-first dispatch: later segments (rollouts: prompt prefix + own keys) and later query blocks of a causal
-    // segment have the most key tiles, so they get the lowest block ids and the short blocks fill the tail
-    const int seg_id = a.lpt ? a.num_segs - 1 - blockIdx.x / a.nqb : blockIdx.x / a.nqb;
-    const int qb = a.lpt ? a.nqb - 1 - blockIdx.x % a.nqb : blockIdx.x % a.nqb;
-    const int h = blockIdx.y, hk = h / (a.Hq / a.Hkv);
-    const spacer_attn_segment seg = a.segs[seg_id];
-    const int qb0 = qb * BQ;
-    if (qb0 >= seg.q_len) return;
-    const int l15 = lane & 15, g = lane >> 4;
-    const int wq0 = qb0 + wave * 32;
-
-    bf16x8 qf[2][DC];
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-        int qi = wq0 + f * 16 + l15;
-        qi = qi < seg.q_len ? qi : seg.q_len - 1;
-        const bf16_t* qp = a.q + (long)(seg.q_start + qi) * a.q_stride + (long)h * D;
-#pragma unroll
-        for (int dc = 0; dc < DC; ++dc) qf[f][dc] = frag_global<D>(qp, dc, lane);
-    }
-
-    f32x4 oacc[2][DF];
-#pragma unroll
-    for (int f = 0; f < 2; ++f)
-#pragma unroll
-        for (int d = 0; d < DF; ++d) oacc[f][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};     // m_run in log2 units (scores * scale * log2 e)
-    const float c2 = a.scale * 1.4426950408889634f;
-
-    const int own_len = a.causal ? min(seg.q_len, qb0 + BQ) : seg.q_len;
-    const int n_pre = (seg.pre_len + BKV - 1) / BKV, n_tiles = n_pre + (own_len + BKV - 1) / BKV;
-
-    uint4 kreg[4], vreg[4];
-    {
-        const KeyTile kt = key_tile(seg, n_pre, own_len, 0);
-        const long off = (long)(kt.start_abs + kt.rel0) * a.kv_stride + (long)hk * D;
-        tile_load<D>(kreg, a.k + off, a.kv_stride, kt.len - kt.rel0, tid);
-        tile_load<D>(vreg, a.v + off, a.kv_stride, kt.len - kt.rel0, tid);
-    }
-    for (int t = 0; t < n_tiles; ++t) {
-        const KeyTile kt = key_tile(seg, n_pre, own_len, t);
-        __syncthreads();
-        tile_store<D, true, false>(kreg, k_lds, nullptr, tid);
-        tile_store<D, true, false>(vreg, v_lds, nullptr, tid);
-        __syncthreads();
-        if (t + 1 < n_tiles) {
-            const KeyTile nx = key_tile(seg, n_pre, own_len, t + 1);
-            const long off = (long)(nx.start_abs + nx.rel0) * a.kv_stride + (long)hk * D;
-            tile_load<D>(kreg, a.k + off, a.kv_stride, nx.len - nx.rel0, tid);
-            tile_load<D>(vreg, a.v + off, a.kv_stride, nx.len - nx.rel0, tid);
-        }
-        // wave-level skip: causal tile entirely above this wave's last row
-        if (kt.own && a.causal && kt.rel0 > wq0 + 31) continue;
-
-        // ---- S^T = K . Q^T : st[kf][f] holds keys kf*16 + g*4 + r for q column f*16 + l15
-        f32x4 st[4][2];
-#pragma unroll
-        for (int kf = 0; kf < 4; ++kf) {
-            st[kf][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; st[kf][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int dc = 0; dc < DC; ++dc) {
-                const bf16x8 kfr = frag_rm(k_lds, kf, dc, lane);
-                st[kf][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[0][dc], st[kf][0], 0, 0, 0);
-                st[kf][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[1][dc], st[kf][1], 0, 0, 0);
-            }
-        }
-
-        // ---- online softmax in the exp2 domain (per q column = per lane&15, replicated over the 4 lane groups):
-        // p = 2^(s*c - m) with c = scale*log2(e) folded into one FMA; masking code only runs on tiles that need it
-        // (ragged last tile of a key range, causal diagonal) -- wave-uniform; O is rescaled only when some row's
-        // running max moved.
-        const bool need_mask = (kt.rel0 + BKV > kt.len) || (kt.own && a.causal && kt.rel0 + BKV - 1 > wq0);
-        bf16x8 pf[2][2];   // [f][32-key half]
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-            const int qi = wq0 + f * 16 + l15;           // query index relative to the segment
-            float mx = -INFINITY;
-            if (need_mask) {
-#pragma unroll
-                for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int kr = kt.rel0 + kf * 16 + g * 4 + r;
-                        const bool ok = kr < kt.len && !(kt.own && a.causal && kr > qi);
-                        st[kf][f][r] = ok ? st[kf][f][r] : -INFINITY;
-                    }
-            }
-#pragma unroll
-            for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kf][f][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run[f], mx * c2);                     // c2 > 0: max commutes with the scaling
-            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = __builtin_amdgcn_exp2f(m_run[f] - m_use);     // m_run = -inf -> 0
-            float psum = 0.f;
-            float p[4][4];
-#pragma unroll
-            for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    p[kf][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kf][f][r], c2, -m_use));
-                    psum += p[kf][r];
-                }
-            l_run[f] = l_run[f] * alpha + psum;
-            m_run[f] = m_new;
-            if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
-#pragma unroll
-                for (int d = 0; d < DF; ++d) oacc[f][d] *= alpha;
-            }
-            pf[f][0] = pack_slots(p[0], p[1]);
-            pf[f][1] = pack_slots(p[2], p[3]);
-        }
-
-        // ---- O^T += V^T . P^T
-#pragma unroll
-        for (int df = 0; df < DF; ++df)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const bf16x8 vf = frag_tr(v_lds, df, c, lane);       // V^T fragment by transposing read
-                oacc[0][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[0][c], oacc[0][df], 0, 0, 0);
-                oacc[1][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[1][c], oacc[1][df], 0, 0, 0);
-            }
-    }
-
-    // ---- epilogue: O[q][d] = O^T[d][q] / l ; lane owns q = l15, d = df*16 + g*4 + r (4 consecutive dims)
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-        float l = l_run[f];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
-        const int qi = wq0 + f * 16 + l15;
-        if (qi >= seg.q_len) continue;
-        const float inv = 1.f / l;
-        const long tok = seg.q_start + qi;
-        bf16_t* op = a.o + tok * a.o_stride + (long)h * D;
-#pragma unroll
-        for (int df = 0; df < DF; ++df) {
-            const f32x4 v = oacc[f][df];
-            *(uint2*)(op + df * 16 + g * 4) = make_uint2(pack_bf2(v[0] * inv, v[1] * inv), pack_bf2(v[2] * inv, v[3] * inv));
-        }
-        if (a.lse && g == 0) a.lse[(long)h * a.T + tok] = m_run[f] * 0.6931471805599453f + logf(l);
-    }
-}
-
 // ================================================================================================ forward, pipelined form
-// Same decomposition and arithmetic as attn_fwd_kernel.  K / V tiles reach LDS by global_load_lds DMA straight into TWO pairs of
+// Decomposition: see the file header.  K / V tiles reach LDS by global_load_lds DMA straight into TWO pairs of
 // images (64 KiB per workgroup, still two workgroups per CU), issued one tile ahead, ONE barrier per tile:
 //     top of tile t:  s_waitcnt vmcnt(0)  (my pieces of tile t landed)  ->  s_barrier (everyone's landed, and everyone is done
 //                     with tile t-1's buffer)  ->  issue the DMA of tile t+1 into that buffer  ->  compute tile t.
@@ -217,7 +61,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 //   * row max across the four lane groups: v_permlane16_swap / v_permlane32_swap (VALU) instead of two ds_bpermute trips.
 //   * addresses: per-lane LDS bases hoisted (the swizzle is an XOR on a bit field disjoint from the row and tile fields),
 //     DMA source = scalar tile base + hoisted 32-bit lane offsets; only ragged tiles take the clamping path.
-// Arithmetic is that of attn_fwd_kernel up to the lazy softmax reference (see the loop): O agrees to a bf16 ulp, the LSE to ~1e-6.
+// (The register-staged round-1 forms of these kernels were removed in round 3; csrc/precise.hip keeps the plain structure.)
 typedef __attribute__((ext_vector_type(2))) unsigned int attn_u32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned int attn_u32x4;
 
@@ -436,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(AttnArgs a) {
             // lazy reference: m_run follows the row maximum only when it jumps by more than 2^8 (or leaves -inf), so p <= 256
             // instead of <= 1 (bf16 P keeps its relative precision, l and O are fp32) and the O rescale -- 32 v_pk_mul per
             // fragment, taken on most tiles of random data with the exact rule -- almost never runs: 759 -> 799 TF/s.  O / l and the
-            // LSE m_run ln2 + log l are the same quantities; O moves by at most a bf16 ulp against attn_fwd_kernel.
+            // LSE m_run ln2 + log l are the same quantities; O moves by at most a bf16 ulp against an eager rescale.
             const float m_cand = mx * c2;
             const float m_new = (m_cand > m_run[f] + 8.f) ? m_cand : m_run[f];
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
@@ -524,258 +368,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs a) {
     }
 }
 
-// ---- dQ: same decomposition as forward; per key tile
-//   S^T = K Q^T ; P^T = exp(scale S^T - lse[q]) ; dP^T = V dO^T ; dS^T = P^T (dP^T - delta[q]) scale
-//   dQ^T += K^T dS^T   (A = K^T frag from the transposed image, B = dS^T from registers)
-// NF = 16-row query fragments per wave (workgroup = 64*NF query rows).  NF = 1 keeps Q, dO, dQ^T and the prefetched
-// K/V tile of the next step in registers without spilling at D = 128.
-template <int D, int NF>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
-    constexpr int DC = (D + 31) / 32, DF = D / 16, BQD = 64 * NF;
-    __shared__ __attribute__((aligned(16))) char smem[2 * AT_RM_BYTES];
-    char* k_lds = smem; char* v_lds = smem + AT_RM_BYTES;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // longest-first dispatch: later segments (rollouts: prompt prefix + own keys) and later query blocks of a causal
-    // segment have the most key tiles, so they get the lowest block ids and the short blocks fill the tail
-    const int seg_id = a.lpt ? a.num_segs - 1 - blockIdx.x / a.nqb : blockIdx.x / a.nqb;
-    const int qb = a.lpt ? a.nqb - 1 - blockIdx.x % a.nqb : blockIdx.x % a.nqb;
-    const int h = blockIdx.y, hk = h / (a.Hq / a.Hkv);
-    const spacer_attn_segment seg = a.segs[seg_id];
-    const int qb0 = qb * BQD;
-    if (qb0 >= seg.q_len) return;
-    const int l15 = lane & 15, g = lane >> 4;
-    const int wq0 = qb0 + wave * 16 * NF;
-
-    bf16x8 qf[NF][DC], dof[NF][DC];
-    float lse_q[NF], dl_q[NF];
-#pragma unroll
-    for (int f = 0; f < NF; ++f) {
-        int qi = wq0 + f * 16 + l15;
-        qi = qi < seg.q_len ? qi : seg.q_len - 1;
-        const long tok = seg.q_start + qi;
-        const bf16_t* qp = a.q + tok * a.q_stride + (long)h * D;
-        const bf16_t* dp = a.d_o + tok * a.o_stride + (long)h * D;
-#pragma unroll
-        for (int dc = 0; dc < DC; ++dc) { qf[f][dc] = frag_global<D>(qp, dc, lane); dof[f][dc] = frag_global<D>(dp, dc, lane); }
-        lse_q[f] = a.lse[(long)h * a.T + tok];
-        dl_q[f] = a.delta[(long)h * a.T + tok];
-    }
-    f32x4 acc[NF][DF];
-#pragma unroll
-    for (int f = 0; f < NF; ++f)
-#pragma unroll
-        for (int d = 0; d < DF; ++d) acc[f][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int own_len = a.causal ? min(seg.q_len, qb0 + BQD) : seg.q_len;
-    const int n_pre = (seg.pre_len + BKV - 1) / BKV, n_tiles = n_pre + (own_len + BKV - 1) / BKV;
-
-    const float c2 = a.scale * 1.4426950408889634f;            // exp2 domain: p = 2^(s*c2 - lse*log2 e)
-    float lse2_q[NF];
-#pragma unroll
-    for (int f = 0; f < NF; ++f) lse2_q[f] = lse_q[f] * 1.4426950408889634f;
-
-    uint4 kreg[4], vreg[4];                                    // next tile, in flight under this tile's MFMAs
-    {
-        const KeyTile kt = key_tile(seg, n_pre, own_len, 0);
-        const long off = (long)(kt.start_abs + kt.rel0) * a.kv_stride + (long)hk * D;
-        tile_load<D>(kreg, a.k + off, a.kv_stride, kt.len - kt.rel0, tid);
-        tile_load<D>(vreg, a.v + off, a.kv_stride, kt.len - kt.rel0, tid);
-    }
-    for (int t = 0; t < n_tiles; ++t) {
-        const KeyTile kt = key_tile(seg, n_pre, own_len, t);
-        __syncthreads();
-        tile_store<D, true, false>(kreg, k_lds, nullptr, tid);
-        tile_store<D, true, false>(vreg, v_lds, nullptr, tid);
-        __syncthreads();
-        if (t + 1 < n_tiles) {
-            const KeyTile nx = key_tile(seg, n_pre, own_len, t + 1);
-            const long off = (long)(nx.start_abs + nx.rel0) * a.kv_stride + (long)hk * D;
-            tile_load<D>(kreg, a.k + off, a.kv_stride, nx.len - nx.rel0, tid);
-            tile_load<D>(vreg, a.v + off, a.kv_stride, nx.len - nx.rel0, tid);
-        }
-        if (kt.own && a.causal && kt.rel0 > wq0 + 16 * NF - 1) continue;
-        const bool need_mask = (kt.rel0 + BKV > kt.len) || (kt.own && a.causal && kt.rel0 + BKV - 1 > wq0);
-
-        bf16x8 dsf[NF][2];
-#pragma unroll
-        for (int f = 0; f < NF; ++f) {
-            f32x4 st[4], dp[4];
-#pragma unroll
-            for (int kf = 0; kf < 4; ++kf) {
-                st[kf] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[kf] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int dc = 0; dc < DC; ++dc) {
-                    st[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rm(k_lds, kf, dc, lane), qf[f][dc], st[kf], 0, 0, 0);
-                    dp[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rm(v_lds, kf, dc, lane), dof[f][dc], dp[kf], 0, 0, 0);
-                }
-            }
-            const int qi = wq0 + f * 16 + l15;
-            if (need_mask) {
-#pragma unroll
-                for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int kr = kt.rel0 + kf * 16 + g * 4 + r;
-                        st[kf][r] = (kr < kt.len && !(kt.own && a.causal && kr > qi)) ? st[kf][r] : -INFINITY;   // p = 0
-                    }
-            }
-            float ds[4][4];
-#pragma unroll
-            for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kf][r], c2, -lse2_q[f]));
-                    ds[kf][r] = p * (dp[kf][r] - dl_q[f]) * a.scale;
-                }
-            dsf[f][0] = pack_slots(ds[0], ds[1]);
-            dsf[f][1] = pack_slots(ds[2], ds[3]);
-        }
-#pragma unroll
-        for (int df = 0; df < DF; ++df)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const bf16x8 ktf = frag_tr(k_lds, df, c, lane);      // K^T fragment by transposing read
-#pragma unroll
-                for (int f = 0; f < NF; ++f)
-                    acc[f][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[f][c], acc[f][df], 0, 0, 0);
-            }
-    }
-#pragma unroll
-    for (int f = 0; f < NF; ++f) {
-        const int qi = wq0 + f * 16 + l15;
-        if (qi >= seg.q_len) continue;
-        bf16_t* op = a.dq + (long)(seg.q_start + qi) * a.q_stride + (long)h * D;
-#pragma unroll
-        for (int df = 0; df < DF; ++df) {
-            const f32x4 v = acc[f][df];
-            *(uint2*)(op + df * 16 + g * 4) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-        }
-    }
-}
-
-// ---- dK/dV: workgroup = 64 keys of segment `ks` (own range) x kv head x ONE attending segment `qs`;
-// wave w owns keys w*16..w*16+15 (K, V fragments in registers).  For every q-head of the GQA group and
-// every 64-row query tile of `qs` that can see these keys:
-//   S = Q K^T ; P = exp(scale S - lse[q]) ; dP = dO V^T ; dS = P (dP - delta[q]) scale
-//   dV^T += dO^T P   ;   dK^T += Q^T dS          (A = transposed Q / dO image, B = P / dS from registers)
-// Results are added to fp32 dk/dv with atomics (several attending segments share a prompt's keys).
-template <int D>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
-    constexpr int DC = (D + 31) / 32, DF = D / 16;
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // Q and dO row-major images + 512 B of row statistics
-    char* q_lds = smem; char* do_lds = smem + AT_RM_BYTES;
-    float* stat = (float*)(smem + 2 * AT_RM_BYTES);    // [0..63] lse, [64..127] delta
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nkb = a.nqb;                              // key blocks per segment (host passes ceil(max_q_len/64))
-    // non-causal launches (vision tower: frames / windows) have no shared prefixes: a segment attends only itself,
-    // so the grid carries no attending-segment dimension there
-    const int ks_id = blockIdx.x / nkb, kb = blockIdx.x % nkb, hk = blockIdx.y, qs_id = a.causal ? (int)blockIdx.z : ks_id;
-    const spacer_attn_segment ks = a.segs[ks_id], qs = a.segs[qs_id];
-    const int kb0 = kb * BKV;
-    if (kb0 >= ks.q_len) return;
-    const int key_abs0 = ks.q_start + kb0;
-    const bool own = (ks_id == qs_id);
-    // valid key window [kv_lo, kv_hi) in absolute token index for this attending segment
-    int kv_lo = key_abs0, kv_hi = min(key_abs0 + BKV, ks.q_start + ks.q_len);
-    if (!own) {
-        kv_lo = max(kv_lo, qs.pre_start); kv_hi = min(kv_hi, qs.pre_start + qs.pre_len);
-        if (kv_lo >= kv_hi) return;
-    }
-    const int l15 = lane & 15, g = lane >> 4;
-    const int my_key_abs = key_abs0 + wave * 16 + l15;        // key this lane's column refers to
-    const int my_key_c = min(my_key_abs, ks.q_start + ks.q_len - 1);
-    const bool key_ok = my_key_abs >= kv_lo && my_key_abs < kv_hi;
-    const int my_key_rel = kb0 + wave * 16 + l15;
-
-    bf16x8 kf[DC], vf[DC];
-    {
-        const bf16_t* kp = a.k + (long)my_key_c * a.kv_stride + (long)hk * D;
-        const bf16_t* vp = a.v + (long)my_key_c * a.kv_stride + (long)hk * D;
-#pragma unroll
-        for (int dc = 0; dc < DC; ++dc) { kf[dc] = frag_global<D>(kp, dc, lane); vf[dc] = frag_global<D>(vp, dc, lane); }
-    }
-    f32x4 dka[DF], dva[DF];
-#pragma unroll
-    for (int d = 0; d < DF; ++d) { dka[d] = (f32x4){0.f, 0.f, 0.f, 0.f}; dva[d] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-
-    const int q_first = (own && a.causal) ? (kb0 / BKV) * BKV : 0;   // first query row that can see key kb0
-    const int rep = a.Hq / a.Hkv;
-    const float c2 = a.scale * 1.4426950408889634f, log2e = 1.4426950408889634f;
-    const int q_tiles = (qs.q_len - q_first + BKV - 1) / BKV, n_iter = rep * q_tiles;   // (q head, query tile) pairs
-    const bool keys_full = (kv_lo == key_abs0) && (kv_hi == key_abs0 + BKV);
-
-    uint4 qreg[4], dreg[4];                                    // next (head, query tile), in flight under the MFMAs
-    auto prefetch = [&](int it) {
-        const int h = hk * rep + it / q_tiles, q0 = q_first + (it % q_tiles) * BKV;
-        const long tok0 = qs.q_start + q0;
-        tile_load<D>(qreg, a.q + tok0 * a.q_stride + (long)h * D, a.q_stride, qs.q_len - q0, tid);
-        tile_load<D>(dreg, a.d_o + tok0 * a.o_stride + (long)h * D, a.o_stride, qs.q_len - q0, tid);
-    };
-    if (n_iter > 0) prefetch(0);
-    for (int it = 0; it < n_iter; ++it) {
-        {
-            const int h = hk * rep + it / q_tiles, q0 = q_first + (it % q_tiles) * BKV;
-            const long tok0 = qs.q_start + q0;
-            __syncthreads();
-            tile_store<D, true, false>(qreg, q_lds, nullptr, tid);
-            tile_store<D, true, false>(dreg, do_lds, nullptr, tid);
-            if (tid < 128) {
-                const int r = tid & 63;
-                const long tk = min(tok0 + r, (long)qs.q_start + qs.q_len - 1);
-                stat[tid] = tid < 64 ? a.lse[(long)h * a.T + tk] * log2e : a.delta[(long)h * a.T + tk];
-            }
-            __syncthreads();
-            if (it + 1 < n_iter) prefetch(it + 1);
-            const bool need_mask = !keys_full || (q0 + BKV > qs.q_len) || (own && a.causal && kb0 + BKV - 1 > q0);
-
-            float pv[4][4], dsv[4][4];
-#pragma unroll
-            for (int qf = 0; qf < 4; ++qf) {
-                f32x4 st = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int dc = 0; dc < DC; ++dc) {
-                    st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rm(q_lds, qf, dc, lane), kf[dc], st, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rm(do_lds, qf, dc, lane), vf[dc], dp, 0, 0, 0);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int qr = qf * 16 + g * 4 + r, qi = q0 + qr;     // lane holds S[q = qr][key = l15]
-                    float sv = st[r];
-                    if (need_mask) sv = (key_ok && qi < qs.q_len && !(own && a.causal && my_key_rel > qi)) ? sv : -INFINITY;
-                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sv, c2, -stat[qr]));
-                    pv[qf][r] = p;
-                    dsv[qf][r] = p * (dp[r] - stat[64 + qr]) * a.scale;
-                }
-            }
-            const bf16x8 pf0 = pack_slots(pv[0], pv[1]), pf1 = pack_slots(pv[2], pv[3]);
-            const bf16x8 sf0 = pack_slots(dsv[0], dsv[1]), sf1 = pack_slots(dsv[2], dsv[3]);
-#pragma unroll
-            for (int df = 0; df < DF; ++df) {
-                dva[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(do_lds, df, 0, lane), pf0, dva[df], 0, 0, 0);
-                dva[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(do_lds, df, 1, lane), pf1, dva[df], 0, 0, 0);
-                dka[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(q_lds, df, 0, lane), sf0, dka[df], 0, 0, 0);
-                dka[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(q_lds, df, 1, lane), sf1, dka[df], 0, 0, 0);
-            }
-        }
-    }
-    // lane holds dK^T / dV^T [d = df*16 + g*4 + r][key = l15]
-    if (key_ok) {
-        float* kp = a.dk + ((long)my_key_abs * a.Hkv + hk) * D;
-        float* vp = a.dv + ((long)my_key_abs * a.Hkv + hk) * D;
-#pragma unroll
-        for (int df = 0; df < DF; ++df)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                atomicAdd(kp + df * 16 + g * 4 + r, dka[df][r]);
-                atomicAdd(vp + df * 16 + g * 4 + r, dva[df][r]);
-            }
-    }
-}
-
 // ================================================================================================ dK/dV, pipelined form
-// attn_bwd_dkv_kernel with the forward "pipe" treatment: Q / dO tiles (and the 64 lse / delta values of the tile) go HBM -> LDS
+// dK / dV by key-block owners with the forward "pipe" treatment: Q / dO tiles (and the 64 lse / delta values of the tile) go HBM -> LDS
 // by global_load_lds into two buffers, one barrier per (head, query tile); row-major fragments, the row statistics and the
 // transposing reads are inline-asm LDS reads issued one batch ahead of the MFMAs with counted lgkmcnt waits; addresses hoisted.
 // Both images are read row-major (ds_read_b128: S, dP) AND through the transposing read (dV, dK), so they use at_swz2: the
@@ -993,7 +587,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_pipe_kernel(AttnArgs a) {
 }
 
 // ================================================================================================ dQ, pipelined form
-// attn_bwd_dq_kernel with LDS-DMA K / V tiles (two buffer pairs, one barrier per tile) and pipelined fragment reads.
+// dQ by query-block owners with LDS-DMA K / V tiles (two buffer pairs, one barrier per tile) and pipelined fragment reads.
 // NF = 16-row query fragments per wave.  With NF = 2 every K / V / K^T fragment read from LDS feeds two MFMAs instead of one (at
 // NF = 1 the three products need 192 LDS cycles per 768 MFMA cycles per wave, i.e. at full MFMA rate the LDS would be as busy as
 // the four SIMDs together), but at D = 128 that needs ~280 VGPRs (30 spilled); D = 128 runs NF = 1, D = 80 NF = 2.
@@ -1227,22 +821,15 @@ extern "C" int spacer_attn_fwd(const void* q, const void* k, const void* v, void
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (bf16_t*)o; a.lse = lse;
     a.q_stride = q_stride; a.kv_stride = kv_stride; a.o_stride = o_stride; a.segs = segs_dev; a.num_segs = num_segs;
     a.nqb = cdiv(max_q_len, BQ); a.T = T; a.Hq = Hq; a.Hkv = Hkv; a.causal = causal; a.scale = scale;
-    a.lpt = getenv("SPACER_ATTN_FIFO") ? 0 : 1;
+    a.lpt = 1;                                         // longest blocks first
     const dim3 grid(num_segs * a.nqb, Hq);
-    // forward kernel: "pipe" (default, LDS-DMA tiles + pipelined fragment reads) or "reg" (register-staged tiles, SPACER_ATTN_FWD=reg);
-    // pipe agrees with reg to a bf16 ulp of O (lazy softmax reference); the switch exists for A/B timing (scripts/probes/attn_fwd_time.py)
-    const char* form = getenv("SPACER_ATTN_FWD");
-    const bool reg = form && form[0] == 'r';
     constexpr int LDS = 4 * AT_RM_BYTES;
     static const int once = hipFuncSetAttribute((const void*)attn_fwd_pipe_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)
                           + hipFuncSetAttribute((const void*)attn_fwd_pipe_kernel<80>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     SP_REQUIRE(once == 0, SPACER_ELAUNCH, "attn_fwd: cannot raise the dynamic LDS limit to %d bytes", LDS);
     hipStream_t s = (hipStream_t)stream;
-    if (!reg) {
-        if (D == 128) hipLaunchKernelGGL(attn_fwd_pipe_kernel<128>, grid, dim3(256), LDS, s, a);
-        else hipLaunchKernelGGL(attn_fwd_pipe_kernel<80>, grid, dim3(256), LDS, s, a);
-    } else if (D == 128) hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(attn_fwd_kernel<80>, grid, dim3(256), 0, s, a);
+    if (D == 128) hipLaunchKernelGGL(attn_fwd_pipe_kernel<128>, grid, dim3(256), LDS, s, a);
+    else hipLaunchKernelGGL(attn_fwd_pipe_kernel<80>, grid, dim3(256), LDS, s, a);
     SP_CHECK_LAUNCH();
     return SPACER_OK;
 }
@@ -1259,43 +846,31 @@ extern "C" int spacer_attn_bwd(const void* q, const void* k, const void* v, cons
     a.d_o = (const bf16_t*)d_o; a.delta = delta; a.dq = (bf16_t*)dq; a.dk = dk; a.dv = dv;
     a.q_stride = q_stride; a.kv_stride = kv_stride; a.o_stride = o_stride; a.segs = segs_dev; a.num_segs = num_segs;
     a.T = T; a.Hq = Hq; a.Hkv = Hkv; a.causal = causal; a.scale = scale;
-    a.lpt = getenv("SPACER_ATTN_FIFO") ? 0 : 1;
+    a.lpt = 1;
     hipStream_t s = (hipStream_t)stream;
     const int dgrid = (int)(((long)T * Hq * 16 + 255) / 256 < 4096 ? ((long)T * Hq * 16 + 255) / 256 : 4096);
-    constexpr int NFQ = 1;
-    a.nqb = cdiv(max_q_len, 64 * NFQ);
+    a.nqb = cdiv(max_q_len, 64);                       // dQ at D = 128: 64 query rows per workgroup (16 per wave)
     const dim3 qgrid(num_segs * a.nqb, Hq);
     AttnArgs b = a;
     b.nqb = cdiv(max_q_len, BKV);
     const dim3 kgrid(num_segs * b.nqb, Hkv, causal ? num_segs : 1);
-    // backward kernels: "pipe" (default; LDS-DMA tiles, pipelined fragment reads) or "reg" (register-staged tiles) -- A/B switch
-    const char* form = getenv("SPACER_ATTN_BWD");
-    const bool pipe = !(form && form[0] == 'r');
     constexpr int PIPE_LDS = 4 * AT_RM_BYTES + 1024, DQ_LDS = 4 * AT_RM_BYTES;
-    AttnArgs ap = a;                                   // pipelined dQ at D = 80: 128 query rows per workgroup
+    AttnArgs ap = a;                                   // dQ at D = 80: 128 query rows per workgroup
     ap.nqb = cdiv(max_q_len, 128);
     const dim3 pgrid(num_segs * ap.nqb, Hq);
-    static const int once_dq = hipFuncSetAttribute((const void*)attn_bwd_dq_pipe_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS)
-                             + hipFuncSetAttribute((const void*)attn_bwd_dq_pipe_kernel<80, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS);
-    SP_REQUIRE(once_dq == 0, SPACER_ELAUNCH, "attn_bwd: cannot raise the dynamic LDS limit");
+    static const int once = hipFuncSetAttribute((const void*)attn_bwd_dq_pipe_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS)
+                          + hipFuncSetAttribute((const void*)attn_bwd_dq_pipe_kernel<80, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS)
+                          + hipFuncSetAttribute((const void*)attn_bwd_dkv_pipe_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS)
+                          + hipFuncSetAttribute((const void*)attn_bwd_dkv_pipe_kernel<80>, hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS);
+    SP_REQUIRE(once == 0, SPACER_ELAUNCH, "attn_bwd: cannot raise the dynamic LDS limit");
     if (D == 128) {
         hipLaunchKernelGGL(attn_delta_kernel<128>, dim3(dgrid), dim3(256), 0, s, a);
-        if (pipe) hipLaunchKernelGGL((attn_bwd_dq_pipe_kernel<128, 1>), qgrid, dim3(256), DQ_LDS, s, a);
-        else hipLaunchKernelGGL((attn_bwd_dq_kernel<128, NFQ>), qgrid, dim3(256), 0, s, a);
-        static const int once128 = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AT_RM_BYTES + 512)
-                                 + hipFuncSetAttribute((const void*)attn_bwd_dkv_pipe_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS)
-                                 + hipFuncSetAttribute((const void*)attn_bwd_dkv_pipe_kernel<80>, hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS);
-        SP_REQUIRE(once128 == 0, SPACER_ELAUNCH, "attn_bwd: cannot raise the dynamic LDS limit");
-        if (pipe) hipLaunchKernelGGL(attn_bwd_dkv_pipe_kernel<128>, kgrid, dim3(256), PIPE_LDS, s, b);
-        else hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, kgrid, dim3(256), 2 * AT_RM_BYTES + 512, s, b);
+        hipLaunchKernelGGL((attn_bwd_dq_pipe_kernel<128, 1>), qgrid, dim3(256), DQ_LDS, s, a);
+        hipLaunchKernelGGL(attn_bwd_dkv_pipe_kernel<128>, kgrid, dim3(256), PIPE_LDS, s, b);
     } else {
         hipLaunchKernelGGL(attn_delta_kernel<80>, dim3(dgrid), dim3(256), 0, s, a);
-        if (pipe) hipLaunchKernelGGL((attn_bwd_dq_pipe_kernel<80, 2>), pgrid, dim3(256), DQ_LDS, s, ap);
-        else hipLaunchKernelGGL((attn_bwd_dq_kernel<80, NFQ>), qgrid, dim3(256), 0, s, a);
-        static const int once80 = hipFuncSetAttribute((const void*)attn_bwd_dkv_pipe_kernel<80>, hipFuncAttributeMaxDynamicSharedMemorySize, PIPE_LDS);
-        SP_REQUIRE(once80 == 0, SPACER_ELAUNCH, "attn_bwd: cannot raise the dynamic LDS limit");
-        if (pipe) hipLaunchKernelGGL(attn_bwd_dkv_pipe_kernel<80>, kgrid, dim3(256), PIPE_LDS, s, b);
-        else hipLaunchKernelGGL(attn_bwd_dkv_kernel<80>, kgrid, dim3(256), 2 * AT_RM_BYTES + 512, s, b);
+        hipLaunchKernelGGL((attn_bwd_dq_pipe_kernel<80, 2>), pgrid, dim3(256), DQ_LDS, s, ap);
+        hipLaunchKernelGGL(attn_bwd_dkv_pipe_kernel<80>, kgrid, dim3(256), PIPE_LDS, s, b);
     }
     SP_CHECK_LAUNCH();
     return SPACER_OK;

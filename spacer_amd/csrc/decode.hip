@@ -328,101 +328,6 @@ __global__ __launch_bounds__(256) void swiglu_f32_kernel(float* __restrict__ acc
 // attention: ~24 GB/s per CU, so re-reading the prompt in all 8 rollouts' workgroups costs 8x the time).
 constexpr int PRE_SPLITS = 8;
 
-template <int REP>
-__global__ __launch_bounds__(256, 2) void attn_decode_prefix_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ pk,
-                                                                    const bf16_t* __restrict__ pv, const int* __restrict__ plen,
-                                                                    float* __restrict__ pre, int Kn, int Pmax, int Hq, int Hkv,
-                                                                    float scale) {
-    constexpr int D = 128, DC = 4, DF = 8;
-    __shared__ __attribute__((aligned(16))) char smem[AT_RM_BYTES + AT_T_BYTES(D)];
-    char* k_lds = smem;
-    char* vt_lds = smem + AT_RM_BYTES;
-    const int pr = blockIdx.x, hk = blockIdx.y, sp = blockIdx.z;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, g = lane >> 4;
-    const int P = plen[pr];
-    const int tiles = (P + 63) >> 6, tps = (tiles + PRE_SPLITS - 1) / PRE_SPLITS;
-    const int t0 = sp * tps, t1 = min(tiles, t0 + tps);
-    const int col = wave * 16 + l15;                       // (rollout, head) column of this lane
-    const bool col_ok = col < Kn * REP;
-    bf16x8 qf[DC];
-    {
-        const int kr = col_ok ? col / REP : 0, hr = col_ok ? col % REP : 0;
-        const bf16_t* qp = q + ((long)(pr * Kn + kr) * Hq + hk * REP + hr) * D;
-#pragma unroll
-        for (int dc = 0; dc < DC; ++dc) {
-            uint4 t = make_uint4(0, 0, 0, 0);
-            if (col_ok) t = *(const uint4*)(qp + dc * 32 + g * 8);
-            qf[dc] = __builtin_bit_cast(bf16x8, t);
-        }
-    }
-    f32x4 oacc[DF];
-#pragma unroll
-    for (int d = 0; d < DF; ++d) oacc[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;
-    const long row_stride = (long)Hkv * D;
-    uint4 kreg[4], vreg[4];
-    if (t0 < t1) {
-        const long off = (((long)pr * Pmax + t0 * 64) * Hkv + hk) * D;
-        tile_load<D>(kreg, pk + off, row_stride, P - t0 * 64, tid);
-        tile_load<D>(vreg, pv + off, row_stride, P - t0 * 64, tid);
-    }
-    for (int t = t0; t < t1; ++t) {
-        __syncthreads();
-        tile_store<D, true, false>(kreg, k_lds, nullptr, tid);
-        tile_store<D, false, true>(vreg, nullptr, vt_lds, tid);
-        __syncthreads();
-        if (t + 1 < t1) {
-            const long off = (((long)pr * Pmax + (t + 1) * 64) * Hkv + hk) * D;
-            tile_load<D>(kreg, pk + off, row_stride, P - (t + 1) * 64, tid);
-            tile_load<D>(vreg, pv + off, row_stride, P - (t + 1) * 64, tid);
-        }
-        f32x4 st[4];
-#pragma unroll
-        for (int kf = 0; kf < 4; ++kf) {
-            st[kf] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int dc = 0; dc < DC; ++dc)
-                st[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rm(k_lds, kf, dc, lane), qf[dc], st[kf], 0, 0, 0);
-        }
-        float p[4][4], mx = -INFINITY;
-#pragma unroll
-        for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float sv = (t * 64 + kf * 16 + g * 4 + r < P) ? st[kf][r] * scale : -INFINITY;
-                p[kf][r] = sv;
-                mx = fmaxf(mx, sv);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);           // finite: a visited tile has >= 1 valid key
-        const float alpha = __expf(m_run - m_new);
-        float psum = 0.f;
-#pragma unroll
-        for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { p[kf][r] = __expf(p[kf][r] - m_new); psum += p[kf][r]; }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-#pragma unroll
-        for (int d = 0; d < DF; ++d) oacc[d] *= alpha;
-        const bf16x8 pf0 = pack_slots(p[0], p[1]), pf1 = pack_slots(p[2], p[3]);
-#pragma unroll
-        for (int df = 0; df < DF; ++df) {
-            oacc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t(vt_lds, df, 0, lane), pf0, oacc[df], 0, 0, 0);
-            oacc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_t(vt_lds, df, 1, lane), pf1, oacc[df], 0, 0, 0);
-        }
-    }
-    l_run += __shfl_xor(l_run, 16, 64);
-    l_run += __shfl_xor(l_run, 32, 64);
-    // lane holds O^T[d = df*16 + g*4 + r][col]; partial record = [D floats O | m | l]
-    float* rec = pre + (((long)(pr * Hkv + hk) * PRE_SPLITS + sp) * 64 + col) * (D + 2);
-#pragma unroll
-    for (int df = 0; df < DF; ++df)
-        *(float4*)(rec + df * 16 + g * 4) = make_float4(oacc[df][0], oacc[df][1], oacc[df][2], oacc[df][3]);
-    if (g == 0) { rec[D] = m_run; rec[D + 1] = l_run; }
-}
 
 // =============================================================================== decode attention (MFMA)
 // Workgroup = (sequence b, kv head); the REP q-heads of the GQA group are the MFMA's 16-wide N dimension (zero
@@ -812,92 +717,6 @@ __global__ __launch_bounds__(REP * 128) void attn_decode_merge_kernel(const floa
     o[((long)b * Hq + hk * REP + qh) * D + d] = f2bf(O / L);
 }
 
-// =============================================================================== decode attention (VALU reference form)
-// Workgroup = (sequence b, kv head).  16 lanes x 8 dims cover one key; a wave scores 4 keys per step, the
-// 4 waves stride over keys; all `REP` q heads of the GQA group are scored against each loaded key/value.
-template <int D, int REP>
-__global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ pk,
-                                                          const bf16_t* __restrict__ pv, const int* __restrict__ plen,
-                                                          const int* __restrict__ prompt_of, const bf16_t* __restrict__ tk,
-                                                          const bf16_t* __restrict__ tv, const int* __restrict__ tail_len,
-                                                          bf16_t* __restrict__ o, int Pmax, int Cmax, int Hq, int Hkv,
-                                                          float scale) {
-    static_assert(D == 128, "decode attention is written for head_dim 128");
-    __shared__ float red_m[4][REP], red_l[4][REP];
-    __shared__ float red_o[4][REP][D];
-    const int b = blockIdx.x, hk = blockIdx.y;
-    const int tid = threadIdx.x, sub = tid & 15, grp = tid >> 4;   // 16 key groups
-    const int pr = prompt_of[b], P = plen[pr], Tl = *tail_len + 1;    // tail includes the token appended this step
-    float qv[REP][8];
-#pragma unroll
-    for (int r = 0; r < REP; ++r) {
-        const uint4 t = *(const uint4*)(q + ((long)b * Hq + hk * REP + r) * D + sub * 8);
-        qv[r][0] = bf_lo(t.x) * scale; qv[r][1] = bf_hi(t.x) * scale; qv[r][2] = bf_lo(t.y) * scale; qv[r][3] = bf_hi(t.y) * scale;
-        qv[r][4] = bf_lo(t.z) * scale; qv[r][5] = bf_hi(t.z) * scale; qv[r][6] = bf_lo(t.w) * scale; qv[r][7] = bf_hi(t.w) * scale;
-    }
-    float m[REP], l[REP], acc[REP][8];
-#pragma unroll
-    for (int r = 0; r < REP; ++r) {
-        m[r] = -INFINITY; l[r] = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[r][e] = 0.f;
-    }
-    const int total = P + Tl;
-    for (int key = grp; key < total; key += 16) {
-        const bf16_t *kp, *vp;
-        if (key < P) {
-            const long off = (((long)pr * Pmax + key) * Hkv + hk) * D + sub * 8;
-            kp = pk + off; vp = pv + off;
-        } else {
-            const long off = (((long)b * Cmax + (key - P)) * Hkv + hk) * D + sub * 8;
-            kp = tk + off; vp = tv + off;
-        }
-        const uint4 kk = *(const uint4*)kp, vv = *(const uint4*)vp;
-        const float kf[8] = {bf_lo(kk.x), bf_hi(kk.x), bf_lo(kk.y), bf_hi(kk.y), bf_lo(kk.z), bf_hi(kk.z), bf_lo(kk.w), bf_hi(kk.w)};
-        const float vf[8] = {bf_lo(vv.x), bf_hi(vv.x), bf_lo(vv.y), bf_hi(vv.y), bf_lo(vv.z), bf_hi(vv.z), bf_lo(vv.w), bf_hi(vv.w)};
-#pragma unroll
-        for (int r = 0; r < REP; ++r) {
-            float s = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s += qv[r][e] * kf[e];
-            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
-            const float mn = fmaxf(m[r], s);
-            const float al = __expf(m[r] - mn), p = __expf(s - mn);
-            l[r] = l[r] * al + p; m[r] = mn;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[r][e] = acc[r][e] * al + p * vf[e];
-        }
-    }
-    // combine: first the 4 key groups inside each wave (lanes sub + 16*j) with shuffles, then the 4 waves via LDS
-    const int wave = tid >> 6, lane = tid & 63;
-#pragma unroll
-    for (int r = 0; r < REP; ++r) {
-        float M = fmaxf(m[r], __shfl_xor(m[r], 16, 64));
-        M = fmaxf(M, __shfl_xor(M, 32, 64));
-        const float w = (m[r] == -INFINITY) ? 0.f : __expf(m[r] - M);
-        float L = l[r] * w;
-        L += __shfl_xor(L, 16, 64); L += __shfl_xor(L, 32, 64);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float a = acc[r][e] * w;
-            a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
-            if (lane < 16) red_o[wave][r][sub * 8 + e] = a;
-        }
-        if (lane == 0) { red_m[wave][r] = M; red_l[wave][r] = L; }
-    }
-    __syncthreads();
-    for (int i = tid; i < REP * D; i += 256) {
-        const int r = i / D, d = i % D;
-        float M = -INFINITY;
-        for (int gq = 0; gq < 4; ++gq) M = fmaxf(M, red_m[gq][r]);
-        float L = 0.f, O = 0.f;
-        for (int gq = 0; gq < 4; ++gq) {
-            const float w = (red_m[gq][r] == -INFINITY) ? 0.f : __expf(red_m[gq][r] - M);
-            L += red_l[gq][r] * w; O += red_o[gq][r][d] * w;
-        }
-        o[((long)b * Hq + hk * REP + r) * D + d] = f2bf(O / L);
-    }
-}
 
 }  // namespace
 
@@ -924,7 +743,7 @@ static int launch_skinny(const void* A, long lda, const void* B, long ldb, void*
     const int spr = cdiv(slices, ranges);
     ranges = cdiv(slices, spr);
     SP_REQUIRE(!overwrite || ranges == 1, SPACER_EINVAL, "gemm_skinny: C = A.B^T (store form) needs whole-K workgroups; N=%d splits K %d ways", N, ranges);
-    const int mflush = getenv("SPACER_PROBE_NOFLUSH") ? 0 : M;
+    const int mflush = M;
     if (packed && MTv == 2)
         hipLaunchKernelGGL((gemm_skinny_kernel<true, false, 2>), dim3(col_groups, ranges), dim3(256), 0, s, (const bf16_t*)A, lda,
                            (const bf16_t*)B, ldb, (float*)C, ldc, M, N, K, spr, mflush, overwrite ? 1 : 0);
@@ -1093,22 +912,16 @@ static int launch_attn_decode(const void* q, const void* prefix_k, const void* p
     if (B <= 0) return SPACER_OK;
     const int rep = Hq / Hkv;
     hipStream_t s = (hipStream_t)stream;
-    const bool valu = getenv("SPACER_DECODE_ATTN_VALU") != nullptr;     // reference form kept for A/B runs
 #define LAUNCH(R)                                                                                                      \
-    if (valu)                                                                                                          \
-        hipLaunchKernelGGL((attn_decode_kernel<128, R>), dim3(B, Hkv), dim3(256), 0, s, (const bf16_t*)q,              \
-                           (const bf16_t*)prefix_k, (const bf16_t*)prefix_v, prefix_len, prompt_of, (const bf16_t*)tail_k, \
-                           (const bf16_t*)tail_v, tail_len_dev, (bf16_t*)o, Pmax, Cmax, Hq, Hkv, scale);              \
-    else                                                                                                               \
-    {                                                                                                              \
+    {                                                                                                                  \
         static const int once = hipFuncSetAttribute((const void*)attn_decode_mfma_kernel<R, 8>,                        \
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 8 * AT_T_BYTES(128));  \
         (void)once;                                                                                                    \
         hipLaunchKernelGGL((attn_decode_mfma_kernel<R, 8>), dim3(B, Hkv), dim3(512), 8 * AT_T_BYTES(128), s, (const bf16_t*)q, \
                            (const bf16_t*)prefix_k, (const bf16_t*)prefix_v, prefix_len, prompt_of, (const bf16_t*)tail_k, \
-                           (const bf16_t*)tail_v, tail_len_dev, (bf16_t*)o, Pmax, Cmax, Hq, Hkv, scale, pre_ws, Kn); \
+                           (const bf16_t*)tail_v, tail_len_dev, (bf16_t*)o, Pmax, Cmax, Hq, Hkv, scale, (float*)nullptr, Kn); \
     }
-    if (pre_ws && !valu && getenv("SPACER_DECODE_ATTN_SERIAL") == nullptr) {
+    if (pre_ws) {
         SP_REQUIRE(Kn > 0 && Kn * rep <= 64 && B % Kn == 0, SPACER_EINVAL, "attn_decode_shared: Kn*rep=%d must be <= 64", Kn * rep);
         const int nA = (B / Kn) * Hkv * PRE_SPLITS;
         float* tailp = pre_ws + (long)(B / Kn) * Hkv * PRE_SPLITS * 64 * (128 + 2);
@@ -1131,18 +944,6 @@ static int launch_attn_decode(const void* q, const void* prefix_k, const void* p
 #undef LAUNCH_SPLIT
         SP_CHECK_LAUNCH();
         return SPACER_OK;
-    }
-    if (pre_ws) {
-        SP_REQUIRE(Kn > 0 && Kn * rep <= 64 && B % Kn == 0, SPACER_EINVAL, "attn_decode_shared: Kn*rep=%d must be <= 64", Kn * rep);
-#define LAUNCH_PRE(R)                                                                                                   \
-        hipLaunchKernelGGL((attn_decode_prefix_kernel<R>), dim3(B / Kn, Hkv, PRE_SPLITS), dim3(256), 0, s, (const bf16_t*)q, \
-                           (const bf16_t*)prefix_k, (const bf16_t*)prefix_v, prefix_len, pre_ws, Kn, Pmax, Hq, Hkv, scale)
-        switch (rep) {
-            case 1: LAUNCH_PRE(1); break; case 2: LAUNCH_PRE(2); break; case 3: LAUNCH_PRE(3); break; case 4: LAUNCH_PRE(4); break;
-            case 5: LAUNCH_PRE(5); break; case 6: LAUNCH_PRE(6); break; case 7: LAUNCH_PRE(7); break; case 8: LAUNCH_PRE(8); break;
-            default: SP_REQUIRE(false, SPACER_EINVAL, "attn_decode: GQA ratio %d not instantiated", rep);
-        }
-#undef LAUNCH_PRE
     }
     switch (rep) {
         case 1: LAUNCH(1); break;

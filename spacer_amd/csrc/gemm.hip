@@ -53,15 +53,13 @@ struct GemmArgs {
     int total_blocks, stage_bf16;
 };
 
-// workgroups of a persistent 256-tile launch: one per CU (SPACER_GEMM_PERSIST=0: one per work item, the round-1 form, for A/B runs)
+// workgroups of a persistent 256-tile launch: one per CU
 static unsigned persistent_grid(long items) {
     static const int cus = [] {
         hipDeviceProp_t p;
         int d = 0;
         return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) ? p.multiProcessorCount : 256;
     }();
-    const char* e = getenv("SPACER_GEMM_PERSIST");
-    if (e && e[0] == '0') return (unsigned)items;
     return (unsigned)(items < cus ? items : cus);
 }
 

@@ -31,7 +31,11 @@ def test_bench_json_contract_tiny(dev):
     assert rf["bound"] in ("mfma", "hbm") and rf["unit"] in ("TFLOP/s", "GB/s") and rf["peak"] > 0 and "frac" in rf and "traffic" in rf
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "samples/s" and cb["sample"]
-    assert set(d["variants"]) == {"temporal", "free_running"} and all("samples_per_s" in v for v in d["variants"].values())
+    v = d["variants"]
+    assert set(v) == {"temporal", "free_running", "through_trainer", "precise_scoring", "decode_cfg4_rows"}, set(v)
+    assert all("samples_per_s" in v[k] for k in ("temporal", "free_running", "through_trainer")), v
+    assert v["through_trainer"]["gradient_accumulation_steps"] == 2 and v["through_trainer"]["vs_headline"] > 0
+    assert v["precise_scoring"]["ratio"] > 0 and v["decode_cfg4_rows"]["ms_per_token_step"] > 0
 
 
 def test_bench_refuses_more_gpus_than_visible(dev):
@@ -42,7 +46,8 @@ def test_bench_refuses_more_gpus_than_visible(dev):
     assert r.returncode != 0 and "GPU(s) visible" in (r.stderr + r.stdout)
 
 
-def test_bench_two_ranks_control_flow_on_one_gpu(dev):
+@pytest.mark.parametrize("algo", ["allreduce", "rs_ag"])
+def test_bench_two_ranks_control_flow_on_one_gpu(dev, algo):
     """`python bench.py --gpus 2` with no launcher environment becomes the launcher (torch.distributed.run, 2 ranks); with
     --backend gloo both ranks share cuda:0 and the overlapped gradient reducer stages through the host, so the whole multi-rank
     control flow -- rendezvous, per-rank seeds, reducer hooks during the last backward, barrier + max-over-ranks timing, rank 0
@@ -50,10 +55,10 @@ def test_bench_two_ranks_control_flow_on_one_gpu(dev):
     tests/test_multigpu_gpu.py)."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tiny", "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--backend", "gloo"], capture_output=True, text=True, timeout=900, env=env)
+                        "--backend", "gloo", "--grad-algo", algo], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["config"]["rccl_world"] == 2 and d["config"]["parallelism"] == "dp2"
+    assert d["n_gpus"] == 2 and d["config"]["rccl_world"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["grad_algo"] == algo
     assert d["config"]["global_batch"] == 2 * 2 * 4 and d["value"] > 0 and "cpu_baseline" not in d and "variants" not in d

@@ -344,41 +344,6 @@ def test_attention_fwd_bwd(dev, case):
     assert_close(dv32, vr.grad, 0.03 * float(vr.grad.abs().max()) + 1e-3, 3e-2, f"{name} dv")
 
 
-@pytest.mark.parametrize("case", [ATTN_CASES[1], ATTN_CASES[5]], ids=["vit_520", "shared_prefix_big"])
-def test_attention_kernel_forms_agree(dev, case, monkeypatch):
-    """The register-staged kernels (SPACER_ATTN_FWD=reg / SPACER_ATTN_BWD=reg) and the LDS-DMA pipelined ones (default) share the
-    arithmetic: forward pipe (lazy softmax reference) agrees with reg to a bf16 ulp of O; backward dQ bit for bit, dK / dV
-    (fp32 atomics, a bf16 rounding of dS may flip) to rounding."""
-    name, D, Hq, Hkv, causal, segs = case
-    T = max(s[0] + s[1] for s in segs)
-    qkv = rnd((T, (Hq + 2 * Hkv) * D), dev, 11, 0.7)
-    q, k, v = qkv[:, :Hq * D], qkv[:, Hq * D:(Hq + Hkv) * D], qkv[:, (Hq + Hkv) * D:]
-    sd = K.make_segments(segs, dev)
-    mq = max(s[1] for s in segs)
-    d_o = rnd((T, Hq * D), dev, 12, 0.5)
-    fwd = {}
-    for form in ("reg", "pipe"):
-        monkeypatch.setenv("SPACER_ATTN_FWD", form)
-        fwd[form] = K.attn_fwd(q, k, v, sd, mq, Hq, Hkv, D, causal, D ** -0.5)
-    # pipe: lazy softmax reference -> every P element is rounded to bf16 at another scale (<= 2^-8 relative each), so O agrees to a
-    # bf16 ulp of the output scale; the LSE to fp32 rounding
-    od = (fwd["reg"][0].float() - fwd["pipe"][0].float()).abs()
-    assert float(od.max()) <= 2 ** -7 * float(fwd["reg"][0].float().abs().max()), f"{name}: O (pipe) differs by {float(od.max())}"
-    assert float((fwd["reg"][1] - fwd["pipe"][1]).abs().max()) <= 1e-5, f"{name}: lse (pipe)"
-    o, lse = fwd["reg"]
-    bwd = {}
-    for form in ("reg", "pipe"):                       # same O / LSE into both backward forms
-        monkeypatch.setenv("SPACER_ATTN_BWD", form)
-        dqkv = torch.zeros_like(qkv)
-        dk32 = torch.zeros(T, Hkv * D, device=dev); dv32 = torch.zeros(T, Hkv * D, device=dev)
-        K.attn_bwd(q, k, v, o, d_o, lse, sd, mq, Hq, Hkv, D, causal, D ** -0.5, dq=dqkv[:, :Hq * D], dk32=dk32, dv32=dv32)
-        bwd[form] = (dqkv[:, :Hq * D].clone(), dk32, dv32)
-    assert torch.equal(bwd["reg"][0], bwd["pipe"][0]), f"{name}: dQ differs"
-    for i, nm in ((1, "dK"), (2, "dV")):
-        ref = bwd["reg"][i]
-        assert float((ref - bwd["pipe"][i]).abs().max()) <= 5e-3 * float(ref.abs().max()), f"{name}: {nm}"
-
-
 def test_attention_forced_rescale(dev):
     """Spike one key so the running max jumps at a late tile (rescale branch is exercised)."""
     D, Hq, Hkv, T = 128, 1, 1, 256
@@ -431,33 +396,6 @@ def test_attention_decode_shared_prefix(dev):
             s = torch.einsum("hd,lhd->hl", q[b].float().view(Hq, D), kk) * D ** -0.5
             want = torch.einsum("hl,lhd->hd", torch.softmax(s, -1), vv).reshape(-1)
             assert_close(o[b], want, 2e-2, 2e-2, f"shared decode attn b={b} tl={tl}")
-
-
-def test_gemm_persistent_workgroups_match_one_item_per_workgroup(dev, monkeypatch):
-    """bf16 output without a residual runs on persistent workgroups (min(items, CUs) of them, the next item's first K tile
-    requested under the epilogue); SPACER_GEMM_PERSIST=0 launches one workgroup per item.  Same arithmetic: bit-identical, for
-    NT / dX / SwiGLU shapes with more items than CUs, ragged edges and a split-K tail."""
-    cases = [("nt", 4160, 5120, 1280), ("nt", 5498, 4608, 3584), ("dx", 4160, 5120, 1280), ("swiglu", 4200, 8192, 512), ("nt", 2831, 6152, 704)]
-    for kind, M, N, Kd in cases:
-        a = rnd((M, Kd), dev, 1, 0.5)
-        outs = []
-        for persist in ("1", "0"):
-            monkeypatch.setenv("SPACER_GEMM_PERSIST", persist)
-            if kind == "nt":
-                b = rnd((N, Kd), dev, 2, 0.05)
-                outs.append(K.gemm_nt(a, b, bias=rnd((N,), dev, 3, 0.2)))
-            elif kind == "dx":
-                b = rnd((Kd, N), dev, 2, 0.05)
-                outs.append(K.gemm(a, b, trans_b=True))
-            else:
-                w = rnd((N, Kd), dev, 2, 0.05)
-                act, gu = K.gemm_swiglu(a, w)
-                outs.append(torch.cat([act, gu], 1))
-        assert torch.equal(outs[0], outs[1]), f"{kind} {M}x{N}x{Kd}: persistent form differs by {float((outs[0].float() - outs[1].float()).abs().max())}"
-    monkeypatch.delenv("SPACER_GEMM_PERSIST")
-    # and against fp32 torch for one of them (the persistent path is the default everywhere else in the suite)
-    a, b = rnd((4160, 1280), dev, 1, 0.5), rnd((5120, 1280), dev, 2, 0.05)
-    assert_close(K.gemm_nt(a, b), a.float() @ b.float().t(), 2e-2, 2e-2, "persistent gemm vs fp32")
 
 
 def test_decode_qkv_projection_with_folded_rmsnorm(dev):
