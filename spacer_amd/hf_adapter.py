@@ -94,8 +94,19 @@ class SpacerModel:
         out = torch.empty(B, S, cfg.vocab, device=self.device, dtype=F32)
         for b in range(B):
             ids = input_ids[b].to(self.device).long()
-            x0, _ = e.embed(ids, video)
-            pos3, _ = POS.mrope_positions(ids.tolist(), list(grids or []), cfg, self.era_rule)
+            # only the first Nv placeholder ids are placeholders (they sit in the prompt); a SAMPLED <|video_pad|> / <|image_pad|>
+            # further on is an ordinary token with its own embedding row and a text position, as in Qwen2VLEngine.score_groups
+            cut = S
+            if video is not None:
+                is_vis = (ids == cfg.video_token_id) | (ids == cfg.image_token_id)
+                nth = torch.nonzero(is_vis).reshape(-1)
+                assert nth.numel() >= video.shape[0], "fewer placeholder tokens than vision rows"
+                cut = int(nth[video.shape[0] - 1]) + 1
+            x0, _ = e.embed(ids, video, placeholder_scopes=[(0, cut)] if video is not None else None)
+            pos3, delta = POS.mrope_positions(ids[:cut].tolist(), list(grids or []), cfg, self.era_rule)
+            if cut < S:
+                tail = (cut + delta) + torch.arange(S - cut)
+                pos3 = torch.cat([pos3, tail.view(1, -1).expand(3, -1)], dim=1)
             cos, sin = POS.mrope_tables(pos3, cfg, self.device)
             segs = K.make_segments([(0, S, 0, 0)], self.device)
             x = e.llm_forward(x0, cos, sin, segs, S)

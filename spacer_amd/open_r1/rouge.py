@@ -102,11 +102,22 @@ def porter_stem(word: str) -> str:
     # step 1c (nltk extension: y -> i only after a consonant and when the stem is longer than one letter)
     if w.endswith("y") and len(w) > 2 and _cons(w, len(w) - 2):
         w = w[:-1] + "i"
-    # step 2
-    w = _replace(w, (("ational", "ate"), ("tional", "tion"), ("enci", "ence"), ("anci", "ance"), ("izer", "ize"), ("bli", "ble"),
-                     ("alli", "al"), ("entli", "ent"), ("eli", "e"), ("ousli", "ous"), ("ization", "ize"), ("ation", "ate"),
-                     ("ator", "ate"), ("alism", "al"), ("iveness", "ive"), ("fulness", "ful"), ("ousness", "ous"), ("aliti", "al"),
-                     ("iviti", "ive"), ("biliti", "ble"), ("fulli", "ful"), ("logi", "log")), lambda s: _measure(s) > 0)
+    # step 2 (nltk NLTK_EXTENSIONS form, the stemmer rouge_score uses): "alli" -> "al" is tried FIRST and its result goes through
+    # step 2 again ("rationally" -> "rational" -> "ration" ... per nltk/stem/porter.py _step2); the "logi" -> "log" rule measures the
+    # stem WITH its "l" (word[:-3]), so that "geology" / "theology" behave like "archaeology"
+    def step2(v: str) -> str:
+        if v.endswith("alli") and _measure(v[:-4]) > 0:
+            return step2(v[:-4] + "al")
+        for suf, rep in (("ational", "ate"), ("tional", "tion"), ("enci", "ence"), ("anci", "ance"), ("izer", "ize"), ("bli", "ble"),
+                         ("alli", "al"), ("entli", "ent"), ("eli", "e"), ("ousli", "ous"), ("ization", "ize"), ("ation", "ate"),
+                         ("ator", "ate"), ("alism", "al"), ("iveness", "ive"), ("fulness", "ful"), ("ousness", "ous"), ("aliti", "al"),
+                         ("iviti", "ive"), ("biliti", "ble"), ("fulli", "ful"), ("logi", "log")):
+            if v.endswith(suf):
+                stem = v[:len(v) - len(suf)]
+                ok = _measure(v[:-3]) > 0 if suf == "logi" else _measure(stem) > 0
+                return stem + rep if ok else v
+        return v
+    w = step2(w)
     # step 3
     w = _replace(w, (("icate", "ic"), ("ative", ""), ("alize", "al"), ("iciti", "ic"), ("ical", "ic"), ("ful", ""), ("ness", "")),
                  lambda s: _measure(s) > 0)

@@ -59,7 +59,9 @@ class RolloutEngine:
         # decode: the input RMSNorm of every layer folded into its q|k|v projection (weights packed as W diag(w_ln1), the GEMM
         # stages the fp32 residual stream itself and sums x^2, the finishing kernel applies rstd): one launch less per layer.
         # SPACER_DECODE_NORM=separate keeps the norm kernel (A/B runs); batches of more than 64 rows always keep it.
-        self.fold_norm = os.environ.get("SPACER_DECODE_NORM", "fold") != "separate"
+        # (the finishing kernel of layer i clears the row sums of layer (i + 1) % layers while it reads layer i's: a one-layer model
+        # would clear what it reads, so it keeps the separate norm launch)
+        self.fold_norm = os.environ.get("SPACER_DECODE_NORM", "fold") != "separate" and engine.cfg.layers >= 2
 
     # ------------------------------------------------------------------ decode-layout weights
     def invalidate(self) -> None:

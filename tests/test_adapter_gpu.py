@@ -74,3 +74,22 @@ def test_forward_logits_call_shape(model):
     # and it is the same quantity the engine's shared-prompt scoring produces
     eng_lp = m.engine.score_group(g["prompt"].to(m.device), g["completions"].to(m.device), m._pixels(model["inputs"])[0], [model["grid"]])
     assert float((lp - eng_lp).abs().max()) < 5e-3
+
+
+def test_forward_with_a_sampled_placeholder_id_in_the_completion(model):
+    """A random-init policy does sample <|video_pad|> as a completion token.  Through the adapter it is an ordinary token (own
+    embedding row, text position), exactly as in the engine's shared-prompt scoring: no exception, no extra vision row consumed,
+    and the log-probs before the injected position are untouched (causality)."""
+    g, m = model["g"], model["m"]
+    P = g["prompt"].numel()
+    comps = g["completions"].clone()
+    base_ids = torch.stack([torch.cat([g["prompt"], c]) for c in comps]).to(m.device)
+    comps[1, 3] = TINY.video_token_id
+    ids = torch.stack([torch.cat([g["prompt"], c]) for c in comps]).to(m.device)
+    kw = dict(pixel_values_videos=model["rows"], video_grid_thw=torch.tensor([list(model["grid"])]))
+    lp0 = _get_per_token_logps(m, base_ids, **kw)[:, P - 1:]
+    lp1 = _get_per_token_logps(m, ids, **kw)[:, P - 1:]
+    assert torch.isfinite(lp1).all()
+    assert torch.equal(lp0[0], lp1[0]) and torch.equal(lp0[1, :3], lp1[1, :3]) and not torch.equal(lp0[1, 4:], lp1[1, 4:])
+    eng_lp = m.engine.score_group(g["prompt"].to(m.device), comps.to(m.device), m._pixels(model["inputs"])[0], [model["grid"]])
+    assert float((lp1 - eng_lp).abs().max()) < 5e-3
