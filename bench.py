@@ -280,6 +280,9 @@ def main():
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="gloo: every rank on cuda:0, gradients staged through the host -- exercises the multi-rank control flow on a "
                          "one-GPU box (tests only; the number it prints is not a scaling measurement)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="create the process group (and run the reducer / barrier / max-over-ranks code) even for a world of ONE rank: "
+                         "exercises the RCCL path of the multi-GPU job on a one-GPU box (tests)")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 --pmc passes for roofline.traffic (use the committed table)")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra --temporal / free-running measurements (N = 1)")
     ap.add_argument("--phase-times", action="store_true", help="print per-phase wall times (adds synchronisations)")
@@ -310,8 +313,14 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pg = None
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         import torch.distributed as dist
+        if args.force_dist and "WORLD_SIZE" not in os.environ:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]), RANK="0", WORLD_SIZE="1")
         if args.backend == "gloo":
             dist.init_process_group("gloo")
         else:
@@ -390,7 +399,7 @@ def main():
         tick("reduce+adamw", t0)
 
     def barrier():
-        if world > 1:
+        if dist_on:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -408,7 +417,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t_start
     K.PROFILER.enabled = False
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
         t = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -542,7 +551,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, (preset, F, Hpx, Wpx, n_text, Kgen, C, groups))
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -62,3 +62,18 @@ def test_bench_two_ranks_control_flow_on_one_gpu(dev, algo):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["rccl_world"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["grad_algo"] == algo
     assert d["config"]["global_batch"] == 2 * 2 * 4 and d["value"] > 0 and "cpu_baseline" not in d and "variants" not in d
+
+
+@pytest.mark.parametrize("algo", ["allreduce", "rs_ag"])
+def test_bench_rccl_branch_with_a_world_of_one(dev, algo):
+    """bench.py's distributed branch over RCCL ("nccl") on the one-GPU box: --force-dist forms a process group of one rank, so the
+    process-group creation with device_id, the overlapped reducer on its side stream (bf16 wire), the barrier and the max-over-ranks
+    timing all run against the real library -- the calls the driver's N = 2, 4, 8 runs make."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tiny", "--steps", "2", "--warmup", "1", "--force-dist",
+                        "--grad-algo", algo, "--no-variants", "--no-cpu-baseline", "--no-pmc"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["backend"] == "nccl" and d["config"]["grad_algo"] == algo and d["value"] > 0

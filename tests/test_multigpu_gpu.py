@@ -110,3 +110,51 @@ def test_rccl_gradient_exchange_two_gpus():
     ret = mp.Manager().dict()
     mp.spawn(_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
     assert ret[0] and ret[1]
+
+
+def _nccl_world1_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from spacer_amd.grpo import GradReducer, ShardedExchange, allreduce_flat_
+    from spacer_amd.qwen2vl.config import TINY
+    from spacer_amd.qwen2vl.weights import param_specs, total_numel
+    pg = dist.group.WORLD
+    specs = param_specs(TINY)
+    n = total_numel(specs)
+    ok = True
+    for wire in (None, torch.bfloat16):
+        src = torch.randn(n, generator=torch.Generator().manual_seed(3))
+        want = src.to(wire).float() if wire is not None else src
+        flat = src.to(dev)
+        allreduce_flat_(flat, pg, bucket_elems=100_000, wire_dtype=wire)
+        ok = ok and torch.equal(flat.cpu(), want)
+        flat = src.to(dev)
+        red = GradReducer(flat, specs, pg, wire_dtype=wire, bucket_elems=100_000)      # RCCL collectives on the side stream
+        red.ready("llm.norm_w"); red.ready("llm.lm_head")
+        for i in reversed(range(TINY.layers)):
+            red.ready(f"llm.{i}.")
+        red.finish()
+        torch.cuda.synchronize()
+        ok = ok and torch.equal(flat.cpu(), want)
+        flat = src.to(dev)
+        sh = ShardedExchange(n, pg, wire_dtype=wire, bucket=70_000)                    # reduce_scatter_tensor / all_gather_into_tensor
+        sh.reduce_scatter_(flat)
+        sh.all_gather_(flat)
+        torch.cuda.synchronize()
+        ok = ok and torch.equal(flat.cpu(), want)
+    ok = ok and _dp_step(0, 1, pg, dev)
+    ret[0] = ok
+    dist.destroy_process_group()
+
+
+def test_rccl_code_path_on_one_gpu():
+    """RCCL itself ("nccl" backend) with a world of ONE rank on the box's single GPU: the collectives are trivial, but every call the
+    multi-GPU job makes -- process-group creation with device_id, async all_reduce on the reducer's side stream with bf16 wire
+    buffers, reduce_scatter_tensor / all_gather_into_tensor of the sharded exchange, the scalar all-reduce of the clip norm, the
+    data-parallel step under both algorithms -- runs against the real library on device buffers (the >= 2-GPU variant above skips
+    on this box)."""
+    ret = mp.Manager().dict()
+    mp.spawn(_nccl_world1_worker, args=(1, _free_port(), ret), nprocs=1, join=True)
+    assert ret[0]
