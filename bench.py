@@ -303,6 +303,12 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         sys.exit(subprocess.run(cmd, env=env).returncode)
+    # stdout carries exactly ONE line, the result: everything else that lands on file descriptor 1 -- RCCL's version banner (printed
+    # through C stdio, flushed at exit, i.e. AFTER a Python print), library chatter, the trainer variant's log lines -- is sent
+    # to stderr for the lifetime of the process; the JSON line is written to the saved descriptor at the end
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -550,7 +556,8 @@ def main():
             out["variants"] = variants
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, (preset, F, Hpx, Wpx, n_text, Kgen, C, groups))
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist_on:
         import torch.distributed as dist
         dist.destroy_process_group()

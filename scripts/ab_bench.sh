@@ -4,7 +4,7 @@
 mkdir -p gpurun_out
 for spec in "$@"; do
   label="${spec%%|*}"; args="${spec#*|}"
-  python bench.py --no-variants --no-cpu-baseline --no-pmc $args 2>gpurun_out/ab_$label.err | tail -1 > gpurun_out/ab_$label.json
+  python bench.py --no-variants --no-cpu-baseline --no-pmc $args 2>gpurun_out/ab_$label.err | grep "^{" | tail -1 > gpurun_out/ab_$label.json
   python - "$label" <<'PY'
 import json, sys
 lab = sys.argv[1]
