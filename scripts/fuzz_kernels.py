@@ -200,10 +200,82 @@ def fuzz_norm(r):
     close(dw, wr.grad, 3e-2 * math.sqrt(rows), 2e-2, f"rmsnorm dw {rows}x{cols} f32={f32}")
 
 
+def fuzz_pair(r):
+    """Precise scoring mode (csrc/precise.hip): the pair attention on random segment layouts and the two-pass GEMM with ragged shapes,
+    against fp64 torch at ~2^-16 of the output scale (a dropped lo part would miss by two orders of magnitude)."""
+    if r.randint(0, 1):
+        D, Hq, Hkv = r.choice([(128, 4, 2), (128, 7, 1), (80, 3, 3)])
+        causal = D == 128
+        segs, at = [], 0
+        if causal and r.randint(0, 1):
+            P = r.randint(1, 300)
+            segs.append((0, P, 0, 0)); at = P
+            for _ in range(r.randint(1, 4)):
+                L = r.randint(1, 200)
+                segs.append((at, L, 0, P)); at += L
+        else:
+            for _ in range(r.randint(1, 4)):
+                L = r.randint(1, 330)
+                segs.append((at, L, 0, 0)); at += L
+        T = at
+        qkv = rnd((T, (Hq + 2 * Hkv) * D), 0.9, torch.float32)
+        hi, lo = K.split_pair(qkv)
+        qd, kd = Hq * D, Hkv * D
+        cut = lambda t: (t[:, :qd], t[:, qd:qd + kd], t[:, qd + kd:])            # noqa: E731
+        (qh, kh, vh), (ql, kl, vl) = cut(hi), cut(lo)
+        o = K.attn_fwd_pair((qh, ql), (kh, kl), (vh, vl), K.make_segments(segs, dev), max(s[1] for s in segs), Hq, Hkv, D, causal, D ** -0.5)
+        x = hi.double() + lo.double()
+        q64, k64, v64 = cut(x)
+        mask = dense_mask(segs, T, causal).to(dev)
+        qq = q64.reshape(T, Hq, D).transpose(0, 1)
+        kk = k64.reshape(T, Hkv, D).repeat_interleave(Hq // Hkv, 1).transpose(0, 1)
+        vv = v64.reshape(T, Hkv, D).repeat_interleave(Hq // Hkv, 1).transpose(0, 1)
+        sc = (qq @ kk.transpose(1, 2)) * D ** -0.5
+        want = (torch.softmax(sc.masked_fill(~mask, float("-inf")), -1) @ vv).transpose(0, 1).reshape(T, Hq * D)
+        got = o[0].double() + o[1].double()
+        err = float((got - want).abs().max() / want.abs().max())
+        if not err <= 3e-4:
+            raise AssertionError(f"MISMATCH attn pair {segs}: rel err {err:.3g}")
+    else:
+        M, N, Kd = r.randint(1, 3000), r.randint(1, 300) * 8, r.randint(1, 40) * 64
+        a = rnd((M, Kd), 1.0, torch.float32)
+        w = rnd((N, Kd), 0.05)
+        res = rnd((M, N), 1.0, torch.float32)
+        want = a.double() @ w.double().t() + res.double()
+        x = res.clone()
+        K.gemm_pair(*K.split_pair(a), w, residual=x, out=x)
+        err = float((x.double() - want).abs().max() / want.abs().max())
+        if not err <= 2.0 ** -15:
+            raise AssertionError(f"MISMATCH gemm pair {M}x{N}x{Kd}: rel err {err:.3g}")
+
+
+def fuzz_chunk_head(r):
+    """Vocabulary-chunked log-sum-exp / dlogits (loss.hip) against the one-shot kernels for ragged chunk sizes and strided views."""
+    rows, V = r.randint(1, 300), r.randint(3, 500) * 4
+    ch = r.choice([V, r.randint(1, max(1, V // 4)) * 4])
+    logits = rnd((rows, V + 8), 3.0, torch.float32)[:, 4:V + 4] if r.randint(0, 1) else rnd((rows, V), 3.0, torch.float32)
+    tg = torch.randint(0, V, (rows,), device=dev)
+    g = rnd((rows,), 1.0, torch.float32)
+    state = torch.empty(3, rows, device=dev)
+    for c0 in range(0, V, ch):
+        K.lse_chunk_(logits[:, c0:min(V, c0 + ch)], tg, c0, state, first=c0 == 0)
+    logp, lse = K.lse_finish(state)
+    want = torch.log_softmax(logits.double(), -1).gather(1, tg.view(-1, 1)).view(-1)
+    close(logp, want, 2e-5, 1e-5, f"chunk lse {rows}x{V} ch {ch}")
+    dl = torch.empty(rows, V, device=dev, dtype=BF)
+    for c0 in range(0, V, ch):
+        c1 = min(V, c0 + ch)
+        K.logprob_bwd_chunk(logits[:, c0:c1], tg, c0, lse, g, dl[:, c0:c1])
+    p = torch.softmax(logits.double(), -1)
+    onehot = torch.zeros_like(p).scatter_(1, tg.view(-1, 1), 1.0)
+    close(dl, (onehot - p) * g.double().view(-1, 1), 1e-2 * float(g.abs().max()), 1e-2, f"chunk dlogits {rows}x{V} ch {ch}")
+
+
 def run(budget: float, seed: int) -> dict:
     r = random.Random(seed)
     torch.manual_seed(seed)
-    fns = [fuzz_gemm, fuzz_gemm_trans, fuzz_swiglu, fuzz_attention, fuzz_decode_attention, fuzz_skinny, fuzz_skinny_normed, fuzz_norm, fuzz_resize]
+    fns = [fuzz_gemm, fuzz_gemm_trans, fuzz_swiglu, fuzz_attention, fuzz_decode_attention, fuzz_skinny, fuzz_skinny_normed, fuzz_norm, fuzz_resize, fuzz_pair,
+           fuzz_chunk_head]
     counts = {f.__name__: 0 for f in fns}
     t0 = time.time()
     while time.time() - t0 < budget:
