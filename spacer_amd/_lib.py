@@ -108,6 +108,9 @@ def load() -> C.CDLL:
         raise SpacerError(
             f"{LIB_PATH} not found: the HIP extension is not built (run __graft_entry__.build()). "
             "spacer_amd has no CPU fallback for the hot path.")
+    # torch first: its wheel bundles its own HIP runtime (libamdhip64) and the library must bind to THAT copy -- loaded the other way
+    # round the process holds two runtimes and launches from this library fail with "no ROCm-capable device is detected"
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)
