@@ -333,6 +333,14 @@ class GRPOEngine:
     def rollout(self, prompts: List[PromptInput], sp: SamplingParams, stats: Optional[dict] = None) -> torch.Tensor:
         return self.roll.generate(prompts, self.h.num_generations, sp, stats=stats)
 
+    @torch.no_grad()
+    def logps(self, prompts: List[PromptInput], completions: List[torch.Tensor], *, which: str = "policy", precise: bool = False,
+              era_rule: bool = False) -> torch.Tensor:
+        """Per-token log-probs [G*K, C] of the completions under the policy or the frozen reference model (TR:353-366, no
+        gradient): evaluation / reporting.  ``precise=True`` = the mode that holds 1e-3 against an fp32 evaluation at full depth."""
+        eng = {"policy": self.engine, "ref": self.ref_engine}[which]
+        return eng.score_groups([(p.ids, p.pix, p.grids) for p in prompts], completions, era_rule=era_rule, precise=precise)
+
     def score_and_backward(self, prompt: PromptInput, completion_ids: torch.Tensor, advantages: torch.Tensor,
                            grad_scale: float = 1.0, *, era_rule: bool = False, last_group: bool = False) -> Dict[str, torch.Tensor]:
         """One prompt group: masks, reference + policy log-probs, loss, backward into self.G.  ``advantages`` fp32 [K]

@@ -28,8 +28,12 @@ F32 = torch.float32
 class SpacerModel:
     """``model``-shaped view of a ``Qwen2VLEngine`` (+ its ``RolloutEngine``)."""
 
-    def __init__(self, engine: Qwen2VLEngine, roll: Optional[RolloutEngine] = None, *, era_rule: bool = False, seed: int = 0):
+    def __init__(self, engine: Qwen2VLEngine, roll: Optional[RolloutEngine] = None, *, era_rule: bool = False, seed: int = 0,
+                 precise: bool = False):
         self.engine, self.roll = engine, roll or RolloutEngine(engine)
+        # precise = True: ``model(input_ids, ...).logits`` through the precise scoring mode (csrc/precise.hip: (hi, lo) operand pairs,
+        # fp32 between operators) -- log-probs within 1e-3 of an fp32 evaluation at full depth, 2-3x the time of the fast path
+        self.precise = precise
         self.cfg, self.device = engine.cfg, engine.dev
         self.era_rule, self.seed, self._calls = era_rule, seed, 0
         self.config = SimpleNamespace(vocab_size=engine.cfg.vocab, hidden_size=engine.cfg.hidden,
@@ -90,7 +94,13 @@ class SpacerModel:
         B, S = input_ids.shape
         pix, grids = self._pixels(kw, copies=B if (kw.get("video_grid_thw") is not None and kw["video_grid_thw"].shape[0] == B and B > 1)
                                   or (kw.get("image_grid_thw") is not None and kw["image_grid_thw"].shape[0] == B and B > 1) else 1)
-        video = e.vit_forward(pix, grids) if pix is not None else None
+        unit_rev = None
+        if pix is None:
+            video = None
+        elif self.precise:
+            video, unit_rev = e._vit_forward_precise(pix, grids)
+        else:
+            video = e.vit_forward(pix, grids)
         out = torch.empty(B, S, cfg.vocab, device=self.device, dtype=F32)
         for b in range(B):
             ids = input_ids[b].to(self.device).long()
@@ -102,13 +112,17 @@ class SpacerModel:
                 nth = torch.nonzero(is_vis).reshape(-1)
                 assert nth.numel() >= video.shape[0], "fewer placeholder tokens than vision rows"
                 cut = int(nth[video.shape[0] - 1]) + 1
-            x0, _ = e.embed(ids, video, placeholder_scopes=[(0, cut)] if video is not None else None)
+            x0, _ = e.embed(ids, video, placeholder_scopes=[(0, cut)] if video is not None else None, unit_rev=unit_rev)
             pos3, delta = POS.mrope_positions(ids[:cut].tolist(), list(grids or []), cfg, self.era_rule)
             if cut < S:
                 tail = (cut + delta) + torch.arange(S - cut)
                 pos3 = torch.cat([pos3, tail.view(1, -1).expand(3, -1)], dim=1)
             cos, sin = POS.mrope_tables(pos3, cfg, self.device)
             segs = K.make_segments([(0, S, 0, 0)], self.device)
+            if self.precise:
+                x = e._llm_forward_precise(x0, cos, sin, segs, S)
+                K.gemm_pair(*K.norm_pair(x, e.W["llm.norm_w"], None, cfg.rms_eps), e.W["llm.lm_head"], out=out[b])
+                continue
             x = e.llm_forward(x0, cos, sin, segs, S)
             hn = K.rmsnorm_fwd(x, e.W["llm.norm_w"], cfg.rms_eps)
             K.gemm_nt(hn, e.W["llm.lm_head"], out=out[b], out_dtype=F32)

@@ -93,3 +93,16 @@ def test_forward_with_a_sampled_placeholder_id_in_the_completion(model):
     assert torch.equal(lp0[0], lp1[0]) and torch.equal(lp0[1, :3], lp1[1, :3]) and not torch.equal(lp0[1, 4:], lp1[1, 4:])
     eng_lp = m.engine.score_group(g["prompt"].to(m.device), comps.to(m.device), m._pixels(model["inputs"])[0], [model["grid"]])
     assert float((lp1 - eng_lp).abs().max()) < 5e-3
+
+
+def test_precise_adapter_logits_hold_the_north_star_tolerance(model):
+    """``SpacerModel(engine, precise=True)``: the reference's own ``_get_per_token_logps`` (TR:353-366) run on the adapter's logits
+    lands within 1e-4 of the fp32 oracle on the miniature (the fast adapter: ~3e-3)."""
+    g, m = model["g"], model["m"]
+    pm = SpacerModel(m.engine, m.roll, precise=True)
+    P, (Kn, C) = g["prompt"].numel(), g["completions"].shape
+    ids = torch.stack([torch.cat([g["prompt"], c]) for c in g["completions"]]).to(m.device)
+    kw = dict(pixel_values_videos=model["rows"], video_grid_thw=torch.tensor([list(model["grid"])]))
+    lp = _get_per_token_logps(pm, ids, **kw)[:, P - 1:]
+    want = O.completion_logps(model["wb"], g["cfg"], g["prompt"], g["completions"], model["rows"].to(torch.bfloat16).float(), [model["grid"]])
+    assert float((lp.cpu() - want).abs().max()) < 1e-4
