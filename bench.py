@@ -531,6 +531,7 @@ def main():
                         for k, v in prof.items()},
         }
         out["hbm_peak_gb"] = hbm_peak_gb
+        out["alloc_retries"] = int(torch.cuda.memory_stats().get("num_alloc_retries", 0))      # > 0: the caching allocator hit the limit and flushed
         if roll_stats.get("events"):
             # the north-star's "fused rollout forward": ViT + LLM prefill of every prompt (MFMA-bound), and the decode loop
             # (HBM-bound: packed weights + KV), each from HIP events on the launch stream inside the timed region
