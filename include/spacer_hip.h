@@ -232,6 +232,8 @@ int spacer_act_bwd(const void* x, const void* dy, void* dx, long n, int act, spa
 /* db[cols] (fp32, +=) = column sums of dy [rows, cols] bf16 */
 int spacer_bias_grad(const void* dy, long ld, float* db, int rows, int cols, spacer_stream_t stream);
 /* out_bf16 = f32 (cast), and f32 accumulate/copy helpers for attention grads */
+/* zero fill of `bytes` bytes on the stream (accumulators of the backward kernels, the flat gradient after the optimizer step) */
+int spacer_zero(void* p, long bytes, spacer_stream_t stream);
 int spacer_cast_f32_to_bf16(const float* in, void* out, long n, spacer_stream_t stream);
 int spacer_cast_bf16_to_f32(const void* in, float* out, long n, spacer_stream_t stream);
 /* out[i,:] = src[idx[i],:] (bf16) and dst[idx[i],:] += src[i,:] (bf16 -> fp32 atomics): select / scatter the hidden

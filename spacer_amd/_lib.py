@@ -58,6 +58,7 @@ SIGNATURES = {
     "spacer_act_fwd": [_p, _p, _l, _i, _p],
     "spacer_act_bwd": [_p, _p, _p, _l, _i, _p],
     "spacer_bias_grad": [_p, _l, _p, _i, _i, _p],
+    "spacer_zero": [_p, _l, _p],
     "spacer_cast_f32_to_bf16": [_p, _p, _l, _p],
     "spacer_cast_bf16_to_f32": [_p, _p, _l, _p],
     "spacer_cast_f32_to_bf16_strided": [_p, _l, _p, _l, _i, _i, _p],

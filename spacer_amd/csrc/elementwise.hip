@@ -417,6 +417,14 @@ extern "C" int spacer_embed_fwd(const int64_t* ids, const void* table, const voi
     SP_CHECK_LAUNCH();
     return SPACER_OK;
 }
+// zero fill of a device buffer on the launch stream (dK / dV accumulators of the attention backward, scatter targets, the flat
+// gradient): the runtime's fill kernel, so that a training step consists of this library's launches only
+extern "C" int spacer_zero(void* p, long bytes, spacer_stream_t stream) {
+    if (bytes <= 0) return SPACER_OK;
+    const hipError_t e = hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream);
+    SP_REQUIRE(e == hipSuccess, SPACER_ELAUNCH, "zero: hipMemsetAsync failed: %s", hipGetErrorString(e));
+    return SPACER_OK;
+}
 extern "C" int spacer_decode_embed(const int64_t* ids, const void* table, float* out, int B, int H, int* counter0, int* counter1,
                                    spacer_stream_t stream) {
     SP_REQUIRE(H % 8 == 0 && counter0, SPACER_EINVAL, "decode_embed: H must be a multiple of 8, counter0 non-null");

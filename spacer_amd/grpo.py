@@ -421,7 +421,7 @@ class GRPOEngine:
         lr = lr_at(self.step_count, h)
         self.step_count += 1
         gscale = 1.0 / world_size
-        self._sumsq.zero_()
+        K.zero_(self._sumsq)
         if self.sharded is not None:
             # rs_ag: this rank holds the summed gradient of ITS shard only -> global norm = all-reduce of the shards' sums of squares,
             # AdamW on the shard (master / moments of the other shards are never touched on this rank), all-gather of the bf16 weights
@@ -440,7 +440,7 @@ class GRPOEngine:
             K.adamw_step_(self.master.flat, self.policy.flat, self.m, self.v, self.G.flat, lr=lr, beta1=h.adam_beta1,
                           beta2=h.adam_beta2, eps=h.adam_eps, weight_decay=h.weight_decay, step=self.step_count,
                           sumsq=self._sumsq, max_norm=h.max_grad_norm, grad_scale=gscale)
-        self.G.flat.zero_()
+        K.zero_(self.G.flat)
         self.engine.invalidate_cache()
         self.roll.invalidate()
         return lr

@@ -424,6 +424,17 @@ def bias_grad_(dy, db32):
     return db32
 
 
+def zero_(t: torch.Tensor) -> torch.Tensor:
+    """In-place zero fill of a contiguous device tensor on the current stream (spacer_zero)."""
+    assert t.is_contiguous()
+    check(_lib.load().spacer_zero(_ptr(t), t.numel() * t.element_size(), _stream()), "zero")
+    return t
+
+
+def zeros(*shape, device, dtype=torch.float32) -> torch.Tensor:
+    return zero_(torch.empty(*shape, device=device, dtype=dtype))
+
+
 def cast_bf16(x32, *, out=None):
     if out is None:
         out = torch.empty(x32.shape, device=x32.device, dtype=BF16)

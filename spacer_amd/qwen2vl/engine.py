@@ -54,7 +54,7 @@ class Qwen2VLEngine:
         K.gemm(dy, x, trans_a=True, trans_b=True, out=gw, residual=gw)
 
     def _zeros(self, *shape, dtype=F32):
-        return torch.zeros(*shape, device=self.dev, dtype=dtype)
+        return K.zeros(*shape, device=self.dev, dtype=dtype)
 
     def _empty(self, *shape, dtype=F32):
         return torch.empty(*shape, device=self.dev, dtype=dtype)

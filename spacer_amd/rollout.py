@@ -201,7 +201,7 @@ class RolloutEngine:
             plen=torch.tensor(plen, dtype=torch.int32, device=dev),
             prompt_of=torch.arange(B, dtype=torch.int32, device=dev) // Kn,
             pos_base=torch.tensor(pos_base, dtype=torch.int32, device=dev).repeat_interleave(Kn).contiguous(),
-            tk=torch.zeros(L, B, C, Hkv, D, device=dev, dtype=BF16), tv=torch.zeros(L, B, C, Hkv, D, device=dev, dtype=BF16),
+            tk=K.zeros(L, B, C, Hkv, D, device=dev, dtype=BF16), tv=K.zeros(L, B, C, Hkv, D, device=dev, dtype=BF16),
             tail_len=torch.full((1,), -1, dtype=torch.int32, device=dev), step=torch.full((1,), -1, dtype=torch.int32, device=dev),
             finished=torch.zeros(B, dtype=torch.int32, device=dev), cur_tok=torch.empty(B, dtype=torch.int64, device=dev),
             x=torch.empty(B, H, device=dev, dtype=F32), h=torch.empty(B, H, device=dev, dtype=BF16),

@@ -59,9 +59,9 @@ def test_recompute_matches_the_stored_path(dev, which, groups):
     scale = float(g_a.abs().max())
     print(f"{which} x{groups}: |grad| max {scale:.3e}; stored vs stored {noise:.3e}; stored vs recompute {diff:.3e}")
     assert scale > 0
-    same = (g_a == g_b)
-    assert torch.equal(g_a[same], g_r[same]) or diff <= 4 * noise + 1e-7 * scale
-    assert diff <= 4 * noise + 1e-7 * scale
+    # two STORED runs already differ by the summation order of the backward's fp32 atomics (measured 0 ... 2.5e-4 of the gradient
+    # scale, run to run); the recompute run must sit inside the same band -- a wrong recomputed tensor would miss by O(1)
+    assert diff <= max(4 * noise, 1e-3 * scale), (diff, noise, scale)
 
 
 def test_recomputed_intermediates_are_bit_identical(dev):
