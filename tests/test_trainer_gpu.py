@@ -196,3 +196,29 @@ def test_gpu_front_end_equals_the_processor_route(dev, tmp_path):
         d = (a.pix.float() - b.pix.float()).abs()
         assert float((d > 0).float().mean()) < 1e-3 and float(d.max()) < 0.08, (float((d > 0).float().mean()), float(d.max()))
     assert not torch.equal(nat._prompt_input(pa["proc"]).pix, nat._prompt_input(pa["sproc"]).pix)      # the twin is shuffled
+
+
+def test_groups_per_pass_does_not_change_the_step(dev, tmp_path):
+    """Three gradient-accumulation micro-batches scored one per pass, two per pass ([2, 1]) and three per pass: the same rollouts
+    (same seeds), the same rewards and metrics, and the same update up to the summation order of the backward's atomics."""
+    g = load_tiny()
+    rows = _video_rows(3, seed0=70)
+    finals, logs = {}, {}
+    for gpp in (1, 2, 3):
+        params = FlatParams.empty(TINY, dev)
+        load_state_dict(params, g["w"])
+        out = tmp_path / f"gpp{gpp}"
+        args = GRPOConfig(output_dir=str(out), max_completion_length=6, num_generations=4, learning_rate=1e-4, max_steps=1,
+                          gradient_accumulation_steps=3, logging_steps=1, save_steps=0, seed=11, groups_per_pass=gpp)
+        trainer = SGRLVRTrainer(model=params, reward_funcs=[accuracy_reward, format_reward], args=args,
+                                script_args=GRPOScriptArguments(temporal=True, len_control=True), train_dataset=rows,
+                                processing_class=FakeProcessor(TINY), device=dev)
+        assert trainer.train()["global_step"] == 1
+        finals[gpp] = trainer.engine.master.flat.clone()
+        logs[gpp] = json.loads(open(os.path.join(str(out), "trainer_log.jsonl")).readline())
+    for gpp in (2, 3):
+        for key in ("completion_length", "rewards/accuracy_reward", "rewards/format_reward", "reward", "reward_std", "temporal_rewards"):
+            assert logs[gpp][key] == logs[1][key], (gpp, key)
+        assert abs(logs[gpp]["loss"] - logs[1]["loss"]) < 1e-5 and abs(logs[gpp]["kl"] - logs[1]["kl"]) < 1e-6
+        d = float((finals[gpp] - finals[1]).abs().max())
+        assert d <= 2.1e-4, d          # one AdamW step at lr 1e-4 moves a weight by <= 1e-4: sign flips of ~0 gradients bound the gap
