@@ -398,7 +398,7 @@ def main():
                 ge.score_and_backward(prompts[g0], comp[g0 * Kgen:(g0 + 1) * Kgen], advs[g0].to(dev), grad_scale=1.0 / groups, last_group=last)
             else:
                 ge.score_and_backward_multi([prompts[g] for g in gs], [comp[g * Kgen:(g + 1) * Kgen] for g in gs], [advs[g] for g in gs],
-                                            grad_scale=len(gs) / groups, last_group=last)
+                                            grad_scale=1.0 / groups, last_group=last)      # per-group weight
         t0 = tick("score+backward", t0)
         ge.reduce_gradients()
         ge.optimizer_step(world)

@@ -239,31 +239,45 @@ class ShardedExchange:
 
     def __init__(self, n: int, pg, *, wire_dtype: Optional[torch.dtype], bucket: int = 1 << 26):
         import torch.distributed as dist
-        self.pg, self.wire_dtype, self.bucket = pg, wire_dtype, bucket
+        self.pg, self.wire_dtype = pg, wire_dtype
         self.world, self.rank = dist.get_world_size(pg), dist.get_rank(pg)
         self.n = n
         self.S = ((n + self.world - 1) // self.world + 63) // 64 * 64
+        self.bucket = min(bucket, self.S)
         self.lo, self.hi = min(n, self.rank * self.S), min(n, (self.rank + 1) * self.S)
         self.native = dist.get_backend(pg) == "nccl"
+        self._bufs = {}          # (kind, dtype, device) -> wire buffers, allocated ONCE (world x bucket elements: ~1 GB at world 8)
 
     def shard(self, flat: torch.Tensor) -> torch.Tensor:
         return flat[self.lo:self.hi]
 
+    def _buf(self, kind: str, shape, dtype, dev) -> torch.Tensor:
+        key = (kind, dtype, str(dev))
+        b = self._bufs.get(key)
+        if b is None or tuple(b.shape) != tuple(shape):
+            b = self._bufs[key] = torch.empty(*shape, device=dev, dtype=dtype)
+        return b
+
     def reduce_scatter_(self, flat: torch.Tensor) -> None:
-        """flat[lo:hi] <- sum over ranks of flat[lo:hi] (the other shards of ``flat`` are left as they are: stale)."""
+        """flat[lo:hi] <- sum over ranks of flat[lo:hi] (the other shards of ``flat`` are left as they are: stale).  Runs after
+        the last backward: ``overlap_comm`` has no effect under rs_ag (the shards interleave every layer's range)."""
         import torch.distributed as dist
         W, S, n = self.world, self.S, self.n
         wd = self.wire_dtype or flat.dtype
         dev = flat.device if self.native else torch.device("cpu")
+        wire_full = self._buf("rs_wire", (W, self.bucket), wd, dev)
+        out_full = self._buf("rs_out", (self.bucket,), wd, dev)
         for b0 in range(0, S, self.bucket):
             bl = min(self.bucket, S - b0)
-            wire = torch.zeros(W, bl, device=dev, dtype=wd)
+            wire = wire_full if bl == self.bucket else wire_full.view(-1)[:W * bl].view(W, bl)
             for r in range(W):                                  # piece [b0, b0 + bl) of every rank's shard, clipped at n
                 a, e = min(n, r * S + b0), min(n, r * S + b0 + bl)
                 if e > a:
                     wire[r, :e - a].copy_(flat[a:e])
+                if e - a < bl:                                  # only the clipped tail of the last shard needs zeros
+                    wire[r, max(0, e - a):].zero_()
             if self.native:
-                out = torch.empty(bl, device=dev, dtype=wd)
+                out = out_full[:bl]
                 dist.reduce_scatter_tensor(out, wire.view(-1), group=self.pg)
             else:
                 works = [dist.reduce(wire[r], dst=dist.get_global_rank(self.pg, r), group=self.pg, async_op=True) for r in range(W)]
@@ -279,13 +293,17 @@ class ShardedExchange:
         import torch.distributed as dist
         W, S, n = self.world, self.S, self.n
         dev = flat.device if self.native else torch.device("cpu")
+        mine_full = self._buf("ag_mine", (self.bucket,), flat.dtype, dev)
+        full_full = self._buf("ag_full", (W, self.bucket), flat.dtype, dev)
         for b0 in range(0, S, self.bucket):
             bl = min(self.bucket, S - b0)
-            mine = torch.zeros(bl, device=dev, dtype=flat.dtype)
+            mine = mine_full[:bl]
             a, e = min(n, self.rank * S + b0), min(n, self.rank * S + b0 + bl)
             if e > a:
                 mine[:e - a].copy_(flat[a:e])
-            full = torch.empty(W, bl, device=dev, dtype=flat.dtype)
+            if e - a < bl:
+                mine[max(0, e - a):].zero_()
+            full = full_full if bl == self.bucket else full_full.view(-1)[:W * bl].view(W, bl)
             if self.native:
                 dist.all_gather_into_tensor(full.view(-1), mine, group=self.pg)
             else:
@@ -365,8 +383,9 @@ class GRPOEngine:
     def score_and_backward_multi(self, prompts: List[PromptInput], completions: List[torch.Tensor], advantages: List[torch.Tensor],
                                  grad_scale: float = 1.0, *, era_rule: bool = False, last_group: bool = False) -> Dict[str, torch.Tensor]:
         """``score_and_backward`` for several prompt groups in ONE scoring pass each for the reference and the policy and ONE
-        backward (Qwen2VLEngine.score_groups): the same gradients as calling it group by group -- the loss is the mean over
-        groups, each group's rows enter the loss kernel with 1/len(prompts) -- with G x the rows per kernel launch.
+        backward (Qwen2VLEngine.score_groups): the same gradients as calling it group by group WITH THE SAME ``grad_scale`` --
+        ``grad_scale`` is the weight of EACH group in the accumulated gradient (1 / gradient_accumulation_steps), not of the pass
+        -- with G x the rows per kernel launch.  The returned loss / kl are the means over the pass's groups.
         ``advantages`` may be a CALLABLE returning the list: it is invoked after both forward passes have been queued on the
         stream, so host-side reward functions (decode text -> regex / map scoring, TR:576-593) run while the GPU scores --
         the reference leaves the GPU idle there."""

@@ -214,6 +214,11 @@ class SGRLVRTrainer:
         self.total_steps = total_steps
         # ``engine``: an existing GRPOEngine over ``model`` (bench.py times the trainer on the engine it already holds: a second
         # copy of master weights + Adam state would not fit)
+        if engine is not None:
+            # an injected engine keeps ITS hyper-parameters: refuse a silent mismatch with what ``args`` asks for
+            for key in ("num_generations", "beta", "max_grad_norm"):
+                if getattr(engine.h, key) != getattr(hyper, key):
+                    raise ValueError(f"engine= was built with {key}={getattr(engine.h, key)!r} but args ask for {getattr(hyper, key)!r}")
         self.engine = engine if engine is not None else GRPOEngine(cfg, params, hyper, process_group=process_group)
         # micro-batches of a gradient-accumulation step scored / back-propagated per token-packed pass (GRPOEngine.
         # score_and_backward_multi): 2 = what 288 GB holds at 7B with 16-frame prompts and 512-token rollouts
@@ -435,20 +440,35 @@ class SGRLVRTrainer:
         shaped: List[Optional[dict]] = [None] * acc
         kls: List[Optional[torch.Tensor]] = [None] * acc
         losses = []
-        for j0 in range(0, acc, gpp):
-            js = list(range(j0, min(acc, j0 + gpp)))
+        # passes: consecutive micro-batches, at most ``gpp`` each, that either ALL carry vision inputs or none does (a token-packed
+        # pass runs one ViT over its groups, Qwen2VLEngine.score_groups); a text-only row next to a video row falls back to a
+        # pass of its own
+        passes: List[List[int]] = []
+        for j in range(acc):
+            vis = rolled[j]["prompt"].pix is not None
+            if passes and len(passes[-1]) < gpp and (rolled[passes[-1][0]]["prompt"].pix is not None) == vis:
+                passes[-1].append(j)
+            else:
+                passes.append([j])
+        if gpp > 1 and len(passes) > (acc + gpp - 1) // gpp and not getattr(self, "_warned_mixed_pass", False):
+            self._warned_mixed_pass = True
+            self._note("text-only and vision rows in one optimizer step: mixed neighbours are scored in separate passes")
+        for js in passes:
 
             def advantages(js=js):
                 for j in js:
                     shaped[j] = self._shape([rows[j]], preps[j], rolled[j])
                 return [shaped[j]["adv"] for j in js]
             last = js[-1] == acc - 1
+            # every micro-batch weighs 1 / acc in the accumulated gradient (HF Trainer divides each micro-batch loss by
+            # gradient_accumulation_steps): score_and_backward_multi's grad_scale is PER GROUP, whatever the pass holds
             if len(js) == 1:
+                j0 = js[0]
                 res = eng.score_and_backward(rolled[j0]["prompt"], rolled[j0]["completion_ids"], advantages, grad_scale=1.0 / acc,
                                              era_rule=self.era_rule, last_group=last)
             else:
                 res = eng.score_and_backward_multi([rolled[j]["prompt"] for j in js], [rolled[j]["completion_ids"] for j in js],
-                                                   advantages, grad_scale=len(js) / acc, era_rule=self.era_rule, last_group=last)
+                                                   advantages, grad_scale=1.0 / acc, era_rule=self.era_rule, last_group=last)
             for j in js:
                 kls[j] = res["kl"]              # a pass's KL is the mean over its groups: the logged step mean is unchanged
                 rolled[j] = None
@@ -530,7 +550,13 @@ class SGRLVRTrainer:
     def save_model(self, output_dir: Optional[str] = None, _internal_call: bool = False) -> None:
         """What HF ``Trainer.save_model`` leaves for the reference (open_r1/SG-RLVR.py:377-384): bf16 safetensors in the
         original Qwen2-VL / Qwen2.5-VL tensor names + config.json + tokenizer / processor files, loadable with
-        ``from_pretrained`` (qwen2vl/checkpoint.py), plus the step counter for --resume_from_checkpoint."""
+        ``from_pretrained`` (qwen2vl/checkpoint.py), plus the step counter for --resume_from_checkpoint.
+
+        COLLECTIVE when ``grad_algo == "rs_ag"`` and ``save_only_model`` is false: the fp32 master weights / Adam moments live in
+        the owner's shard only and are all-gathered here, so EVERY rank must call it (``train`` does); calling it on rank 0 only
+        -- the HF idiom -- would hang.  With the default all-reduce exchange, or ``save_only_model=True``, nothing is communicated
+        and a rank-0-only call is fine.  (Between saves under rs_ag, ``engine.master`` / ``m`` / ``v`` outside the rank's own shard
+        are stale by design.)"""
         if not self.args.save_only_model:
             self.engine.gather_optimizer_state()        # collective (grad_algo rs_ag keeps master / moments per shard): every rank
         if self.rank != 0:

@@ -200,10 +200,12 @@ def test_gpu_front_end_equals_the_processor_route(dev, tmp_path):
 
 def test_groups_per_pass_does_not_change_the_step(dev, tmp_path):
     """Three gradient-accumulation micro-batches scored one per pass, two per pass ([2, 1]) and three per pass: the same rollouts
-    (same seeds), the same rewards and metrics, and the same update up to the summation order of the backward's atomics."""
+    (same seeds), the same rewards and metrics, and -- compared BEFORE the optimizer (one Adam step is scale-invariant and would
+    hide a wrong micro-batch weight) -- the same accumulated gradient and gradient norm up to the summation order of the
+    backward's atomics: every micro-batch weighs 1 / gradient_accumulation_steps whatever the pass holds."""
     g = load_tiny()
     rows = _video_rows(3, seed0=70)
-    finals, logs = {}, {}
+    finals, logs, grads = {}, {}, {}
     for gpp in (1, 2, 3):
         params = FlatParams.empty(TINY, dev)
         load_state_dict(params, g["w"])
@@ -213,12 +215,41 @@ def test_groups_per_pass_does_not_change_the_step(dev, tmp_path):
         trainer = SGRLVRTrainer(model=params, reward_funcs=[accuracy_reward, format_reward], args=args,
                                 script_args=GRPOScriptArguments(temporal=True, len_control=True), train_dataset=rows,
                                 processing_class=FakeProcessor(TINY), device=dev)
+        inner = trainer.engine.optimizer_step
+
+        def spy(world=1, inner=inner, eng=trainer.engine, gpp=gpp):
+            grads[gpp] = eng.G.flat.clone()
+            return inner(world)
+        trainer.engine.optimizer_step = spy
         assert trainer.train()["global_step"] == 1
         finals[gpp] = trainer.engine.master.flat.clone()
         logs[gpp] = json.loads(open(os.path.join(str(out), "trainer_log.jsonl")).readline())
+    assert float(grads[1].norm()) > 0
     for gpp in (2, 3):
         for key in ("completion_length", "rewards/accuracy_reward", "rewards/format_reward", "reward", "reward_std", "temporal_rewards"):
             assert logs[gpp][key] == logs[1][key], (gpp, key)
         assert abs(logs[gpp]["loss"] - logs[1]["loss"]) < 1e-5 and abs(logs[gpp]["kl"] - logs[1]["kl"]) < 1e-6
+        rel = float((grads[gpp] - grads[1]).norm() / grads[1].norm())
+        assert rel < 2e-3, (gpp, rel)                                  # a 2x / (2/3, 2/3, 1/3) weighting gives 1.0 / 0.3 here
+        assert abs(logs[gpp]["grad_norm"] / logs[1]["grad_norm"] - 1.0) < 2e-3, (gpp, logs[gpp]["grad_norm"], logs[1]["grad_norm"])
         d = float((finals[gpp] - finals[1]).abs().max())
         assert d <= 2.1e-4, d          # one AdamW step at lr 1e-4 moves a weight by <= 1e-4: sign flips of ~0 gradients bound the gap
+
+
+def test_mixed_text_and_vision_rows_fall_back_to_separate_passes(dev, tmp_path):
+    """with groups_per_pass = 2 a text-only row next to a video row must not land in one token-packed pass (a pass
+    runs one ViT over its groups): the trainer splits such neighbours and still takes the step."""
+    g = load_tiny()
+    rows = _video_rows(2, seed0=90)
+    text_row = dict(rows[1], data_type="text", path="", prompt=[{"role": "user", "content": [{"type": "text", "text": "which one ?"}]}])
+    params = FlatParams.empty(TINY, dev)
+    load_state_dict(params, g["w"])
+    args = GRPOConfig(output_dir=str(tmp_path), max_completion_length=6, num_generations=4, learning_rate=1e-4, max_steps=1,
+                      gradient_accumulation_steps=2, logging_steps=1, save_steps=0, seed=5, groups_per_pass=2)
+    trainer = SGRLVRTrainer(model=params, reward_funcs=[accuracy_reward, format_reward], args=args,
+                            script_args=GRPOScriptArguments(temporal=False, len_control=True), train_dataset=[rows[0], text_row],
+                            processing_class=FakeProcessor(TINY), device=dev)
+    assert trainer.train()["global_step"] == 1
+    assert any("separate passes" in line for line in trainer._log_lines)
+    lg = json.loads(open(os.path.join(str(tmp_path), "trainer_log.jsonl")).readline())
+    assert lg["loss"] == lg["loss"] and lg["grad_norm"] > 0
