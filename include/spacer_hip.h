@@ -11,7 +11,8 @@
  *   - plain device pointers + sizes; no allocation, no ownership transfer, caller owns every buffer
  *   - asynchronous on `stream` (a hipStream_t passed as void*), no hidden synchronisation
  *   - bf16 = raw IEEE bfloat16 bits (uint16), row-major, innermost dimension contiguous unless an ld is given
- *   - no exceptions cross the boundary; re-entrant, no global mutable state
+ *   - no exceptions cross the boundary; re-entrant, no global mutable state, NO environment variables read: launch-plan
+ *     switches (tests, A/B runs, CU budgets) travel in an explicit spacer_plan passed by the caller
  */
 #ifndef SPACER_HIP_H
 #define SPACER_HIP_H
@@ -42,6 +43,18 @@ int spacer_version(void);
  * K must be a multiple of 64 (pad the contraction dim with zeros); M, N arbitrary.
  * out_f32 selects the dtype of C and residual (0 = bf16, 1 = fp32).  residual == C gives C += ...
  * ---------------------------------------------------------------------------------------------- */
+/* Launch-plan switches.  NULL (or a zeroed struct) = the defaults the benchmark runs with.  The Python layer fills one from the
+ * SPACER_* environment variables ONCE at import (spacer_amd/kernels.py:PLAN); the library itself never calls getenv. */
+typedef struct spacer_plan {
+    int gemm_tile;         /* 0 = cost model; 128 / 256 = force that tile kernel (tests run every shape through both) */
+    int gemm_no_split;     /* 1 = no split-K tail in the 256-tile GEMM: one fp32 summation order per output (bit-exact comparisons) */
+    int skinny_blocks;     /* decode GEMMs: target workgroups per launch; 0 = 2 x cus (one resident round); 1 = ONE K range per
+                            * column group, i.e. no split-K atomics (bit-reproducible rollouts) */
+    int skinny_no_balance; /* 1 = decode gate|up GEMM without the tail balance */
+    int cus;               /* compute units the launch may count on; 0 = 256 (all of MI355X).  A caller that runs a second,
+                            * CU-masked stream beside the decode loop passes the decode loop's share */
+} spacer_plan;
+
 typedef struct spacer_gemm_epilogue {
     const void* bias;     /* bf16 [N] or NULL */
     const void* residual; /* [M, ldr] in the output dtype, or NULL */
@@ -55,6 +68,7 @@ typedef struct spacer_gemm_epilogue {
      * NULL: the tail of the launch is not split. */
     void* workspace;
     long workspace_bytes;
+    const spacer_plan* plan; /* NULL = defaults */
 } spacer_gemm_epilogue;
 
 int spacer_gemm_bf16_nt(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
@@ -77,17 +91,17 @@ long spacer_gemm_workspace_bytes(void);
  *   act bf16 [M, inter] = silu(A.Wgate^T + bgate) * (A.Wup^T + bup);   gu bf16 [M, 2*inter] (or NULL) = the rounded gate|up.
  * Same bits as spacer_gemm_bf16_nt into gu + spacer_swiglu_fwd.  Only shapes the 256-tile kernel takes:
  * spacer_gemm_swiglu_fused(M, inter, K) != 0 (inter % 128 == 0, K % 64 == 0, large enough M); otherwise SPACER_EINVAL. */
-int spacer_gemm_swiglu_fused(int M, int inter, int K);
+int spacer_gemm_swiglu_fused(int M, int inter, int K, const spacer_plan* plan);
 int spacer_gemm_swiglu_bf16(const void* A, long lda, const void* W, long ldb, const void* bias, void* act, long ld_act, void* gu,
                             long ld_gu, int M, int inter, int K, spacer_stream_t stream);
 
 /* Which tile spacer_gemm_bf16_nt runs an [M,N,K] problem on: 256 (gemm_bf16_nt_256h_kernel) or 128 (gemm_bf16_nt_kernel).
  * Pure host function; profilers use it to attribute a launch to the kernel rocprof will name. */
-int spacer_gemm_tile(int M, int N, int K, int have_workspace);
+int spacer_gemm_tile(int M, int N, int K, int have_workspace, const spacer_plan* plan);
 
 /* Skinny GEMM for the decode loop (M <= 64 rows; <= 128 with packed weights; weights streamed once from HBM, split-K):
  * C32[M,N] += A[M,K] . B[N,K]^T  (fp32 atomics; C may be the fp32 residual stream itself).  K % 256 == 0.
- * epi must be NULL or {out_f32 = 1, residual = C}.  Replaces the per-token projections inside HF
+ * epi must be NULL or {out_f32 = 1, residual = C} (its ``plan`` is honoured).  Replaces the per-token projections inside HF
  * generate's loop (TR:463). */
 int spacer_gemm_skinny_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
                             const spacer_gemm_epilogue* epi, spacer_stream_t stream);
@@ -96,11 +110,11 @@ int spacer_gemm_skinny_bf16(const void* A, long lda, const void* B, long ldb, vo
  * the skinny GEMM is 1 KiB contiguous (N % 16 == 0, K % 32 == 0); rebuilt once per optimizer step. */
 int spacer_pack_weight_frag(const void* W, long ld, void* out, int N, int K, spacer_stream_t stream);
 int spacer_gemm_skinny_packed_bf16(const void* A, long lda, const void* Bpacked, void* C, long ldc, int M, int N, int K,
-                                   spacer_stream_t stream);
+                                   const spacer_plan* plan, spacer_stream_t stream);
 /* Store form, C32 = A . W^T (no accumulate, C needs no zero fill): only for wide N (>= 448 * 64 columns), where every workgroup
  * covers the whole K range -- the lm_head projection of the decode step (HF lm_head inside generate).  SPACER_EINVAL otherwise. */
 int spacer_gemm_skinny_packed_store_bf16(const void* A, long lda, const void* Bpacked, void* C, long ldc, int M, int N, int K,
-                                         spacer_stream_t stream);
+                                         const spacer_plan* plan, spacer_stream_t stream);
 
 /* Decode-loop MLP front half in one launch:  Y[M, inter] (bf16) = silu(A . Wgate^T) * (A . Wup^T)   (HF Qwen2MLP's
  * act_fn(gate_proj(x)) * up_proj(x) inside generate, TR:463).  W = [gate (inter rows) | up (inter rows)] x K is packed
@@ -115,7 +129,7 @@ int spacer_gemm_skinny_swiglu_bf16(const void* A, long lda, const void* Bpacked,
  * beside the whole-K blocks and meet through agent-scope atomics + a ticket (last arriver runs the SwiGLU epilogue). */
 long spacer_gemm_skinny_swiglu_workspace_bytes(void);
 int spacer_gemm_skinny_swiglu_bf16_ws(const void* A, long lda, const void* Bpacked, void* Y, long ldy, int M, int inter, int K,
-                                      void* workspace, long workspace_bytes, spacer_stream_t stream);
+                                      void* workspace, long workspace_bytes, const spacer_plan* plan, spacer_stream_t stream);
 
 /* out[C, Rpad] = in[R, C]^T, zero-filling columns R..Rpad-1 (bf16).  Feeds the NT GEMM in backward. */
 int spacer_transpose_bf16(const void* in, long ld_in, void* out, long ld_out, int R, int C, int Rpad,
@@ -214,7 +228,7 @@ int spacer_swiglu_f32_fwd(float* acc32, void* y, int B, int inter, spacer_stream
  *   normed finish: spacer_decode_qkv_finish with every sum scaled by rstd[b] = rsqrt(rowss[b] / norm_cols + eps) first;
  *                  rowss_zero[0..B) (the sums of the NEXT normed GEMM) is cleared, B <= 256 */
 int spacer_gemm_skinny_packed_normed(const float* X32, long ldx, const void* Bpacked, float* C32, long ldc, float* rowss, int M,
-                                     int N, int K, spacer_stream_t stream);
+                                     int N, int K, const spacer_plan* plan, spacer_stream_t stream);
 int spacer_decode_qkv_finish_normed(float* acc32, const void* bias, const float* cos_t, const float* sin_t, void* q_out,
                                     void* tail_k, void* tail_v, const int* tail_len_dev, const float* rowss, float* rowss_zero,
                                     int norm_cols, float eps, int B, int Hq, int Hkv, int D, int Cmax, spacer_stream_t stream);

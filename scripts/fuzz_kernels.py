@@ -88,7 +88,7 @@ def fuzz_swiglu(r):
     act, gu = K.gemm_swiglu(a, w, bias=bias, keep_gu=True)
     gu_ref = K.gemm_nt(a, w, bias=bias, split_k=False)
     if not torch.equal(gu, gu_ref) or not torch.equal(act, K.swiglu_fwd(gu_ref)):
-        raise AssertionError(f"MISMATCH gemm_swiglu {M}x{I}x{Kd} (fused={K._lib.load().spacer_gemm_swiglu_fused(M, I, Kd)})")
+        raise AssertionError(f"MISMATCH gemm_swiglu {M}x{I}x{Kd} (fused={K._lib.load().spacer_gemm_swiglu_fused(M, I, Kd, None)})")
 
 
 def fuzz_attention(r):

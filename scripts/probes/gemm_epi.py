@@ -15,4 +15,4 @@ for M, N, f32 in [(5498, 37888, False), (5498, 18944, False), (5498, 3584, True)
         for _ in range(5): K.gemm_nt(a, b, out=out)
         e1.record(); torch.cuda.synchronize()
         t = e0.elapsed_time(e1) / 5 * 1e-3
-        print(f"  {M:6d} {N:6d} K={Kd:5d} {'f32' if f32 else 'bf16'}: {t*1e6:8.1f} us  {2*M*N*Kd/t/1e12:7.1f} TF/s  tile {K._lib.load().spacer_gemm_tile(M, N, Kd, 1)}")
+        print(f"  {M:6d} {N:6d} K={Kd:5d} {'f32' if f32 else 'bf16'}: {t*1e6:8.1f} us  {2*M*N*Kd/t/1e12:7.1f} TF/s  tile {K._lib.load().spacer_gemm_tile(M, N, Kd, 1, None)}")

@@ -18,5 +18,5 @@ for M, N, Kd in shapes:
         for _ in range(10): K.gemm_nt(a, b, out=out, split_k=split)
         e1.record(); torch.cuda.synchronize()
         t = e0.elapsed_time(e1) / 10 * 1e-3
-        res.append((K._lib.load().spacer_gemm_tile(M, N, Kd, int(split)), 2 * M * N * Kd / t / 1e12, t * 1e6))
+        res.append((K._lib.load().spacer_gemm_tile(M, N, Kd, int(split), None), 2 * M * N * Kd / t / 1e12, t * 1e6))
     print(f"  {M:6d} {N:6d} {Kd:6d}: split tile{res[0][0]} {res[0][1]:7.1f} TF/s {res[0][2]:8.1f} us | nosplit tile{res[1][0]} {res[1][1]:7.1f} TF/s {res[1][2]:8.1f} us")

@@ -16,4 +16,4 @@ for M, N, Kd in shapes:
     for i in range(20): K.gemm_nt(a[i % 4], b[i % 4], out=out)
     e1.record(); torch.cuda.synchronize()
     t = e0.elapsed_time(e1) / 20 * 1e-3
-    print(f"  {M:6d} {N:6d} {Kd:6d}: tile {K._lib.load().spacer_gemm_tile(M, N, Kd, 1)}  {2 * M * N * Kd / t / 1e12:7.1f} TF/s {t * 1e6:8.1f} us")
+    print(f"  {M:6d} {N:6d} {Kd:6d}: tile {K._lib.load().spacer_gemm_tile(M, N, Kd, 1, None)}  {2 * M * N * Kd / t / 1e12:7.1f} TF/s {t * 1e6:8.1f} us")

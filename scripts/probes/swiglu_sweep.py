@@ -14,8 +14,7 @@ for I in (12288, 16384, 16416, 16640, 16896, 17408, 17920, 18432, 18944, 20480, 
     out = torch.empty(M, I, device=dev, dtype=torch.bfloat16)
     res = []
     for nb in (None, "1"):
-        if nb: os.environ["SPACER_SKINNY_NOBALANCE"] = nb
-        else: os.environ.pop("SPACER_SKINNY_NOBALANCE", None)
+        K.PLAN.skinny_no_balance = 1 if nb else 0
         for i in range(3): K.gemm_skinny_swiglu(a, ws[i], I, out=out)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -23,6 +22,6 @@ for I in (12288, 16384, 16416, 16640, 16896, 17408, 17920, 18432, 18944, 20480, 
         for r in range(30): K.gemm_skinny_swiglu(a, ws[r % 3], I, out=out)
         e1.record(); torch.cuda.synchronize()
         res.append(e0.elapsed_time(e1) / 30 * 1e3)
-    os.environ.pop("SPACER_SKINNY_NOBALANCE", None)
+    K.PLAN.skinny_no_balance = 0
     print(f"  I={I:6d} col groups {N // 64:4d}: balanced {res[0]:6.1f} us ({N * Kd * 2 / res[0] / 1e6:5.2f} TB/s)   plain {res[1]:6.1f} us ({N * Kd * 2 / res[1] / 1e6:5.2f} TB/s)", flush=True)
     del ws

@@ -19,9 +19,16 @@ class SpacerError(RuntimeError):
     pass
 
 
+class Plan(C.Structure):
+    """include/spacer_hip.h: spacer_plan -- launch-plan switches handed to the library explicitly (it reads no environment)."""
+    _fields_ = [("gemm_tile", C.c_int), ("gemm_no_split", C.c_int), ("skinny_blocks", C.c_int), ("skinny_no_balance", C.c_int),
+                ("cus", C.c_int)]
+
+
 class GemmEpilogue(C.Structure):
     _fields_ = [("bias", C.c_void_p), ("residual", C.c_void_p), ("ldr", C.c_long), ("out_f32", C.c_int),
-                ("act", C.c_int), ("alpha", C.c_float), ("workspace", C.c_void_p), ("workspace_bytes", C.c_long)]
+                ("act", C.c_int), ("alpha", C.c_float), ("workspace", C.c_void_p), ("workspace_bytes", C.c_long),
+                ("plan", C.POINTER(Plan))]
 
 
 class AttnSegment(C.Structure):
@@ -36,11 +43,11 @@ SIGNATURES = {
     "spacer_gemm_bf16": [_p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _i, C.POINTER(GemmEpilogue), _p],
     "spacer_gemm_skinny_bf16": [_p, _l, _p, _l, _p, _l, _i, _i, _i, C.POINTER(GemmEpilogue), _p],
     "spacer_pack_weight_frag": [_p, _l, _p, _i, _i, _p],
-    "spacer_gemm_skinny_packed_bf16": [_p, _l, _p, _p, _l, _i, _i, _i, _p],
-    "spacer_gemm_skinny_packed_store_bf16": [_p, _l, _p, _p, _l, _i, _i, _i, _p],
+    "spacer_gemm_skinny_packed_bf16": [_p, _l, _p, _p, _l, _i, _i, _i, C.POINTER(Plan), _p],
+    "spacer_gemm_skinny_packed_store_bf16": [_p, _l, _p, _p, _l, _i, _i, _i, C.POINTER(Plan), _p],
     "spacer_pack_weight_frag_swiglu": [_p, _l, _p, _i, _i, _p],
     "spacer_gemm_skinny_swiglu_bf16": [_p, _l, _p, _p, _l, _i, _i, _i, _p],
-    "spacer_gemm_skinny_swiglu_bf16_ws": [_p, _l, _p, _p, _l, _i, _i, _i, _p, _l, _p],
+    "spacer_gemm_skinny_swiglu_bf16_ws": [_p, _l, _p, _p, _l, _i, _i, _i, _p, _l, C.POINTER(Plan), _p],
     "spacer_transpose_bf16": [_p, _l, _p, _l, _i, _i, _i, _p],
     "spacer_rmsnorm_fwd": [_p, _i, _p, _p, _p, _i, _i, _f, _p],
     "spacer_rmsnorm_bwd": [_p, _i, _p, _p, _p, _p, _i, _p, _i, _i, _p],
@@ -80,7 +87,7 @@ SIGNATURES = {
     "spacer_decode_rope_table": [_p, _p, _f, _p, _p, _i, _i, _p],
     "spacer_decode_qkv_finish": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "spacer_decode_qkv_finish_normed": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _f, _i, _i, _i, _i, _i, _p],
-    "spacer_gemm_skinny_packed_normed": [_p, _l, _p, _p, _l, _p, _i, _i, _i, _p],
+    "spacer_gemm_skinny_packed_normed": [_p, _l, _p, _p, _l, _p, _i, _i, _i, C.POINTER(Plan), _p],
     "spacer_swiglu_f32_fwd": [_p, _p, _i, _i, _p],
     "spacer_gemm_swiglu_bf16": [_p, _l, _p, _l, _p, _p, _l, _p, _l, _i, _i, _i, _p],
     "spacer_resize_bicubic_aa_u8": [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _i, _p, _p],
@@ -121,9 +128,9 @@ def load() -> C.CDLL:
     lib.spacer_version.restype = C.c_int
     lib.spacer_sample_workspace_bytes.argtypes = [_i, _i]
     lib.spacer_sample_workspace_bytes.restype = C.c_long
-    lib.spacer_gemm_tile.argtypes = [_i, _i, _i, _i]
+    lib.spacer_gemm_tile.argtypes = [_i, _i, _i, _i, C.POINTER(Plan)]
     lib.spacer_gemm_tile.restype = _i
-    lib.spacer_gemm_swiglu_fused.argtypes = [_i, _i, _i]
+    lib.spacer_gemm_swiglu_fused.argtypes = [_i, _i, _i, C.POINTER(Plan)]
     lib.spacer_gemm_swiglu_fused.restype = _i
     lib.spacer_gemm_workspace_bytes.argtypes = []
     lib.spacer_gemm_workspace_bytes.restype = C.c_long

@@ -720,8 +720,14 @@ __global__ __launch_bounds__(REP * 128) void attn_decode_merge_kernel(const floa
 
 }  // namespace
 
+// launch-plan helpers: the resident workgroup slots of a decode GEMM launch are 2 per CU of the caller's CU budget
+static inline int plan_cus(const spacer_plan* plan) { return plan && plan->cus > 0 ? plan->cus : 256; }
+static inline int skinny_target_blocks(const spacer_plan* plan) {
+    return plan && plan->skinny_blocks > 0 ? plan->skinny_blocks : 2 * plan_cus(plan);
+}
+
 static int launch_skinny(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
-                         const spacer_gemm_epilogue* epi, bool packed, hipStream_t s, bool overwrite = false) {
+                         const spacer_gemm_epilogue* epi, bool packed, const spacer_plan* plan, hipStream_t s, bool overwrite = false) {
     SP_REQUIRE(A && B && C, SPACER_EINVAL, "gemm_skinny: null operand");
     SP_REQUIRE(M > 0 && M <= (packed ? 128 : 64), SPACER_EINVAL, "gemm_skinny: M=%d must be in 1..%d", M, packed ? 128 : 64);
     SP_REQUIRE(K % 256 == 0, SPACER_EINVAL, "gemm_skinny: K=%d must be a multiple of 256", K);
@@ -733,13 +739,11 @@ static int launch_skinny(const void* A, long lda, const void* B, long ldb, void*
     // K ranges: 1 (no atomics) when the column groups alone fill the chip, else just enough ranges for ~2 workgroups / CU
     const int col_groups = cdiv(N, 64), slices = K / KSv;
     int ranges = 1;
-    // SPACER_SKINNY_BLOCKS=1 forces one K range per column group (no atomics: bit-reproducible sums); read per call so
-    // a test can switch it
-    const char* tb = getenv("SPACER_SKINNY_BLOCKS");
-    const int target_blocks = tb ? atoi(tb) : 512;
+    // spacer_plan::skinny_blocks = 1 forces one K range per column group (no atomics: bit-reproducible sums)
+    const int target_blocks = skinny_target_blocks(plan);
     // as many K ranges as keep the whole launch in ONE resident round (2 workgroups x 256 CUs): down-proj at 7B (56 column
     // groups x 74 slices) ran as 560 blocks = a full round + a 48-block tail before; now 9 ranges = 504 blocks
-    if (col_groups < 448) ranges = max(1, min(slices, target_blocks / col_groups));
+    if (col_groups < target_blocks - target_blocks / 8) ranges = max(1, min(slices, target_blocks / col_groups));
     const int spr = cdiv(slices, ranges);
     ranges = cdiv(slices, spr);
     SP_REQUIRE(!overwrite || ranges == 1, SPACER_EINVAL, "gemm_skinny: C = A.B^T (store form) needs whole-K workgroups; N=%d splits K %d ways", N, ranges);
@@ -759,25 +763,24 @@ static int launch_skinny(const void* A, long lda, const void* B, long ldb, void*
 
 extern "C" int spacer_gemm_skinny_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N,
                                        int K, const spacer_gemm_epilogue* epi, spacer_stream_t stream) {
-    return launch_skinny(A, lda, B, ldb, C, ldc, M, N, K, epi, false, (hipStream_t)stream);
+    return launch_skinny(A, lda, B, ldb, C, ldc, M, N, K, epi, false, epi ? epi->plan : nullptr, (hipStream_t)stream);
 }
 
 extern "C" int spacer_gemm_skinny_packed_bf16(const void* A, long lda, const void* Bpacked, void* C, long ldc, int M, int N,
-                                              int K, spacer_stream_t stream) {
-    return launch_skinny(A, lda, Bpacked, 0, C, ldc, M, N, K, nullptr, true, (hipStream_t)stream);
+                                              int K, const spacer_plan* plan, spacer_stream_t stream) {
+    return launch_skinny(A, lda, Bpacked, 0, C, ldc, M, N, K, nullptr, true, plan, (hipStream_t)stream);
 }
 
 // C32[M,N] += bf16(X32[M,K]) . Wp[N,K]^T and rowss[m] += sum_k X32[m,k]^2: the K-split decode projection with the RMSNorm in
 // front of it folded in (see gemm_skinny_kernel NORMA); Wp = packed W diag(w_norm).  M <= 64.
 extern "C" int spacer_gemm_skinny_packed_normed(const float* X32, long ldx, const void* Bpacked, float* C, long ldc, float* rowss,
-                                                int M, int N, int K, spacer_stream_t stream) {
+                                                int M, int N, int K, const spacer_plan* plan, spacer_stream_t stream) {
     SP_REQUIRE(X32 && Bpacked && C && rowss, SPACER_EINVAL, "gemm_skinny_normed: null operand");
     SP_REQUIRE(M > 0 && M <= 64 && K % 256 == 0 && N % 16 == 0 && ldx % 4 == 0, SPACER_EINVAL,
                "gemm_skinny_normed: need 0 < M <= 64, K %% 256 == 0, N %% 16 == 0, ldx %% 4 == 0 (M=%d N=%d K=%d)", M, N, K);
     const int col_groups = cdiv(N, 64), slices = K / 256;
-    const char* tb = getenv("SPACER_SKINNY_BLOCKS");
-    const int target_blocks = tb ? atoi(tb) : 512;
-    int ranges = col_groups < 448 ? max(1, min(slices, target_blocks / col_groups)) : 1;
+    const int target_blocks = skinny_target_blocks(plan);
+    int ranges = col_groups < target_blocks - target_blocks / 8 ? max(1, min(slices, target_blocks / col_groups)) : 1;
     const int spr = cdiv(slices, ranges);
     ranges = cdiv(slices, spr);
     hipLaunchKernelGGL((gemm_skinny_kernel<true, false, 1, true>), dim3(col_groups, ranges), dim3(256), 0, (hipStream_t)stream,
@@ -788,8 +791,8 @@ extern "C" int spacer_gemm_skinny_packed_normed(const float* X32, long ldx, cons
 }
 
 extern "C" int spacer_gemm_skinny_packed_store_bf16(const void* A, long lda, const void* Bpacked, void* C, long ldc, int M, int N,
-                                                    int K, spacer_stream_t stream) {
-    return launch_skinny(A, lda, Bpacked, 0, C, ldc, M, N, K, nullptr, true, (hipStream_t)stream, true);
+                                                    int K, const spacer_plan* plan, spacer_stream_t stream) {
+    return launch_skinny(A, lda, Bpacked, 0, C, ldc, M, N, K, nullptr, true, plan, (hipStream_t)stream, true);
 }
 
 extern "C" int spacer_pack_weight_frag(const void* W, long ld, void* out, int N, int K, spacer_stream_t stream) {
@@ -817,7 +820,7 @@ constexpr int SWIGLU_MAX_SPLIT_GROUPS = 256;
 extern "C" long spacer_gemm_skinny_swiglu_workspace_bytes(void) { return (long)SWIGLU_MAX_SPLIT_GROUPS * (64 * 64 * 4 + 4); }
 
 static int launch_skinny_swiglu(const void* A, long lda, const void* Bpacked, void* Y, long ldy, int M, int inter, int K, void* ws,
-                                long ws_bytes, hipStream_t stream) {
+                                long ws_bytes, const spacer_plan* plan, hipStream_t stream) {
     SP_REQUIRE(A && Bpacked && Y, SPACER_EINVAL, "gemm_skinny_swiglu: null operand");
     SP_REQUIRE(M > 0 && M <= 128, SPACER_EINVAL, "gemm_skinny_swiglu: M=%d must be in 1..128", M);
     SP_REQUIRE(K % 256 == 0 && inter % 32 == 0 && lda % 8 == 0, SPACER_EINVAL,
@@ -831,9 +834,9 @@ static int launch_skinny_swiglu(const void* A, long lda, const void* Bpacked, vo
     }
     // tail balance: the column groups beyond the last full round of 512 resident workgroups, when that tail is short
     int split_groups = 0, split_ranges = 1;
-    const int slots = 512, rem = col_groups % slots, slices = K / 256;
-    const bool enabled = ws && ws_bytes >= spacer_gemm_skinny_swiglu_workspace_bytes() && getenv("SPACER_SKINNY_NOBALANCE") == nullptr
-                         && getenv("SPACER_SKINNY_BLOCKS") == nullptr && N % 64 == 0;
+    const int slots = 2 * plan_cus(plan), rem = col_groups % slots, slices = K / 256;
+    const bool enabled = ws && ws_bytes >= spacer_gemm_skinny_swiglu_workspace_bytes() && !(plan && plan->skinny_no_balance)
+                         && !(plan && plan->skinny_blocks) && N % 64 == 0;
     if (enabled && col_groups > slots && rem > 0 && rem <= 192 && rem <= SWIGLU_MAX_SPLIT_GROUPS && slices >= 4) {
         split_groups = rem;
         const int want = min(slices / 2, max(2, slots / rem));                // >= 2 K slices per range, about one round of small blocks
@@ -852,12 +855,13 @@ static int launch_skinny_swiglu(const void* A, long lda, const void* Bpacked, vo
 
 extern "C" int spacer_gemm_skinny_swiglu_bf16(const void* A, long lda, const void* Bpacked, void* Y, long ldy, int M, int inter,
                                               int K, spacer_stream_t stream) {
-    return launch_skinny_swiglu(A, lda, Bpacked, Y, ldy, M, inter, K, nullptr, 0, (hipStream_t)stream);
+    return launch_skinny_swiglu(A, lda, Bpacked, Y, ldy, M, inter, K, nullptr, 0, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int spacer_gemm_skinny_swiglu_bf16_ws(const void* A, long lda, const void* Bpacked, void* Y, long ldy, int M, int inter,
-                                                 int K, void* workspace, long workspace_bytes, spacer_stream_t stream) {
-    return launch_skinny_swiglu(A, lda, Bpacked, Y, ldy, M, inter, K, workspace, workspace_bytes, (hipStream_t)stream);
+                                                 int K, void* workspace, long workspace_bytes, const spacer_plan* plan,
+                                                 spacer_stream_t stream) {
+    return launch_skinny_swiglu(A, lda, Bpacked, Y, ldy, M, inter, K, workspace, workspace_bytes, plan, (hipStream_t)stream);
 }
 
 extern "C" int spacer_decode_rope_table(const int* pos_base, const int* step_dev, float theta, float* cos_t, float* sin_t,

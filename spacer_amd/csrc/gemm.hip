@@ -318,10 +318,9 @@ static void tail_plan(long tiles, int nt, bool have_ws, int* full, int* splits) 
 
 // Tile choice, wave-quantisation aware.  Cost in units of one 256x256 tile on one CU: the 256 tile runs one workgroup
 // per CU (256 slots), the 128 tile two (512 slots) and is ~25 % slower per FLOP, i.e. 0.625 per round.
-// SPACER_GEMM_TILE=128|256 forces one of them (tests run every shape through both).
-static int choose_tile(int M, int N, int K, bool have_ws) {
-    static const char* force = getenv("SPACER_GEMM_TILE");
-    if (force) return atoi(force) >= 256 ? 256 : 128;
+// spacer_plan::gemm_tile = 128 | 256 forces one of them (tests run every shape through both).
+static int choose_tile(int M, int N, int K, bool have_ws, const spacer_plan* plan) {
+    if (plan && plan->gemm_tile) return plan->gemm_tile >= 256 ? 256 : 128;
     const long tiles256 = (long)cdiv(M, 256) * cdiv(N, 256);
     const long tiles128 = (long)cdiv(M, 128) * cdiv(N, 128);
     int full, splits;
@@ -335,7 +334,9 @@ static int choose_tile(int M, int N, int K, bool have_ws) {
 
 extern "C" long spacer_gemm_workspace_bytes(void) { return WS_MAX_SLABS * WS_SLAB_BYTES + WS_TAIL_BYTES; }
 
-extern "C" int spacer_gemm_tile(int M, int N, int K, int have_workspace) { return choose_tile(M, N, K, have_workspace != 0); }
+extern "C" int spacer_gemm_tile(int M, int N, int K, int have_workspace, const spacer_plan* plan) {
+    return choose_tile(M, N, K, have_workspace != 0, plan);
+}
 
 static int launch_gemm(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K, bool ta, bool tb,
                        const spacer_gemm_epilogue* epi, spacer_stream_t stream) {
@@ -364,7 +365,8 @@ static int launch_gemm(const void* A, long lda, const void* B, long ldb, void* C
     const bool have_ws = epi && epi->workspace && epi->workspace_bytes >= spacer_gemm_workspace_bytes();
     SP_REQUIRE(!(epi && epi->workspace) || ((uintptr_t)epi->workspace % 16) == 0, SPACER_EINVAL, "gemm: workspace misaligned");
     // the contraction-major operand forms exist on the 256 tile only
-    const bool big = tb || choose_tile(M, N, K, have_ws) == 256;
+    const spacer_plan* plan = epi ? epi->plan : nullptr;
+    const bool big = tb || choose_tile(M, N, K, have_ws, plan) == 256;
     hipStream_t s = (hipStream_t)stream;
     if (ta && K % BK != 0) {
         // ragged contraction length: the last K % 64 rows of both operands go to zero-padded 64-row tail buffers
@@ -389,7 +391,7 @@ static int launch_gemm(const void* A, long lda, const void* B, long ldb, void* C
         (void)once;
         g.tiles_m = cdiv(M, 256); g.tiles_n = cdiv(N, 256);
         const long tiles = (long)g.tiles_m * g.tiles_n;
-        const char* nosplit = getenv("SPACER_GEMM_NOSPLIT");       // per call: tests switch the K-split tail off for bit-exact comparisons
+        const bool nosplit = plan && plan->gemm_no_split;           // tests switch the K-split tail off for bit-exact comparisons
         tail_plan(tiles, cdiv(K, BK), have_ws && !nosplit, &g.full_tiles, &g.splits);
         g.slabs = have_ws ? (float*)epi->workspace : nullptr;
         const long tail_tiles = tiles - g.full_tiles;
@@ -430,15 +432,15 @@ extern "C" int spacer_gemm_bf16(const void* A, long lda, const void* B, long ldb
 // [M, 2I], may be NULL) additionally receives the rounded gate|up values the backward pass needs.  Bit-identical to
 // spacer_gemm_bf16_nt into gu followed by spacer_swiglu_fwd.  Returns SPACER_EINVAL when the problem would not run on the
 // 256 tile (spacer_gemm_swiglu_fused(M, inter, K) == 0): the caller then takes the two-step path.
-extern "C" int spacer_gemm_swiglu_fused(int M, int inter, int K) {
-    return inter > 0 && inter % 128 == 0 && K % BK == 0 && choose_tile(M, 2 * inter, K, false) == 256;
+extern "C" int spacer_gemm_swiglu_fused(int M, int inter, int K, const spacer_plan* plan) {
+    return inter > 0 && inter % 128 == 0 && K % BK == 0 && choose_tile(M, 2 * inter, K, false, plan) == 256;
 }
 
 extern "C" int spacer_gemm_swiglu_bf16(const void* A, long lda, const void* W, long ldb, const void* bias, void* act, long ld_act,
                                        void* gu, long ld_gu, int M, int inter, int K, spacer_stream_t stream) {
     SP_REQUIRE(A && W && act, SPACER_EINVAL, "gemm_swiglu: null operand");
     SP_REQUIRE(M > 0 && inter > 0 && K > 0, SPACER_EINVAL, "gemm_swiglu: empty shape M=%d I=%d K=%d", M, inter, K);
-    SP_REQUIRE(spacer_gemm_swiglu_fused(M, inter, K), SPACER_EINVAL,
+    SP_REQUIRE(inter > 0 && inter % 128 == 0 && K % BK == 0, SPACER_EINVAL,
                "gemm_swiglu: M=%d I=%d K=%d does not run on the 256 tile (I %% 128, K %% %d); use gemm + swiglu_fwd", M, inter, K, BK);
     SP_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ld_act % 4 == 0 && (!gu || ld_gu % 4 == 0), SPACER_EINVAL, "gemm_swiglu: leading dimensions");
     SP_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)act % 8) == 0 && ((uintptr_t)gu % 8) == 0, SPACER_EINVAL,

@@ -321,13 +321,12 @@ class GRPOEngine:
     """Owns policy + frozen reference weights, fp32 master / Adam state / gradients, and runs the step phases."""
 
     def __init__(self, cfg: Qwen2VLConfig, policy: FlatParams, hyper: GRPOHyper, *, ref: Optional[FlatParams] = None,
-                 process_group=None, cache_wT: bool = True):
+                 process_group=None):
         self.cfg, self.h = cfg, hyper
         self.dev = policy.flat.device
         self.policy = policy
         self.ref = ref if ref is not None else FlatParams(cfg, policy.flat.clone(), policy.specs)   # create_reference_model
-        # W^T copies for the dX GEMMs are kept for the whole optimizer step (all prompt groups reuse them): +1x weights
-        self.engine = Qwen2VLEngine(cfg, self.policy, cache_wT=cache_wT, recompute=hyper.recompute)
+        self.engine = Qwen2VLEngine(cfg, self.policy, recompute=hyper.recompute)
         self.ref_engine = Qwen2VLEngine(cfg, self.ref)
         self.roll = RolloutEngine(self.engine)
         self.master = FlatParams(cfg, policy.flat.float(), policy.specs)
@@ -460,7 +459,6 @@ class GRPOEngine:
                           beta2=h.adam_beta2, eps=h.adam_eps, weight_decay=h.weight_decay, step=self.step_count,
                           sumsq=self._sumsq, max_norm=h.max_grad_norm, grad_scale=gscale)
         K.zero_(self.G.flat)
-        self.engine.invalidate_cache()
         self.roll.invalidate()
         return lr
 

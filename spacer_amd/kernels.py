@@ -13,10 +13,42 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib
+import contextlib
+
 from ._lib import (SPACER_ACT_GELU_ERF, SPACER_ACT_NONE, SPACER_ACT_QUICK_GELU, SPACER_ACT_SILU,  # noqa: F401
-                   AttnSegment, GemmEpilogue, SpacerError, check)
+                   AttnSegment, GemmEpilogue, Plan, SpacerError, check)
 
 BF16 = torch.bfloat16
+
+
+def _plan_from_env() -> Plan:
+    """The SPACER_* launch-plan switches (README.md), read ONCE here: libspacer_hip.so reads no environment variables -- every
+    launch that has a plan gets this struct (include/spacer_hip.h: spacer_plan).  Tests change it with ``plan(...)``."""
+    e = os.environ
+    return Plan(gemm_tile=int(e.get("SPACER_GEMM_TILE", "0") or 0), gemm_no_split=int(bool(e.get("SPACER_GEMM_NOSPLIT"))),
+                skinny_blocks=int(e.get("SPACER_SKINNY_BLOCKS", "0") or 0), skinny_no_balance=int(bool(e.get("SPACER_SKINNY_NOBALANCE"))),
+                cus=int(e.get("SPACER_CUS", "0") or 0))
+
+
+PLAN = _plan_from_env()
+SWIGLU_UNFUSED = bool(os.environ.get("SPACER_GEMM_SWIGLU_UNFUSED"))      # A/B runs: gate|up GEMM + separate SwiGLU launch
+
+
+def _plan():
+    return C.byref(PLAN)
+
+
+@contextlib.contextmanager
+def plan(**fields):
+    """Temporarily change launch-plan switches, e.g. ``with K.plan(gemm_no_split=1): ...`` (bit-exact comparisons in tests)."""
+    old = {k: getattr(PLAN, k) for k in fields}
+    for k, v in fields.items():
+        setattr(PLAN, k, int(v))
+    try:
+        yield PLAN
+    finally:
+        for k, v in old.items():
+            setattr(PLAN, k, v)
 
 
 def _stream() -> C.c_void_p:
@@ -112,6 +144,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = N
     if split_k:
         ws = _gemm_workspace(a.device)
         epi.workspace, epi.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    epi.plan = C.pointer(PLAN)
     t0 = PROFILER.begin()
     check(_lib.load().spacer_gemm_bf16_nt(_ptr(a), _rowmajor(a), _ptr(b), _rowmajor(b), _ptr(out), _rowmajor(out),
                                           M, N, K, C.byref(epi), _stream()), "gemm_bf16_nt")
@@ -121,7 +154,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = N
         # epilogue, persistent workgroups)
         stg = "true" if (out.dtype == BF16 and residual is None) else "false"
         name = (f"gemm_bf16_nt_256h_kernel<true, false, false, {stg}>"
-                if _lib.load().spacer_gemm_tile(M, N, K, 1 if split_k else 0) == 256 else "gemm_bf16_nt_kernel")
+                if _lib.load().spacer_gemm_tile(M, N, K, 1 if split_k else 0, _plan()) == 256 else "gemm_bf16_nt_kernel")
         PROFILER.end(name, t0, 2.0 * M * N * ka, 2.0 * (M * ka + N * ka) + out.element_size() * M * N)
     if PROFILER.by_shape and t0 is not None:
         s0, e0 = PROFILER.records[-1][1], PROFILER.records[-1][2]
@@ -149,6 +182,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, trans_b: bo
                        1 if out.dtype == torch.float32 else 0, SPACER_ACT_NONE, alpha)
     ws = _gemm_workspace(a.device)
     epi.workspace, epi.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    epi.plan = C.pointer(PLAN)
     t0 = PROFILER.begin()
     check(_lib.load().spacer_gemm_bf16(_ptr(a), _rowmajor(a), _ptr(b), _rowmajor(b), _ptr(out), _rowmajor(out), M, N, Kc,
                                        int(trans_a), int(trans_b), C.byref(epi), _stream()), "gemm_bf16")
@@ -171,7 +205,7 @@ def gemm_swiglu(a: torch.Tensor, w_gu: torch.Tensor, *, bias=None, keep_gu: bool
     M, K = a.shape
     two_i = w_gu.shape[0]
     inter = two_i // 2
-    if not _lib.load().spacer_gemm_swiglu_fused(M, inter, K) or os.environ.get("SPACER_GEMM_SWIGLU_UNFUSED"):   # env: A/B runs
+    if not _lib.load().spacer_gemm_swiglu_fused(M, inter, K, _plan()) or SWIGLU_UNFUSED:
         gu = gemm_nt(a, w_gu, bias=bias)
         return swiglu_fwd(gu), (gu if keep_gu else None)
     act = torch.empty(M, inter, device=a.device, dtype=BF16)
@@ -194,8 +228,10 @@ def gemm_skinny_acc(a: torch.Tensor, b: torch.Tensor, c32: torch.Tensor) -> torc
     M, K = a.shape
     N = b.shape[0]
     assert c32.dtype == torch.float32 and a.dtype == BF16 and b.dtype == BF16
+    epi = GemmEpilogue(None, _ptr(c32), _rowmajor(c32), 1, SPACER_ACT_NONE, 1.0)
+    epi.plan = C.pointer(PLAN)
     check(_lib.load().spacer_gemm_skinny_bf16(_ptr(a), _rowmajor(a), _ptr(b), _rowmajor(b), _ptr(c32), _rowmajor(c32),
-                                              M, N, K, None, _stream()), "gemm_skinny_bf16")
+                                              M, N, K, C.byref(epi), _stream()), "gemm_skinny_bf16")
     return c32
 
 
@@ -213,7 +249,7 @@ def gemm_skinny_packed_acc(a: torch.Tensor, bp: torch.Tensor, c32: torch.Tensor,
     M, K = a.shape
     assert bp.numel() == N * K and c32.dtype == torch.float32
     check(_lib.load().spacer_gemm_skinny_packed_bf16(_ptr(a), _rowmajor(a), _ptr(bp), _ptr(c32), _rowmajor(c32), M, N, K,
-                                                     _stream()), "gemm_skinny_packed_bf16")
+                                                     _plan(), _stream()), "gemm_skinny_packed_bf16")
     return c32
 
 
@@ -223,7 +259,7 @@ def gemm_skinny_packed_normed(x32: torch.Tensor, bp: torch.Tensor, c32: torch.Te
     M, K = x32.shape
     assert bp.numel() == N * K and c32.dtype == torch.float32 and x32.dtype == torch.float32 and rowss.dtype == torch.float32
     check(_lib.load().spacer_gemm_skinny_packed_normed(_ptr(x32), _rowmajor(x32), _ptr(bp), _ptr(c32), _rowmajor(c32), _ptr(rowss),
-                                                       M, N, K, _stream()), "gemm_skinny_packed_normed")
+                                                       M, N, K, _plan(), _stream()), "gemm_skinny_packed_normed")
     return c32
 
 
@@ -232,7 +268,7 @@ def gemm_skinny_packed_store(a: torch.Tensor, bp: torch.Tensor, c32: torch.Tenso
     M, K = a.shape
     assert bp.numel() == N * K and c32.dtype == torch.float32
     check(_lib.load().spacer_gemm_skinny_packed_store_bf16(_ptr(a), _rowmajor(a), _ptr(bp), _ptr(c32), _rowmajor(c32), M, N, K,
-                                                           _stream()), "gemm_skinny_packed_store_bf16")
+                                                           _plan(), _stream()), "gemm_skinny_packed_store_bf16")
     return c32
 
 
@@ -260,7 +296,7 @@ def gemm_skinny_swiglu(a: torch.Tensor, bp: torch.Tensor, inter: int, out: Optio
         ws = torch.zeros(_lib.load().spacer_gemm_skinny_swiglu_workspace_bytes() // 4, device=a.device, dtype=torch.int32)
         _SWIGLU_WS[a.device] = ws
     check(_lib.load().spacer_gemm_skinny_swiglu_bf16_ws(_ptr(a), _rowmajor(a), _ptr(bp), _ptr(out), _rowmajor(out), M, inter, K,
-                                                        _ptr(ws), ws.numel() * 4, _stream()), "gemm_skinny_swiglu_bf16")
+                                                        _ptr(ws), ws.numel() * 4, _plan(), _stream()), "gemm_skinny_swiglu_bf16")
     return out
 
 

@@ -592,5 +592,4 @@ class SGRLVRTrainer:
                                      "(checkpoint of another architecture / layout version)")
                 dst.copy_(st[name])
             e.step_count = int(st["step_count"])
-        self.engine.engine.invalidate_cache()
         self.engine.roll.invalidate()

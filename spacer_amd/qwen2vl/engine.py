@@ -26,7 +26,7 @@ BF16, F32 = torch.bfloat16, torch.float32
 class Qwen2VLEngine:
     HEAD_CHUNK = 8192      # vocabulary rows of lm_head per head chunk (fp32 chunk logits: 268 MB at 8192 completion rows)
 
-    def __init__(self, cfg: Qwen2VLConfig, params: FlatParams, cache_wT: bool = False, recompute: bool = False):
+    def __init__(self, cfg: Qwen2VLConfig, params: FlatParams, recompute: bool = False):
         self.cfg = cfg
         self.W = params
         self.dev = params.flat.device
@@ -36,14 +36,8 @@ class Qwen2VLEngine:
         # by the SAME kernel launch as in the forward -- bit-identical gradients (tests/test_recompute_gpu.py), one more
         # gate|up GEMM per layer and one more lm_head GEMM.  17.5 + 2.5 of the 27 + 2.5 GB per 5.5k-token 7B group.
         self.recompute = recompute
-        self.cache_wT = cache_wT          # kept for callers; unused since the backward GEMMs read W / dY / X in place
-        self._wT: Dict[str, torch.Tensor] = {}
 
     # ------------------------------------------------------------------ helpers
-    def invalidate_cache(self) -> None:
-        """Call after the optimizer rewrites the bf16 weights (nothing is cached any more: the dX GEMMs read W in place)."""
-        self._wT.clear()
-
     def _dx(self, dy: torch.Tensor, name: str) -> torch.Tensor:
         """dX[T, in] = dY[T, out] . W[out, in]: contraction over W's ROW index, read in place (trans_b)."""
         return K.gemm(dy, self.W[name], trans_b=True)

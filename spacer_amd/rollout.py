@@ -24,6 +24,7 @@ from .qwen2vl import positions as POS
 from .qwen2vl.engine import Qwen2VLEngine
 
 BF16, F32 = torch.bfloat16, torch.float32
+DECODE_NORM_FOLD = os.environ.get("SPACER_DECODE_NORM", "fold") != "separate"     # A/B switch, read once at import
 
 
 @dataclass
@@ -61,7 +62,7 @@ class RolloutEngine:
         # SPACER_DECODE_NORM=separate keeps the norm kernel (A/B runs); batches of more than 64 rows always keep it.
         # (the finishing kernel of layer i clears the row sums of layer (i + 1) % layers while it reads layer i's: a one-layer model
         # would clear what it reads, so it keeps the separate norm launch)
-        self.fold_norm = os.environ.get("SPACER_DECODE_NORM", "fold") != "separate" and engine.cfg.layers >= 2
+        self.fold_norm = DECODE_NORM_FOLD and engine.cfg.layers >= 2
 
     # ------------------------------------------------------------------ decode-layout weights
     def invalidate(self) -> None:

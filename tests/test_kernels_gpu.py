@@ -80,9 +80,9 @@ def test_gemm_split_k_tail(dev, M, N, Kd):
     res = rnd((M, N), dev, 14, dtype=torch.float32)
     want = a.float() @ b.float().t()
     lib = K._lib.load()
-    if os.environ.get("SPACER_GEMM_TILE"):
+    if K.PLAN.gemm_tile:
         pytest.skip("tile forced by SPACER_GEMM_TILE")
-    assert lib.spacer_gemm_tile(M, N, Kd, 1) == 256
+    assert lib.spacer_gemm_tile(M, N, Kd, 1, None) == 256
     for _ in range(3):
         got = K.gemm_nt(a, b, bias=bias, act=K.SPACER_ACT_QUICK_GELU)
         assert_close(got, O.quick_gelu(want + bias.float()), 3e-2, 1e-2, "split-K bias+quick_gelu")
@@ -188,11 +188,8 @@ def test_gemm_skinny_swiglu_tail_balance_leaves_workspace_clean(dev):
     ws = K._SWIGLU_WS[a.device]
     torch.cuda.synchronize()
     assert int(ws.abs().sum()) == 0
-    os.environ["SPACER_SKINNY_NOBALANCE"] = "1"
-    try:
+    with K.plan(skinny_no_balance=1):
         plain = K.gemm_skinny_swiglu(a, wp, I).clone()
-    finally:
-        del os.environ["SPACER_SKINNY_NOBALANCE"]
     # whole-K columns are bit-identical; the 80 split groups differ only by fp32 summation order before the bf16 rounding
     assert torch.equal(outs[0][:, :(512 * 64) // 2], plain[:, :(512 * 64) // 2])
     assert_close(outs[0], plain, 1e-2, 1e-2, "balanced vs plain")

@@ -58,7 +58,7 @@ def test_graph_replay_equals_eager_and_scoring_agrees(tiny, dev, monkeypatch):
     # split-K flushes of the decode GEMMs are fp32 atomics (arrival order = last-bit noise in the residual stream, which
     # can flip a sampled token whose draw sits on a CDF boundary); one K range per block makes the sums reproducible so
     # that "replay == eager" can be asserted bit for bit
-    monkeypatch.setenv("SPACER_SKINNY_BLOCKS", "1")
+    monkeypatch.setattr(K.PLAN, "skinny_blocks", 1)
     eng = Qwen2VLEngine(TINY, tiny["params"])
     roll = RolloutEngine(eng)
     sp = SamplingParams(max_new_tokens=12, top_k=50, top_p=0.95, seed=11, suppress_eos=True)

@@ -10,6 +10,7 @@ pytestmark = pytest.mark.gpu
 
 from fake_processor import FakeProcessor                                  # noqa: E402
 from golden_util import load_tiny                                         # noqa: E402
+from spacer_amd import kernels as K                                         # noqa: E402
 from spacer_amd.open_r1.config import GRPOConfig, GRPOScriptArguments     # noqa: E402
 from spacer_amd.open_r1.rewards import format_reward                      # noqa: E402
 from spacer_amd.open_r1.trainer import SGRLVRTrainer                      # noqa: E402
@@ -137,7 +138,7 @@ def test_resume_skips_consumed_steps_and_restores_optimizer(dev, tmp_path, monke
     """--resume_from_checkpoint (SG-RLVR.py:377-381, HF Trainer semantics): the run continues AFTER the samples already
     consumed (no replay from position 0), and with --save_only_model false the fp32 master weights and Adam moments come back,
     so a resumed run reproduces the uninterrupted one."""
-    monkeypatch.setenv("SPACER_SKINNY_BLOCKS", "1")          # decode GEMMs without split-K atomics: reproducible rollouts
+    monkeypatch.setattr(K.PLAN, "skinny_blocks", 1)          # decode GEMMs without split-K atomics: reproducible rollouts
     g = load_tiny()
     rows = _video_rows(3)
     common = dict(reward_funcs=[accuracy_reward, format_reward], script_args=GRPOScriptArguments(temporal=False, len_control=True),
