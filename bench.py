@@ -16,7 +16,11 @@ Prints ONE JSON line on rank 0 (see the driver contract in the task statement) w
                 the launch stream over the timed region: sum(2*M*N*K) / sum(duration)
   cpu_baseline  the whole step for one prompt group restated on the host (oracle/cpu_path.py, kind "port": ViT + prefill +
                 KV-cache decode + reference / policy scoring + autograd backward) timed on a bounded sample of the workload
-  variants      (N = 1) the same workload with the shipped script's --temporal true, and free-running (EOS allowed, 1024 new tokens)
+  roofline_hbm  HBM roofline of the step's largest kernel BY TIME, the decode loop's gate|up + SwiGLU weight-streaming GEMM
+                (gemm_skinny_kernel<true, true, 1, false>): algorithmic weight bytes / live HIP-event launch time
+  variants      (N = 1) the same workload with the shipped script's --temporal true, free-running (EOS allowed, 1024 new tokens),
+                through SGRLVRTrainer.train(), and precise_step = the full step with --precise-logps (log-probs <= 1e-3 of fp32)
+  comm          (N > 1 or --force-dist) the gradient exchange: algorithm, bytes on the wire, ms not hidden under the backward
 """
 from __future__ import annotations
 
@@ -68,7 +72,18 @@ def cpu_gemm_rate(cfg, seconds_budget: float = 4.0):
     return per_layer * n / dt / 1e12
 
 
-def cpu_baseline(cfg, workload):
+def cpu_fulldepth_measure(model: str, C: int = 32):
+    """Re-measure the FULL-DEPTH CPU group (scripts/run_cpu_fulldepth.py: 28 + 32 layers, real vocabulary, K = 8, C = 32) in a
+    subprocess on this host; minutes of host time, so only behind --cpu-fulldepth."""
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "run_cpu_fulldepth.py"), "--model", model, "--C", str(C)],
+                         capture_output=True, text=True, timeout=3000)
+    if out.returncode != 0:
+        return {"error": out.stderr[-300:]}
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+def cpu_baseline(cfg, workload, fulldepth: bool = False):
     """The reference path's CPU stand-in (SURVEY 8(d) "CPU baseline"): ONE prompt group through the WHOLE step on the host
     (oracle/cpu_path.py: ViT + prefill, KV-cache decode, reference + policy scoring with the prompt shared, GRPO loss,
     autograd backward; fp32 torch) on a BOUNDED sample of the workload: the model's real widths and REAL VOCABULARY with the depth
@@ -141,6 +156,8 @@ def cpu_baseline(cfg, workload):
     }
     t_group = sum(full.values())
     res = {"value": Kgen / t_group, "unit": "samples/s", "cores": threads, "kind": "port",
+           "value_kind": f"EXTRAPOLATED from the bounded {Ls}-layer sample below to full depth / K / C (see 'extrapolation'); the full-depth "
+                         "measurement is 'full_depth_C32' (measured 0.0553 samples/s at C = 32, its own extrapolation to C = 512: 0.0107)",
            "sample": f"one prompt group through oracle/cpu_path.py at the model's widths and vocabulary ({vocab_s}), {Ls} decoder layers + {Vs} "
                      f"vision blocks, {F} frames {Hpx}x{Wpx}, P={P}, K={Ks}, C={Cs}: {out['total_seconds']:.1f} s measured",
            "measured_phase_seconds": {k: round(v, 3) for k, v in sec.items()},
@@ -156,6 +173,16 @@ def cpu_baseline(cfg, workload):
                 rec = json.load(f)
             rec["source"] = f"profiles/{fname}: recorded on an MI355X box's host, NOT re-measured in this run"
             res[key] = rec
+    if fulldepth and preset in ("Qwen2-VL-7B", "Qwen2-VL-2B"):
+        # --cpu-fulldepth: the full-depth group re-measured in THIS run; its C = 512 extrapolation becomes ``value``
+        rec = cpu_fulldepth_measure("7b" if preset == "Qwen2-VL-7B" else "2b")
+        rec["source"] = "measured in this run (scripts/run_cpu_fulldepth.py on this host)"
+        res["full_depth_C32"] = rec
+        if "extrapolated_to_C512" in rec:
+            res["value_from_sample"] = res["value"]
+            res["value"] = rec["extrapolated_to_C512"]["samples_per_s"]
+            res["value_kind"] = ("full-depth group (28 + 32 layers, K = 8) MEASURED in this run at C = 32 "
+                                 f"({rec['measured']['samples_per_s']} samples/s), decode / scoring scaled to C = 512 by token count")
     return res
 
 
@@ -225,6 +252,43 @@ def through_trainer(ge, cfg, params, frames, dev, *, groups, Kgen, C, n_text, gp
             "kl": logs[-1].get("kl"), "completion_length": logs[-1].get("completion_length")}
 
 
+def skinny_roofline(ge, cfg, dev, rows: int, step_seconds: float, launches_per_step: int):
+    """HBM roofline of the step's largest kernel by time: the decode loop's gate|up + SwiGLU GEMM
+    (``gemm_skinny_kernel<true, true, 1, false>``, 15.6 % of the kernel time in profiles/r03_cfg3_step_kernel_stats_v1.md).  Inside the
+    timed region it is replayed from the decode hipGraph, where HIP events cannot bracket single kernels; so the decode step's own
+    launches -- the 28 layers' packed gate|up weights in layer order, the step's row count -- are replayed eagerly right after the
+    timed region with an event pair around EVERY launch (7.6 GB of distinct weights per round: nothing stays in the 256 MiB
+    Infinity Cache).  Algorithmic bytes per launch = the packed weights 2 * 2I * H (decode is weight streaming) + the
+    activations in and out."""
+    from spacer_amd import kernels as K
+    PW = ge.roll._pack()
+    I, H = cfg.intermediate, cfg.hidden
+    h2 = torch.randn(rows, H, device=dev).to(torch.bfloat16)
+    a = torch.empty(rows, I, device=dev, dtype=torch.bfloat16)
+    ev = []
+    for rnd in range(4):
+        for i in range(cfg.layers):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            K.gemm_skinny_swiglu(h2, PW[f"llm.{i}.gu_w"], I, out=a)
+            e1.record()
+            if rnd:
+                ev.append((e0, e1))
+    torch.cuda.synchronize()
+    us = sum(x.elapsed_time(y) for x, y in ev) / len(ev) * 1e3
+    algo = 2.0 * 2 * I * H + 2.0 * rows * (H + I)
+    gbps = algo / (us * 1e-6) / 1e9
+    ge.roll.invalidate()
+    return {"bound": "hbm", "kernel": "gemm_skinny_kernel<true, true, 1, false>", "achieved": round(gbps, 1), "peak": 8000.0, "unit": "GB/s",
+            "frac": round(gbps / 8000.0, 4), "avg_launch_us": round(us, 2), "launches_timed": len(ev),
+            "algorithmic_bytes_per_launch": round(algo), "rows": rows,
+            "traffic": 275.4e6 if (I, H) == (18944, 3584) else None,
+            "traffic_source": "profiles/r03_decode_pmc.md (rocprofv3 --pmc FETCH_SIZE x 2 KiB units over eager decode steps: 275.4 MB read per launch)",
+            "share_of_step": round(us * 1e-6 * launches_per_step / step_seconds, 3),
+            "how": "eager replay of the decode step's 28 gate|up launches after the timed region, HIP event pair per launch on the launch "
+                   "stream; in the timed region the same launches run from the decode hipGraph (rocprof average of that: profiles/)"}
+
+
 def precise_scoring(ge, cfg, frames, dev, *, F, Hpx, Wpx, n_text, Kgen, C, gpp):
     """What the north-star's 1e-3 log-prob tolerance costs: the scoring forward of ``gpp`` prompt groups (reference-model
     log-probs, no tape) on the fast bf16-operand path and in the precise mode (csrc/precise.hip: (hi, lo) operand pairs, two-pass
@@ -270,6 +334,11 @@ def main():
                     help="selective activation recompute in the policy backward (--gradient_checkpointing true of the shipped script): "
                          "MLP intermediates and lm_head logits are recomputed, which makes room for more groups per pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-fulldepth", action="store_true",
+                    help="cpu_baseline: also re-measure the FULL-DEPTH group on the host (minutes) and quote value from it")
+    ap.add_argument("--precise-logps", action="store_true",
+                    help="the headline step with GRPOHyper.precise_logps: policy / reference log-probs, KL and loss in the precise mode "
+                         "(<= 1e-3 of fp32 at full depth); default: the fast bf16-operand path, precise step reported under variants")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--grad-comm", choices=("fp32", "bf16"), default="bf16",
                     help="wire format of the gradient all-reduce (N > 1): bf16 as the reference's DeepSpeed bf16 mode sends them, or fp32")
@@ -346,7 +415,8 @@ def main():
     C = args.completion_len or C
     cfg = PRESETS[preset]
     hyper = GRPOHyper(num_generations=Kgen, temporal=False, len_control=True, total_steps=1000, grad_comm_bf16=args.grad_comm == "bf16",
-                      overlap_comm=not args.no_overlap, recompute=args.recompute, grad_algo=args.grad_algo)
+                      overlap_comm=not args.no_overlap, recompute=args.recompute, grad_algo=args.grad_algo,
+                      precise_logps=args.precise_logps)
     params = FlatParams.empty(cfg, dev)
     random_init_(params, seed=1234)
     ge = GRPOEngine(cfg, params, hyper, process_group=pg)
@@ -416,6 +486,7 @@ def main():
     roll_stats.clear()
     K.PROFILER.reset(enabled=True)
     K.PROFILER.by_shape = args.gemm_shapes
+    ge.comm_timing(True)
     barrier()
     t_start = time.perf_counter()
     for i in range(args.steps):
@@ -423,6 +494,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t_start
     K.PROFILER.enabled = False
+    comm = ge.comm_stats(args.steps)
+    ge.comm_timing(False)
     if dist_on:
         import torch.distributed as dist
         t = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
@@ -460,7 +533,7 @@ def main():
         if args.workload in ("cfg3", "tiny"):
             try:
                 variants["through_trainer"] = through_trainer(ge, cfg, params, frames, dev, groups=groups, Kgen=Kgen, C=C, n_text=n_text,
-                                                              gpp=max(1, min(gpp_default, groups)), steps=2, use_graph=not args.no_graph)
+                                                              gpp=max(1, min(gpp_default, groups)), steps=4, use_graph=not args.no_graph)
                 if "ms_per_step" in variants["through_trainer"]:
                     variants["through_trainer"]["vs_headline"] = round(variants["through_trainer"]["samples_per_s"] / (groups * Kgen * args.steps / elapsed), 4)
             except Exception as exc:
@@ -476,6 +549,28 @@ def main():
                                                 "weight_stream_tbps": round(DECODE_WEIGHT_GB.get(preset, 0.0) * rs["decode_steps"] / dec8 / 1e3, 3)}
             except Exception as exc:
                 variants["decode_cfg4_rows"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+            if not args.precise_logps:
+                # the FULL step with the stated tolerance in it: reference + policy log-probs, KL and loss from the
+                # precise mode, gradient from the production backward on the precise forward's tape
+                try:
+                    ge.h.precise_logps = True
+                    step(20_000)
+                    torch.cuda.synchronize()
+                    t_v = time.perf_counter()
+                    n_v = 2
+                    for i in range(n_v):
+                        step(20_001 + i)
+                    torch.cuda.synchronize()
+                    dt_v = (time.perf_counter() - t_v) / n_v
+                    variants["precise_step"] = {"samples_per_s": round(groups * Kgen / dt_v, 3), "ms_per_step": round(1e3 * dt_v, 1), "steps": n_v,
+                                                "vs_headline_step_time": round(dt_v / (elapsed / args.steps), 3),
+                                                "what": "policy + reference log-probs, KL, loss in the precise mode (<= 1e-3 of the fp32 oracle at full 7B "
+                                                        "depth: tests/test_precise_gpu.py); gradient = production backward on the precise tape"}
+                except Exception as exc:
+                    variants["precise_step"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+                    torch.cuda.empty_cache()
+                finally:
+                    ge.h.precise_logps = False
             try:
                 variants["precise_scoring"] = precise_scoring(ge, cfg, frames, dev, F=F, Hpx=Hpx, Wpx=Wpx, n_text=n_text, Kgen=Kgen, C=C,
                                                               gpp=max(1, min(gpp_default, groups)))
@@ -516,7 +611,11 @@ def main():
                                    f"(rollout+ref/policy scoring+backward+AdamW)",
                        "global_batch": groups * Kgen * world, "parallelism": f"dp{world}", "decode_graph": not args.no_graph,
                        "grad_comm": args.grad_comm, "grad_algo": args.grad_algo, "overlap_comm": not args.no_overlap, "backend": args.backend, "groups_per_pass": max(1, min(gpp_default, groups)),
-                       "rccl_world": world, "recompute": bool(args.recompute),
+                       "rccl_world": world, "recompute": bool(args.recompute), "precise_logps": bool(args.precise_logps),
+                       "groups_per_gpu": groups,
+                       "launch_shape": ("the reference script's own: 1 prompt group (K rollouts) per GPU per step (run_SpaceR_SG_RLVR.sh:21)"
+                                        if groups == 1 else f"weak scaling with {groups} prompt groups per GPU per step (decode batch {groups * Kgen} rows); "
+                                        "--groups 1 / --workload cfg4 gives the reference script's 1 group per GPU"),
                        "devices": [torch.cuda.get_device_name(local)] if world == 1 else f"{world} x {torch.cuda.get_device_name(local)}"},
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": round(gemm["tflops"], 2),
                          "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gemm["tflops"] / MFMA_PEAK_TFLOPS, 4),
@@ -553,10 +652,18 @@ def main():
             out["phase_seconds_per_step"] = {k: round(v / args.steps, 3) for k, v in phase.items()}
         if world == 1:
             out["roofline"]["traffic"], out["roofline"]["traffic_source"] = pmc_traffic(args.workload, dom_name, not args.no_pmc)
+        if roll_stats.get("decode_steps") and groups * Kgen <= 64:
+            try:
+                out["roofline_hbm"] = skinny_roofline(ge, cfg, dev, groups * Kgen, elapsed / args.steps,
+                                                      cfg.layers * roll_stats["decode_steps"] // max(1, args.steps))
+            except Exception as exc:        # noqa: BLE001
+                out["roofline_hbm"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+        if comm is not None:
+            out["comm"] = comm
         if variants:
             out["variants"] = variants
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg, (preset, F, Hpx, Wpx, n_text, Kgen, C, groups))
+            out["cpu_baseline"] = cpu_baseline(cfg, (preset, F, Hpx, Wpx, n_text, Kgen, C, groups), fulldepth=args.cpu_fulldepth)
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist_on:

@@ -361,18 +361,25 @@ int spacer_adamw_step(float* master, void* shadow_bf16, float* m, float* v, cons
  * Precise scoring mode (csrc/precise.hip): per-token log-probs within 1e-3 of an fp32 evaluation at full depth (TR:353-366;
  * the north-star tolerance).  An activation is carried as a PAIR of bf16 arrays (hi = bf16(x), lo = bf16(x - hi)); a linear
  * layer is two accumulate passes of spacer_gemm_bf16_nt (A_hi, then A_lo with residual == C) into an fp32 C.  These entries
- * are the fp32 -> pair producers between the GEMMs and the attention on pair operands.  Forward only.
+ * are the fp32 -> pair producers between the GEMMs and the attention on pair operands.
+ * Round 4: the producers can also emit what the FAST path's backward kernels read -- norm statistics (mean / rstd), bf16
+ * pre-activations (act / SwiGLU inputs), the attention log-sum-exp -- so that a training step (TR:527-552: the log-probs that
+ * enter KL, loss and metrics) evaluates its forward in this mode and back-propagates through the production kernels on the hi
+ * halves (spacer_attn_bwd, spacer_gemm_bf16 dX / dW, spacer_rmsnorm_bwd, ...).  All such outputs are optional (NULL).
  * ---------------------------------------------------------------------------------------------- */
 /* y_hi / y_lo [rows, ldy] bf16 <- x fp32 [rows, ldx] (cols, ldx, ldy multiples of 4) */
 int spacer_split_f32_pair(const float* x, long ldx, void* y_hi, void* y_lo, long ldy, int rows, int cols, spacer_stream_t stream);
-/* y = act(x) in fp32 (enum spacer_act), as a pair */
-int spacer_act_f32_pair(const float* x, long ldx, void* y_hi, void* y_lo, long ldy, int rows, int cols, int act,
+/* y = act(x) in fp32 (enum spacer_act), as a pair; pre_bf16 [rows, ldy] (or NULL) receives bf16(x), the point spacer_act_bwd
+ * differentiates at */
+int spacer_act_f32_pair(const float* x, long ldx, void* y_hi, void* y_lo, long ldy, int rows, int cols, int act, void* pre_bf16,
                         spacer_stream_t stream);
-/* gu fp32 [rows, 2*inter] = [gate | up] -> silu(gate) * up as a pair [rows, inter] */
-int spacer_swiglu_f32_pair(const float* gu, void* y_hi, void* y_lo, int rows, int inter, spacer_stream_t stream);
-/* RMSNorm (layer == 0, b ignored) or LayerNorm (layer != 0) of fp32 rows, bf16 weights, output as a pair */
+/* gu fp32 [rows, 2*inter] = [gate | up] -> silu(gate) * up as a pair [rows, inter]; gu_bf16 [rows, 2*inter] (or NULL) receives
+ * bf16(gate | up) for spacer_swiglu_bwd */
+int spacer_swiglu_f32_pair(const float* gu, void* y_hi, void* y_lo, int rows, int inter, void* gu_bf16, spacer_stream_t stream);
+/* RMSNorm (layer == 0, b ignored) or LayerNorm (layer != 0) of fp32 rows, bf16 weights, output as a pair; mean_out (LayerNorm
+ * only) / rstd_out fp32 [rows] (or NULL) receive the row statistics spacer_layernorm_bwd / spacer_rmsnorm_bwd take */
 int spacer_norm_f32_pair(const float* x, const void* w, const void* b, void* y_hi, void* y_lo, int rows, int cols, float eps,
-                         int layer, spacer_stream_t stream);
+                         int layer, float* mean_out, float* rstd_out, spacer_stream_t stream);
 /* rotary on the first rot_heads heads of fp32 rows [tokens, heads, head_dim] (ldx floats between tokens), the other heads copied;
  * output as a pair with token stride ldy */
 int spacer_rope_f32_pair(const float* x, long ldx, const float* cos_t, const float* sin_t, void* y_hi, void* y_lo, long ldy,
@@ -381,7 +388,7 @@ int spacer_rope_f32_pair(const float* x, long ldx, const float* cos_t, const flo
 int spacer_embed_fwd_f32video(const int64_t* ids, const void* table, const float* video, const int* video_row_of_token, float* out,
                               int T, int H, spacer_stream_t stream);
 /* spacer_attn_fwd on pair operands: S = Qh Kh + Qh Kl + Ql Kh, O = Ph Vh + Ph Vl + Pl Vh, fp32 softmax; O written as a pair.
- * lse may be NULL. */
+ * lse fp32 [Hq, T] (or NULL): natural-log sum-exp of every query row, the layout spacer_attn_bwd reads. */
 int spacer_attn_fwd_pair(const void* q_hi, const void* q_lo, const void* k_hi, const void* k_lo, const void* v_hi, const void* v_lo,
                          void* o_hi, void* o_lo, float* lse, long q_stride, long kv_stride, long o_stride,
                          const spacer_attn_segment* segs_dev, int num_segs, int max_q_len, int T, int Hq, int Hkv, int D, int causal,

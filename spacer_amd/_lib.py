@@ -95,9 +95,9 @@ SIGNATURES = {
     "spacer_sumsq_f32": [_p, _l, _p, _p],
     "spacer_adamw_step": [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _f, _p, _f, _f, _p],
     "spacer_split_f32_pair": [_p, _l, _p, _p, _l, _i, _i, _p],
-    "spacer_act_f32_pair": [_p, _l, _p, _p, _l, _i, _i, _i, _p],
-    "spacer_swiglu_f32_pair": [_p, _p, _p, _i, _i, _p],
-    "spacer_norm_f32_pair": [_p, _p, _p, _p, _p, _i, _i, _f, _i, _p],
+    "spacer_act_f32_pair": [_p, _l, _p, _p, _l, _i, _i, _i, _p, _p],
+    "spacer_swiglu_f32_pair": [_p, _p, _p, _i, _i, _p, _p],
+    "spacer_norm_f32_pair": [_p, _p, _p, _p, _p, _i, _i, _f, _i, _p, _p, _p],
     "spacer_rope_f32_pair": [_p, _l, _p, _p, _p, _p, _l, _i, _i, _i, _i, _p],
     "spacer_embed_fwd_f32video": [_p, _p, _p, _p, _p, _i, _i, _p],
     "spacer_attn_fwd_pair": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _l, _l, _l, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p],

@@ -6,8 +6,9 @@
 // exactly bf16 on both sides, so a linear layer is TWO accumulate passes of the production GEMM (A_hi . W^T, then += A_lo . W^T)
 // into an fp32 output; attention needs both operands of both products split: S = Qh Kh + Qh Kl + Ql Kh, O = Ph Vh + Ph Vl + Pl Vh
 // (the lo x lo terms are 2^-16 of the result and dropped).  Everything between the matmuls (norms, rotary, activations, softmax)
-// runs in fp32 and writes a pair.  Forward only: the reference model's log-probs and the policy's reported log-probs; the
-// training gradient stays on the bf16 path.
+// runs in fp32 and writes a pair.  The forward can also EMIT THE TAPE of the fast path's backward (round 4: norm statistics, the
+// attention log-sum-exp, bf16 pre-activations; the hi halves of the pairs are the bf16 activations): the training step then takes its
+// log-probs, KL and loss from this mode and its gradient from the production backward kernels on those activations.
 #include "attn_common.h"
 
 namespace {
@@ -36,7 +37,8 @@ constexpr int MAXIT = 8;      // cols <= NT*4*MAXIT = 8192
 template <bool LAYER>
 __global__ __launch_bounds__(NT) void norm_pair_kernel(const float* __restrict__ x, const bf16_t* __restrict__ w,
                                                        const bf16_t* __restrict__ b, bf16_t* __restrict__ yh,
-                                                       bf16_t* __restrict__ yl, int rows, int cols, float eps) {
+                                                       bf16_t* __restrict__ yl, int rows, int cols, float eps,
+                                                       float* __restrict__ mean_out, float* __restrict__ rstd_out) {
     __shared__ float red[32];
     for (int row = blockIdx.x; row < rows; row += gridDim.x) {
         const long base = (long)row * cols;
@@ -64,6 +66,10 @@ __global__ __launch_bounds__(NT) void norm_pair_kernel(const float* __restrict__
         }
         const float var = block_sum(ss, red) / cols;
         const float rstd = 1.f / sqrtf(var + eps);
+        if (threadIdx.x == 0) {                       // the statistics the fast path's backward kernels take (taped precise forward)
+            if (LAYER && mean_out) mean_out[row] = mu;
+            if (rstd_out) rstd_out[row] = rstd;
+        }
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
             const int c = (it * NT + threadIdx.x) * 4;
@@ -121,7 +127,8 @@ __device__ __forceinline__ float act_p(float v, int act) {
     return v;
 }
 __global__ __launch_bounds__(NT) void act_pair_kernel(const float* __restrict__ x, long ldx, bf16_t* __restrict__ yh,
-                                                      bf16_t* __restrict__ yl, long ldy, int rows, int cols, int act) {
+                                                      bf16_t* __restrict__ yl, long ldy, int rows, int cols, int act,
+                                                      bf16_t* __restrict__ pre) {
     const int per_row = cols >> 2;
     const long total = (long)rows * per_row;
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
@@ -129,11 +136,12 @@ __global__ __launch_bounds__(NT) void act_pair_kernel(const float* __restrict__ 
         const float4 t = *(const float4*)(x + r * ldx + c);
         const float o[4] = {act_p(t.x, act), act_p(t.y, act), act_p(t.z, act), act_p(t.w, act)};
         store_pair4(yh, yl, r * ldy + c, o);
+        if (pre) *(uint2*)(pre + r * ldy + c) = make_uint2(pack_bf2(t.x, t.y), pack_bf2(t.z, t.w));   // bf16(x): what act_bwd differentiates at
     }
 }
 // gu fp32 [rows, 2*inter] = [gate | up] -> silu(gate) * up as a pair [rows, inter]
 __global__ __launch_bounds__(NT) void swiglu_pair_kernel(const float* __restrict__ gu, bf16_t* __restrict__ yh,
-                                                         bf16_t* __restrict__ yl, int rows, int inter) {
+                                                         bf16_t* __restrict__ yl, int rows, int inter, bf16_t* __restrict__ gu16) {
     const int per_row = inter >> 2;
     const long total = (long)rows * per_row;
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
@@ -141,6 +149,10 @@ __global__ __launch_bounds__(NT) void swiglu_pair_kernel(const float* __restrict
         const float4 g = *(const float4*)(gu + r * 2 * inter + c), u = *(const float4*)(gu + r * 2 * inter + inter + c);
         const float o[4] = {g.x * sigm_p(g.x) * u.x, g.y * sigm_p(g.y) * u.y, g.z * sigm_p(g.z) * u.z, g.w * sigm_p(g.w) * u.w};
         store_pair4(yh, yl, r * inter + c, o);
+        if (gu16) {                                   // bf16(gate | up): what swiglu_bwd differentiates at (taped precise forward)
+            *(uint2*)(gu16 + r * 2 * inter + c) = make_uint2(pack_bf2(g.x, g.y), pack_bf2(g.z, g.w));
+            *(uint2*)(gu16 + r * 2 * inter + inter + c) = make_uint2(pack_bf2(u.x, u.y), pack_bf2(u.z, u.w));
+        }
     }
 }
 
@@ -362,33 +374,34 @@ extern "C" int spacer_split_f32_pair(const float* x, long ldx, void* y_hi, void*
     SP_REQUIRE(cols % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, SPACER_EINVAL, "split_f32_pair: cols / strides must be multiples of 4");
     if (rows <= 0 || cols <= 0) return SPACER_OK;
     hipLaunchKernelGGL(act_pair_kernel, dim3(grid_for((long)rows * cols / 4)), dim3(NT), 0, (hipStream_t)stream, x, ldx,
-                       (bf16_t*)y_hi, (bf16_t*)y_lo, ldy, rows, cols, SPACER_ACT_NONE);
+                       (bf16_t*)y_hi, (bf16_t*)y_lo, ldy, rows, cols, SPACER_ACT_NONE, (bf16_t*)nullptr);
     SP_CHECK_LAUNCH();
     return SPACER_OK;
 }
 
 extern "C" int spacer_act_f32_pair(const float* x, long ldx, void* y_hi, void* y_lo, long ldy, int rows, int cols, int act,
-                                   spacer_stream_t stream) {
+                                   void* pre_bf16, spacer_stream_t stream) {
     SP_REQUIRE(cols % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, SPACER_EINVAL, "act_f32_pair: cols / strides must be multiples of 4");
     SP_REQUIRE(act >= SPACER_ACT_NONE && act <= SPACER_ACT_SILU, SPACER_EINVAL, "act_f32_pair: unknown activation %d", act);
     if (rows <= 0 || cols <= 0) return SPACER_OK;
     hipLaunchKernelGGL(act_pair_kernel, dim3(grid_for((long)rows * cols / 4)), dim3(NT), 0, (hipStream_t)stream, x, ldx,
-                       (bf16_t*)y_hi, (bf16_t*)y_lo, ldy, rows, cols, act);
+                       (bf16_t*)y_hi, (bf16_t*)y_lo, ldy, rows, cols, act, (bf16_t*)pre_bf16);
     SP_CHECK_LAUNCH();
     return SPACER_OK;
 }
 
-extern "C" int spacer_swiglu_f32_pair(const float* gu, void* y_hi, void* y_lo, int rows, int inter, spacer_stream_t stream) {
+extern "C" int spacer_swiglu_f32_pair(const float* gu, void* y_hi, void* y_lo, int rows, int inter, void* gu_bf16,
+                                      spacer_stream_t stream) {
     SP_REQUIRE(inter % 4 == 0, SPACER_EINVAL, "swiglu_f32_pair: inter=%d must be a multiple of 4", inter);
     if (rows <= 0 || inter <= 0) return SPACER_OK;
     hipLaunchKernelGGL(swiglu_pair_kernel, dim3(grid_for((long)rows * inter / 4)), dim3(NT), 0, (hipStream_t)stream, gu,
-                       (bf16_t*)y_hi, (bf16_t*)y_lo, rows, inter);
+                       (bf16_t*)y_hi, (bf16_t*)y_lo, rows, inter, (bf16_t*)gu_bf16);
     SP_CHECK_LAUNCH();
     return SPACER_OK;
 }
 
 extern "C" int spacer_norm_f32_pair(const float* x, const void* w, const void* b, void* y_hi, void* y_lo, int rows, int cols,
-                                    float eps, int layer, spacer_stream_t stream) {
+                                    float eps, int layer, float* mean_out, float* rstd_out, spacer_stream_t stream) {
     SP_REQUIRE(cols % 4 == 0 && cols <= NT * 4 * MAXIT, SPACER_EINVAL, "norm_f32_pair: cols=%d must be a multiple of 4, <= %d", cols,
                NT * 4 * MAXIT);
     SP_REQUIRE(!layer || b, SPACER_EINVAL, "norm_f32_pair: LayerNorm needs a bias");
@@ -396,10 +409,10 @@ extern "C" int spacer_norm_f32_pair(const float* x, const void* w, const void* b
     const int grid = rows < 256 * 8 ? rows : 256 * 8;
     if (layer)
         hipLaunchKernelGGL(norm_pair_kernel<true>, dim3(grid), dim3(NT), 0, (hipStream_t)stream, x, (const bf16_t*)w, (const bf16_t*)b,
-                           (bf16_t*)y_hi, (bf16_t*)y_lo, rows, cols, eps);
+                           (bf16_t*)y_hi, (bf16_t*)y_lo, rows, cols, eps, mean_out, rstd_out);
     else
         hipLaunchKernelGGL(norm_pair_kernel<false>, dim3(grid), dim3(NT), 0, (hipStream_t)stream, x, (const bf16_t*)w, (const bf16_t*)nullptr,
-                           (bf16_t*)y_hi, (bf16_t*)y_lo, rows, cols, eps);
+                           (bf16_t*)y_hi, (bf16_t*)y_lo, rows, cols, eps, mean_out, rstd_out);
     SP_CHECK_LAUNCH();
     return SPACER_OK;
 }

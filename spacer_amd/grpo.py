@@ -52,6 +52,12 @@ class GRPOHyper:
     # directly, so the reduce-scatter + all-gather pair moves (n-1)/n x 2 bytes per parameter in bf16 instead of the all-reduce's
     # (n-1)/n x 4, and the optimizer's 16 B/param of HBM traffic shrinks by world x).  Replicas end bit-identical either way.
     grad_algo: str = "allreduce"
+    # --precise_logps: the per-token log-probs of the policy AND the reference model that enter KL, loss and the logged metrics
+    # (TR:527-552) are evaluated in the precise mode (csrc/precise.hip: (hi, lo) bf16 operand pairs, two-pass GEMMs, pair
+    # attention, fp32 everywhere else) -- within the north-star's 1e-3 of an fp32 evaluation at full 7B depth, where the fast path
+    # sits at the bf16-operand floor (~1e-1 max).  The precise forward of the policy also emits the tape of the production
+    # backward (Qwen2VLEngine._llm_forward_precise), so the gradient costs nothing extra; the forward costs ~2x the fast one.
+    precise_logps: bool = False
 
 
 # ------------------------------------------------------------------------------------- reward shaping (host)
@@ -153,6 +159,11 @@ class GradReducer:
         self.host_staged = flat.is_cuda and dist.get_backend(pg) == "gloo"
         self.cuda = flat.is_cuda and not self.host_staged
         self.side = torch.cuda.Stream(device=flat.device) if self.cuda else None
+        # bench.py's ``comm`` object: (event at finish() entry, event when the compute stream may go on) per step = the part of the
+        # exchange NOT hidden under the last backward; bytes handed to the collective per step
+        self.timing = False
+        self.exposed = []
+        self.wire_bytes = 0
         self.reset()
 
     def reset(self) -> None:
@@ -178,6 +189,7 @@ class GradReducer:
             work = dist.all_reduce(buf, group=self.pg, async_op=True)
         self.inflight.append((lo, hi, wire, work))
         self.sent += hi - lo
+        self.wire_bytes += (hi - lo) * buf.element_size()
 
     def _flush(self, force: bool) -> None:
         """Merge adjacent finished ranges; send every merged run that reached the bucket size (all of them when forced)."""
@@ -204,6 +216,10 @@ class GradReducer:
 
     def finish(self) -> None:
         """Send what has not been sent (everything, if no ``ready`` call was made), wait, widen bf16 wires back."""
+        t_in = None
+        if self.timing and self.cuda:
+            t_in = torch.cuda.Event(enable_timing=True)
+            t_in.record(torch.cuda.current_stream())
         covered = sorted([(lo, hi) for lo, hi, _, _ in self.inflight] + self.pending)
         pos, gaps = 0, []
         for lo, hi in covered:
@@ -226,6 +242,10 @@ class GradReducer:
                     self.flat[lo:hi].copy_(wire)
         if self.cuda:
             torch.cuda.current_stream().wait_stream(self.side)
+        if t_in is not None:
+            t_out = torch.cuda.Event(enable_timing=True)
+            t_out.record(torch.cuda.current_stream())
+            self.exposed.append((t_in, t_out))
         assert self.sent == self.flat.numel(), (self.sent, self.flat.numel())
         self.reset()
 
@@ -366,9 +386,10 @@ class GRPOEngine:
         cfg = self.cfg
         mask, lengths = K.completion_mask(completion_ids, cfg.eos_token_id)
         with torch.no_grad():
-            ref_lp = self.ref_engine.score_group(prompt.ids, completion_ids, prompt.pix, prompt.grids, era_rule=era_rule)
+            pr = self.h.precise_logps
+            ref_lp = self.ref_engine.score_group(prompt.ids, completion_ids, prompt.pix, prompt.grids, era_rule=era_rule, precise=pr)
             tape: dict = {}
-            lp = self.engine.score_group(prompt.ids, completion_ids, prompt.pix, prompt.grids, tape=tape, era_rule=era_rule)
+            lp = self.engine.score_group(prompt.ids, completion_ids, prompt.pix, prompt.grids, tape=tape, era_rule=era_rule, precise=pr)
             if callable(advantages):           # lazy: the host shapes the rewards while the two forwards run (see _multi)
                 advantages = advantages()
                 advantages = (advantages[0] if isinstance(advantages, (list, tuple)) else advantages).to(self.dev)
@@ -397,9 +418,10 @@ class GRPOEngine:
         mask, lengths = K.completion_mask(comp_all, cfg.eos_token_id)
         entries = [(p.ids, p.pix, p.grids) for p in prompts]
         with torch.no_grad():
-            ref_lp = self.ref_engine.score_groups(entries, completions, era_rule=era_rule)
+            pr = self.h.precise_logps
+            ref_lp = self.ref_engine.score_groups(entries, completions, era_rule=era_rule, precise=pr)
             tape: dict = {}
-            lp = self.engine.score_groups(entries, completions, tape=tape, era_rule=era_rule)
+            lp = self.engine.score_groups(entries, completions, tape=tape, era_rule=era_rule, precise=pr)
             if callable(advantages):
                 advantages = advantages()
             # the loss kernel averages over its rows: G groups of K rows -> mean over G*K rows = (1/G) * sum of group means
@@ -431,7 +453,19 @@ class GRPOEngine:
         if self.reducer is not None:
             self.reducer.finish()
         if self.sharded is not None:
+            t = self._comm_mark()
             self.sharded.reduce_scatter_(self.G.flat)
+            self._comm_mark(t)
+
+    def _comm_mark(self, start=None):
+        """rs_ag runs on the compute stream: its collectives are exposed in full; bracket them with events when timing is on."""
+        if not getattr(self, "_comm_on", False) or not self.G.flat.is_cuda:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream())
+        if start is not None:
+            self._comm_events.append((start, e))
+        return e
 
     def optimizer_step(self, world_size: int = 1) -> float:
         """Global-norm clip (max_grad_norm) + AdamW on fp32 master, bf16 policy refreshed in the same kernel."""
@@ -452,7 +486,9 @@ class GRPOEngine:
             K.adamw_step_(sh.shard(self.master.flat), sh.shard(self.policy.flat), sh.shard(self.m), sh.shard(self.v), sh.shard(self.G.flat),
                           lr=lr, beta1=h.adam_beta1, beta2=h.adam_beta2, eps=h.adam_eps, weight_decay=h.weight_decay,
                           step=self.step_count, sumsq=self._sumsq, max_norm=h.max_grad_norm, grad_scale=gscale)
+            t = self._comm_mark()
             sh.all_gather_(self.policy.flat)
+            self._comm_mark(t)
         else:
             K.sumsq_(self.G.flat, self._sumsq)
             K.adamw_step_(self.master.flat, self.policy.flat, self.m, self.v, self.G.flat, lr=lr, beta1=h.adam_beta1,
@@ -471,3 +507,37 @@ class GRPOEngine:
 
     def grad_norm(self, world_size: int = 1) -> float:
         return float(self._sumsq.sqrt()) / world_size
+
+    # -------------------------------------------------------------- data-parallel exchange accounting (bench.py ``comm``)
+    def comm_timing(self, on: bool) -> None:
+        """Start / stop collecting the exposed-exchange events (and reset the byte counter)."""
+        self._comm_events = []
+        if self.reducer is not None:
+            self.reducer.timing, self.reducer.exposed, self.reducer.wire_bytes = on, [], 0
+        self._comm_on = on
+
+    def comm_stats(self, steps: int) -> Optional[dict]:
+        """{algo, world, wire dtype, bytes handed to the collectives per step, bytes each GPU puts on its xGMI links per step
+        (ring / direct all-reduce: 2 (n-1)/n x buffer; reduce-scatter + all-gather: (n-1)/n x (gradient + weights)), exposed_ms =
+        time per step the compute stream waited for the exchange (what the last backward did not hide)}."""
+        if self.pg is None:
+            return None
+        import torch.distributed as dist
+        n = dist.get_world_size(self.pg)
+        wire = 2 if self.h.grad_comm_bf16 else 4
+        numel = self.G.flat.numel()
+        torch.cuda.synchronize()
+        if self.reducer is not None:
+            ev = self.reducer.exposed
+            per_step = self.reducer.wire_bytes / max(1, steps)
+            on_wire = 2.0 * (n - 1) / n * numel * wire
+            algo = "allreduce (bucketed, overlapped with the last backward)" if self.h.overlap_comm else "allreduce (after the last backward)"
+        else:
+            ev = getattr(self, "_comm_events", [])
+            per_step = numel * wire + numel * 2
+            on_wire = (n - 1) / n * (numel * wire + numel * 2)
+            algo = "rs_ag (reduce-scatter + sharded AdamW + all-gather of bf16 weights)"
+        ms = [a.elapsed_time(b) for a, b in ev]
+        return {"algo": algo, "rccl_world": n, "wire_dtype": "bf16" if wire == 2 else "fp32", "bytes_to_collectives_per_step": round(per_step),
+                "bytes_on_wire_per_gpu_per_step": round(on_wire), "exposed_ms": round(sum(ms) / max(1, steps), 3),
+                "exposed_events": len(ms)}

@@ -590,29 +590,34 @@ def split_pair(x32):
     return hi, lo
 
 
-def act_pair(x32, act):
+def act_pair(x32, act, *, pre_out=None):
+    """act(x) as a pair; ``pre_out`` (bf16, same shape) also receives bf16(x): the tape entry act_bwd differentiates at."""
     rows, cols = x32.shape
     hi, lo = _pair_out(rows, cols, x32.device)
-    check(_lib.load().spacer_act_f32_pair(_ptr(x32), _rowmajor(x32), _ptr(hi), _ptr(lo), cols, rows, cols, act, _stream()),
+    assert pre_out is None or (pre_out.dtype == BF16 and pre_out.is_contiguous() and tuple(pre_out.shape) == (rows, cols))
+    check(_lib.load().spacer_act_f32_pair(_ptr(x32), _rowmajor(x32), _ptr(hi), _ptr(lo), cols, rows, cols, act, _ptr(pre_out), _stream()),
           "act_f32_pair")
     return hi, lo
 
 
-def swiglu_pair(gu32):
+def swiglu_pair(gu32, *, gu_out=None):
+    """silu(gate) * up as a pair; ``gu_out`` (bf16 [rows, 2I]) also receives bf16(gate | up) for swiglu_bwd."""
     rows, two_i = gu32.shape
     assert gu32.is_contiguous() and gu32.dtype == torch.float32
+    assert gu_out is None or (gu_out.dtype == BF16 and gu_out.is_contiguous() and tuple(gu_out.shape) == (rows, two_i))
     hi, lo = _pair_out(rows, two_i // 2, gu32.device)
-    check(_lib.load().spacer_swiglu_f32_pair(_ptr(gu32), _ptr(hi), _ptr(lo), rows, two_i // 2, _stream()), "swiglu_f32_pair")
+    check(_lib.load().spacer_swiglu_f32_pair(_ptr(gu32), _ptr(hi), _ptr(lo), rows, two_i // 2, _ptr(gu_out), _stream()), "swiglu_f32_pair")
     return hi, lo
 
 
-def norm_pair(x32, w, b=None, eps=1e-6):
-    """RMSNorm (b is None) or LayerNorm of fp32 rows with the output as a (hi, lo) pair."""
+def norm_pair(x32, w, b=None, eps=1e-6, *, mean=None, rstd=None):
+    """RMSNorm (b is None) or LayerNorm of fp32 rows with the output as a (hi, lo) pair; ``mean`` / ``rstd`` (fp32 [rows]) receive
+    the row statistics the fast path's norm backward kernels take."""
     rows, cols = x32.shape
     assert x32.is_contiguous() and x32.dtype == torch.float32
     hi, lo = _pair_out(rows, cols, x32.device)
     check(_lib.load().spacer_norm_f32_pair(_ptr(x32), _ptr(w), _ptr(b), _ptr(hi), _ptr(lo), rows, cols, eps, int(b is not None),
-                                           _stream()), "norm_f32_pair")
+                                           _ptr(mean), _ptr(rstd), _stream()), "norm_f32_pair")
     return hi, lo
 
 
@@ -635,13 +640,15 @@ def embed_fwd_f32video(ids, table, video32, video_row_of_token):
     return out
 
 
-def attn_fwd_pair(q, k, v, segs, max_q_len, Hq, Hkv, D, causal, scale):
-    """attn_fwd on pair operands: q, k, v are (hi, lo) tuples of views with equal strides; returns the (hi, lo) pair of O."""
+def attn_fwd_pair(q, k, v, segs, max_q_len, Hq, Hkv, D, causal, scale, *, lse=None):
+    """attn_fwd on pair operands: q, k, v are (hi, lo) tuples of views with equal strides; returns the (hi, lo) pair of O.
+    ``lse`` fp32 [Hq, T] receives the log-sum-exp rows attn_bwd reads (taped precise forward)."""
     (qh, ql), (kh, kl), (vh, vl) = q, k, v
     T = qh.shape[0]
     oh, ol = _pair_out(T, Hq * D, qh.device)
     assert qh.stride(0) == ql.stride(0) and kh.stride(0) == kl.stride(0) == vh.stride(0) == vl.stride(0)
-    check(_lib.load().spacer_attn_fwd_pair(_ptr(qh), _ptr(ql), _ptr(kh), _ptr(kl), _ptr(vh), _ptr(vl), _ptr(oh), _ptr(ol), None,
+    assert lse is None or (lse.dtype == torch.float32 and lse.is_contiguous() and tuple(lse.shape) == (Hq, T))
+    check(_lib.load().spacer_attn_fwd_pair(_ptr(qh), _ptr(ql), _ptr(kh), _ptr(kl), _ptr(vh), _ptr(vl), _ptr(oh), _ptr(ol), _ptr(lse),
                                            qh.stride(0), kh.stride(0), oh.stride(0), _ptr(segs), segs.shape[0], max_q_len, T, Hq, Hkv,
                                            D, int(causal), scale, _stream()), "attn_fwd_pair")
     return oh, ol

@@ -71,6 +71,9 @@ class GRPOConfig:                              # the trl.GRPOConfig / TrainingAr
     # gradient-accumulation micro-batches scored / back-propagated per token-packed pass (GRPOEngine.score_and_backward_multi);
     # 2 fits 288 GB at 7B with 16-frame prompts and 512-token rollouts, 1 = one prompt group per pass
     groups_per_pass: int = 2
+    # --precise_logps true: policy and reference per-token log-probs (KL, loss, metrics: TR:527-552) evaluated in the precise mode
+    # (within 1e-3 of an fp32 evaluation at full 7B depth; GRPOHyper.precise_logps); the gradient runs on the production backward
+    precise_logps: bool = False
     grad_algo: str = "allreduce"               # data-parallel exchange: "allreduce" (overlapped, replicated AdamW) or "rs_ag" (GRPOHyper.grad_algo)
     # vLLM-trainer topology (trl.GRPOConfig fields read by vllm_grpo_trainer_modified.py:300,325,362): generation on a dedicated GPU
     use_vllm: bool = False

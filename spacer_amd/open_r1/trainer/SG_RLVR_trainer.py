@@ -207,7 +207,10 @@ class SGRLVRTrainer:
                           adam_eps=args.adam_epsilon, max_grad_norm=args.max_grad_norm, temporal=self.temporal,
                           len_control=self.len_control, lr_scheduler_type=args.lr_scheduler_type, total_steps=total_steps,
                           warmup_steps=args.warmup_steps, recompute=bool(getattr(args, "gradient_checkpointing", False)),
-                          grad_algo=getattr(args, "grad_algo", "allreduce"))
+                          grad_algo=getattr(args, "grad_algo", "allreduce"), precise_logps=bool(getattr(args, "precise_logps", False)))
+        if hyper.precise_logps:
+            self._note("--precise_logps true: policy / reference log-probs in the precise mode (hi+lo bf16 operand pairs; <= 1e-3 of fp32 "
+                       "at full depth), gradient on the production backward of the same tape")
         if hyper.recompute:
             self._note("--gradient_checkpointing true: selective activation recompute (MLP intermediates + lm_head logits are "
                        "recomputed in the backward; gradients are bit-identical to the stored path)")
@@ -216,7 +219,7 @@ class SGRLVRTrainer:
         # copy of master weights + Adam state would not fit)
         if engine is not None:
             # an injected engine keeps ITS hyper-parameters: refuse a silent mismatch with what ``args`` asks for
-            for key in ("num_generations", "beta", "max_grad_norm"):
+            for key in ("num_generations", "beta", "max_grad_norm", "precise_logps"):
                 if getattr(engine.h, key) != getattr(hyper, key):
                     raise ValueError(f"engine= was built with {key}={getattr(engine.h, key)!r} but args ask for {getattr(hyper, key)!r}")
         self.engine = engine if engine is not None else GRPOEngine(cfg, params, hyper, process_group=process_group)

@@ -209,7 +209,8 @@ class Qwen2VLEngine:
         Np = tape["pix"].shape[0]
         scale = hd ** -0.5
         cos, sin = tape["cos"], tape["sin"]
-        d_merged = K.gather_rows(d_out, tape["unit_perm"])                   # out[i] = merged[rev[i]]  =>  d_merged[u] = d_out[perm[u]]
+        # out[i] = merged[rev[i]]  =>  d_merged[u] = d_out[perm[u]]; a precise-mode tape hands d_out over in the tower's order already
+        d_merged = K.gather_rows(d_out, tape["unit_perm"]) if tape["unit_perm"] is not None else d_out
         d_g = self._dx(d_merged, "merger.m2_w")
         self._dw(G["merger.m2_w"], d_merged, tape["g"]); K.bias_grad_(d_merged, G["merger.m2_b"])
         d_m1 = K.act_bwd(tape["m1"], d_g, K.SPACER_ACT_GELU_ERF)
@@ -315,15 +316,20 @@ class Qwen2VLEngine:
             ready(p)
         return dx
 
-    # ================================================================== precise scoring mode (forward only)
+    # ================================================================== precise mode (forward; optionally emits the backward's tape)
     # csrc/precise.hip: every activation between operators is fp32 or a (hi, lo) bf16 pair, every linear layer is two
     # accumulate passes of the production GEMM, attention runs on pair operands.  Same operator order as the fast path.
-    def _vit_forward_precise(self, pix: torch.Tensor, grids) -> torch.Tensor:
-        """pix bf16 [Np, patch_kpad] -> merged vision embeds fp32 [Np/4, hidden] (in merge-unit order)."""
+    # With ``tape``: the forward also leaves exactly what the FAST backward reads -- the fp32 residual-stream copies, the norm
+    # statistics, the attention log-sum-exp, bf16 pre-activations, and the hi halves of the pairs as the bf16 activations -- so
+    # ``backward_group`` runs unchanged on a tape whose log-probs hold the north-star's 1e-3 (GRPOHyper.precise_logps).
+    def _vit_forward_precise(self, pix: torch.Tensor, grids, tape: Optional[dict] = None):
+        """pix bf16 [Np, patch_kpad] -> (merged vision embeds fp32 [Np/4, hidden] in merge-unit order of the tower, unit_rev)."""
         cfg, W = self.cfg, self.W
         D, Hh, hd = cfg.vit_dim, cfg.vit_heads, cfg.vit_head_dim
         Np = pix.shape[0]
         v25 = cfg.vit_kind == "qwen2_5"
+        taped = tape is not None
+        keep = taped and not self.recompute
         cos, sin = POS.vit_tables(grids, cfg, self.dev)
         frame_list = POS.vit_segments(grids)
         frame_segs, max_frame = K.make_segments(frame_list, self.dev), max(s[1] for s in frame_list)
@@ -335,49 +341,93 @@ class Qwen2VLEngine:
             win_segs, max_win = K.make_segments(win_list, self.dev), max(s[1] for s in win_list)
             pix = K.gather_rows(pix, rows_dev.int())
         scale = hd ** -0.5
+        stat = (lambda: self._empty(Np)) if taped else (lambda: None)
         x = K.gemm_nt(pix, W["vit.patch_w"], out_dtype=F32)                # pixel rows are exactly bf16: one pass
+        blocks: List[dict] = []
         for i in range(cfg.vit_depth):
             p = f"vit.{i}."
             segs, max_q = (frame_segs, max_frame) if (not v25 or i in cfg.vit_fullatt) else (win_segs, max_win)
-            h = K.norm_pair(x, W[p + "n1_w"], None if v25 else W[p + "n1_b"], 1e-6)
+            mean1, rstd1 = (None if v25 else stat()), stat()
+            h = K.norm_pair(x, W[p + "n1_w"], None if v25 else W[p + "n1_b"], 1e-6, mean=mean1, rstd=rstd1)
             qkv32 = K.gemm_pair(*h, W[p + "qkv_w"], bias=W[p + "qkv_b"])
             qh, ql = K.rope_pair(qkv32, cos, sin, 2 * Hh, 3 * Hh, hd)
             del qkv32
+            lse = self._empty(Hh, Np) if taped else None
             o = K.attn_fwd_pair((qh[:, :D], ql[:, :D]), (qh[:, D:2 * D], ql[:, D:2 * D]), (qh[:, 2 * D:], ql[:, 2 * D:]),
-                                segs, max_q, Hh, Hh, hd, False, scale)
-            K.gemm_pair(*o, W[p + "proj_w"], bias=W[p + "proj_b"], residual=x, out=x)
-            h2 = K.norm_pair(x, W[p + "n2_w"], None if v25 else W[p + "n2_b"], 1e-6)
+                                segs, max_q, Hh, Hh, hd, False, scale, lse=lse)
+            del ql
+            # taped: every residual-stream state is its own buffer (the backward reads x_in / x_mid); else updated in place
+            x_mid = K.gemm_pair(*o, W[p + "proj_w"], bias=W[p + "proj_b"], residual=x, out=None if taped else x)
+            mean2, rstd2 = (None if v25 else stat()), stat()
+            h2 = K.norm_pair(x_mid, W[p + "n2_w"], None if v25 else W[p + "n2_b"], 1e-6, mean=mean2, rstd=rstd2)
             if v25:
-                a = K.swiglu_pair(K.gemm_pair(*h2, W[p + "gu_w"], bias=W[p + "gu_b"]))
-                K.gemm_pair(*a, W[p + "down_w"], bias=W[p + "down_b"], residual=x, out=x)
+                gu32 = K.gemm_pair(*h2, W[p + "gu_w"], bias=W[p + "gu_b"])
+                pre = self._empty(*gu32.shape, dtype=BF16) if keep else None
+                a = K.swiglu_pair(gu32, gu_out=pre)
+                del gu32
+                x_out = K.gemm_pair(*a, W[p + "down_w"], bias=W[p + "down_b"], residual=x_mid, out=None if taped else x_mid)
+                if taped:
+                    blocks.append(dict(x_in=x, rstd1=rstd1, h=h[0], qkv=qh, o=o[0], lse=lse, x_mid=x_mid, rstd2=rstd2, h2=h2[0], gu=pre,
+                                       a=a[0] if keep else None, segs=segs, max_q=max_q))
             else:
-                a = K.act_pair(K.gemm_pair(*h2, W[p + "fc1_w"], bias=W[p + "fc1_b"]), K.SPACER_ACT_QUICK_GELU)
-                K.gemm_pair(*a, W[p + "fc2_w"], bias=W[p + "fc2_b"], residual=x, out=x)
-        hm = K.norm_pair(x, W["merger.ln_w"], None if v25 else W["merger.ln_b"], 1e-6)
+                f32 = K.gemm_pair(*h2, W[p + "fc1_w"], bias=W[p + "fc1_b"])
+                pre = self._empty(*f32.shape, dtype=BF16) if keep else None
+                a = K.act_pair(f32, K.SPACER_ACT_QUICK_GELU, pre_out=pre)
+                del f32
+                x_out = K.gemm_pair(*a, W[p + "fc2_w"], bias=W[p + "fc2_b"], residual=x_mid, out=None if taped else x_mid)
+                if taped:
+                    blocks.append(dict(x_in=x, mean1=mean1, rstd1=rstd1, h=h[0], qkv=qh, o=o[0], lse=lse, x_mid=x_mid, mean2=mean2,
+                                       rstd2=rstd2, h2=h2[0], f1=pre, a=a[0] if keep else None))
+            del h, o, h2, a
+            x = x_out
+        mean, rstd = (None if v25 else stat()), stat()
+        hm = K.norm_pair(x, W["merger.ln_w"], None if v25 else W["merger.ln_b"], 1e-6, mean=mean, rstd=rstd)
         m4 = cfg.merge ** 2
-        g = K.act_pair(K.gemm_pair(hm[0].view(Np // m4, m4 * D), hm[1].view(Np // m4, m4 * D), W["merger.m0_w"],
-                                   bias=W["merger.m0_b"]), K.SPACER_ACT_GELU_ERF)
+        hm4 = hm[0].view(Np // m4, m4 * D)
+        m32 = K.gemm_pair(hm4, hm[1].view(Np // m4, m4 * D), W["merger.m0_w"], bias=W["merger.m0_b"])
+        m1 = self._empty(*m32.shape, dtype=BF16) if taped else None
+        g = K.act_pair(m32, K.SPACER_ACT_GELU_ERF, pre_out=m1)
         merged = K.gemm_pair(*g, W["merger.m2_w"], bias=W["merger.m2_b"])
+        if taped:
+            # unit_perm None: the gradient of the vision rows arrives in the tower's own (window) order -- the embedding maps the
+            # placeholder tokens through unit_rev instead of gathering the rows back
+            tape.update(pix=pix, blocks=blocks, x_last=x, mean=mean, rstd=rstd, hm4=hm4, m1=m1, g=g[0], cos=cos, sin=sin,
+                        segs=frame_segs, max_q=max_frame, unit_perm=None)
         return merged, (None if unit_perm is None else torch.argsort(unit_perm).to(self.dev))
 
-    def _llm_forward_precise(self, x: torch.Tensor, cos, sin, segs, max_q: int) -> torch.Tensor:
-        """x fp32 [T, hidden], updated in place layer by layer -> the stream before the final norm."""
+    def _llm_forward_precise(self, x: torch.Tensor, cos, sin, segs, max_q: int, tape: Optional[list] = None) -> torch.Tensor:
+        """x fp32 [T, hidden] -> the stream before the final norm (updated in place layer by layer unless taped)."""
         cfg, W = self.cfg, self.W
         Hq, Hkv, D = cfg.heads, cfg.kv_heads, cfg.head_dim
         qd, kd = Hq * D, Hkv * D
+        T = x.shape[0]
         scale = D ** -0.5
+        taped = tape is not None
+        keep = taped and not self.recompute
         for i in range(cfg.layers):
             p = f"llm.{i}."
-            h = K.norm_pair(x, W[p + "ln1_w"], None, cfg.rms_eps)
+            rstd1 = self._empty(T) if taped else None
+            h = K.norm_pair(x, W[p + "ln1_w"], None, cfg.rms_eps, rstd=rstd1)
             qkv32 = K.gemm_pair(*h, W[p + "qkv_w"], bias=W[p + "qkv_b"])
             qh, ql = K.rope_pair(qkv32, cos, sin, Hq + Hkv, Hq + 2 * Hkv, D)
             del qkv32
+            lse = self._empty(Hq, T) if taped else None
             o = K.attn_fwd_pair((qh[:, :qd], ql[:, :qd]), (qh[:, qd:qd + kd], ql[:, qd:qd + kd]), (qh[:, qd + kd:], ql[:, qd + kd:]),
-                                segs, max_q, Hq, Hkv, D, True, scale)
-            K.gemm_pair(*o, W[p + "o_w"], residual=x, out=x)
-            h2 = K.norm_pair(x, W[p + "ln2_w"], None, cfg.rms_eps)
-            a = K.swiglu_pair(K.gemm_pair(*h2, W[p + "gu_w"]))
-            K.gemm_pair(*a, W[p + "down_w"], residual=x, out=x)
+                                segs, max_q, Hq, Hkv, D, True, scale, lse=lse)
+            del ql
+            x_mid = K.gemm_pair(*o, W[p + "o_w"], residual=x, out=None if taped else x)
+            rstd2 = self._empty(T) if taped else None
+            h2 = K.norm_pair(x_mid, W[p + "ln2_w"], None, cfg.rms_eps, rstd=rstd2)
+            gu32 = K.gemm_pair(*h2, W[p + "gu_w"])
+            gu = self._empty(*gu32.shape, dtype=BF16) if keep else None
+            a = K.swiglu_pair(gu32, gu_out=gu)
+            del gu32
+            x_out = K.gemm_pair(*a, W[p + "down_w"], residual=x_mid, out=None if taped else x_mid)
+            if taped:
+                tape.append(dict(x_in=x, rstd1=rstd1, h=h[0], qkv=qh, o=o[0], lse=lse, x_mid=x_mid, rstd2=rstd2, h2=h2[0], gu=gu,
+                                 a=a[0] if keep else None))
+            del h, o, h2, a
+            x = x_out
         return x
 
     # ================================================================== embeddings
@@ -433,14 +483,13 @@ class Qwen2VLEngine:
         assert all(tuple(c.shape) == (Kn, C) for c in completions) and len(prompts) == len(completions)
         with_video = [g for g, (_, pix, _) in enumerate(prompts) if pix is not None]
         assert len(with_video) in (0, len(prompts)), "groups of one pass either all carry vision inputs or none does"
-        assert not (precise and tape is not None), "the precise scoring mode is forward only"
         vit_tape = {} if tape is not None else None
         video, all_grids, unit_rev = None, [], None
         if with_video:
             all_grids = [g for _, _, gr in prompts for g in gr]
             pix_all = prompts[0][1] if len(prompts) == 1 else torch.cat([p[1] for p in prompts], 0)
             if precise:
-                video, unit_rev = self._vit_forward_precise(pix_all, all_grids)
+                video, unit_rev = self._vit_forward_precise(pix_all, all_grids, vit_tape)
             else:
                 video = self.vit_forward(pix_all, all_grids, vit_tape)
         ids_parts, pos_parts, seg_list, sel_parts, scope = [], [], [], [], []
@@ -463,29 +512,34 @@ class Qwen2VLEngine:
         sel = torch.cat(sel_parts).to(self.dev)
         max_q = max(s[1] for s in seg_list)
         targets = torch.cat([c.reshape(-1) for c in completions]).contiguous()
-        if precise:
-            x0 = self.embed(ids, video, placeholder_scopes=scope, unit_rev=unit_rev)[0]
-            x = self._llm_forward_precise(x0, cos, sin, segs, max_q)
-            hn = K.norm_pair(x, self.W["llm.norm_w"], None, cfg.rms_eps)
-            logits = K.gemm_pair(K.gather_rows(hn[0], sel), K.gather_rows(hn[1], sel), self.W["llm.lm_head"])
-            return K.logprob_fwd(logits, targets)[0].view(len(prompts) * Kn, C)
-        x0, vrow = self.embed(ids, video, placeholder_scopes=scope)
         llm_tape = [] if tape is not None else None
-        x = self.llm_forward(x0, cos, sin, segs, max_q, tape=llm_tape)
-        logp = self.head_forward(x, sel, targets, tape)
+        if precise:
+            x0, vrow = self.embed(ids, video, placeholder_scopes=scope, unit_rev=unit_rev)
+            x = self._llm_forward_precise(x0, cos, sin, segs, max_q, tape=llm_tape)
+        else:
+            x0, vrow = self.embed(ids, video, placeholder_scopes=scope)
+            x = self.llm_forward(x0, cos, sin, segs, max_q, tape=llm_tape)
+        logp = self.head_forward(x, sel, targets, tape, precise=precise)
         if tape is not None:
             tape.update(vit=vit_tape, llm=llm_tape, ids=ids, vrow=vrow, cos=cos, sin=sin, segs=segs, max_q=max_q, T=T,
                         has_video=video is not None)
         return logp.view(len(prompts) * Kn, C)
 
     # ================================================================== head: final norm -> lm_head -> log-prob of the targets
-    def head_forward(self, x: torch.Tensor, sel: torch.Tensor, targets: torch.Tensor, tape: Optional[dict] = None) -> torch.Tensor:
+    def head_forward(self, x: torch.Tensor, sel: torch.Tensor, targets: torch.Tensor, tape: Optional[dict] = None, *,
+                     precise: bool = False) -> torch.Tensor:
         """x fp32 [T, hidden] (pre-final-norm stream); rows ``sel`` (int32) predict ``targets`` (int64): the reference's
-        ``log_softmax(logits)[token]`` (TR:353-366) on the completion rows only.  Returns logp fp32 [len(sel)]."""
+        ``log_softmax(logits)[token]`` (TR:353-366) on the completion rows only.  Returns logp fp32 [len(sel)].  ``precise``: the
+        normed rows travel as a (hi, lo) pair and every vocabulary chunk is a two-pass GEMM (csrc/precise.hip)."""
         cfg = self.cfg
         rstd_f = self._empty(x.shape[0])
-        hn = K.rmsnorm_fwd(x, self.W["llm.norm_w"], cfg.rms_eps, rstd=rstd_f)
-        hsel = K.gather_rows(hn, sel)
+        hsel_lo = None
+        if precise:
+            hn = K.norm_pair(x, self.W["llm.norm_w"], None, cfg.rms_eps, rstd=rstd_f)
+            hsel, hsel_lo = K.gather_rows(hn[0], sel), K.gather_rows(hn[1], sel)
+        else:
+            hn = K.rmsnorm_fwd(x, self.W["llm.norm_w"], cfg.rms_eps, rstd=rstd_f)
+            hsel = K.gather_rows(hn, sel)
         del hn
         # lm_head over vocabulary chunks with an online log-sum-exp (SURVEY K17): a chunk's fp32 logits update the running
         # (max, sum-exp, target logit) of every row and are dead afterwards.  Only a taped pass WITHOUT the recompute policy keeps
@@ -499,11 +553,14 @@ class Qwen2VLEngine:
         for c0 in range(0, V, ch):
             c1 = min(V, c0 + ch)
             lg = logits[:, c0:c1] if store else buf[:, :c1 - c0]
-            K.gemm_nt(hsel, Wlm[c0:c1], out=lg, out_dtype=F32)
+            if precise:
+                K.gemm_pair(hsel, hsel_lo, Wlm[c0:c1], out=lg)
+            else:
+                K.gemm_nt(hsel, Wlm[c0:c1], out=lg, out_dtype=F32)
             K.lse_chunk_(lg, targets, c0, state, first=c0 == 0)
         logp, lse = K.lse_finish(state)
         if tape is not None:
-            tape.update(sel=sel, x_final=x, rstd_f=rstd_f, hsel=hsel, logits=logits, targets=targets, lse=lse)
+            tape.update(sel=sel, x_final=x, rstd_f=rstd_f, hsel=hsel, hsel_lo=hsel_lo, logits=logits, targets=targets, lse=lse)
         return logp
 
     def head_backward(self, tape: dict, dlogp: torch.Tensor, G: FlatParams) -> torch.Tensor:
@@ -525,6 +582,8 @@ class Qwen2VLEngine:
             c1 = min(V, c0 + ch)
             if logits is not None:
                 lg = logits[:, c0:c1]
+            elif tape.get("hsel_lo") is not None:       # recompute policy behind a precise forward: the same two-pass chunk GEMM
+                lg = K.gemm_pair(hsel, tape["hsel_lo"], Wlm[c0:c1], out=buf[:, :c1 - c0])
             else:
                 lg = K.gemm_nt(hsel, Wlm[c0:c1], out=buf[:, :c1 - c0], out_dtype=F32)
             dl = K.logprob_bwd_chunk(lg, targets, c0, lse, g, dl_buf[:, :c1 - c0])

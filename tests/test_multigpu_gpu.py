@@ -68,10 +68,17 @@ def _dp_step(rank, world, pg, dev):
         ge = GRPOEngine(TINY, params, GRPOHyper(num_generations=3, learning_rate=1e-3, grad_algo=algo), process_group=pg)
         pix, grid = K.patchify(g["frames"].to(dev), kpad=TINY.patch_kpad)
         prompt = PromptInput(g["prompt"].to(dev), pix, [tuple(grid)])
+        text_only = PromptInput(g["prompt"][-9:].to(dev), None, None)
+        ge.comm_timing(True)
         for step in range(2):
             comp = ge.rollout([prompt], SamplingParams(max_new_tokens=8, seed=1 + rank + 10 * step))
             adv, _ = group_advantages(torch.tensor([2.0, 0.0, 1.0]), 3)
-            ge.score_and_backward(prompt, comp, adv.to(dev), last_group=True)
+            # two micro-batches per step; the LAST one (whose backward feeds the overlapped reducer) is TEXT-ONLY on the odd ranks
+            # and a video row on the even ones: every rank must still issue the same sequence of collectives
+            ge.score_and_backward(prompt, comp, adv.to(dev), grad_scale=0.5)
+            last = text_only if rank % 2 else prompt
+            comp2 = ge.rollout([last], SamplingParams(max_new_tokens=8, seed=77 + rank + 10 * step))
+            ge.score_and_backward(last, comp2, adv.to(dev), grad_scale=0.5, last_group=True)
             ge.reduce_gradients()
             ge.optimizer_step(world)
             torch.cuda.synchronize()
@@ -79,6 +86,10 @@ def _dp_step(rank, world, pg, dev):
             both = [None] * world
             dist.all_gather_object(both, mine, group=pg)
             ok = ok and all(torch.equal(both[0], b) for b in both) and not torch.equal(mine, ge.ref.flat.float().cpu())
+        st = ge.comm_stats(2)
+        ok = ok and st["rccl_world"] == world and st["bytes_on_wire_per_gpu_per_step"] >= 0 and algo.split("_")[0] in st["algo"]
+        if dist.get_backend(pg) == "nccl":
+            ok = ok and st["exposed_events"] > 0 and st["exposed_ms"] >= 0.0      # the reducer's side stream / the sharded collectives were timed
         ge.gather_optimizer_state()
         masters = [None] * world
         dist.all_gather_object(masters, ge.master.flat.cpu(), group=pg)

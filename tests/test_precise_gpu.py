@@ -113,7 +113,8 @@ def test_attention_pair_matches_fp64(dev, case):
     cut = lambda t: (t[:, :qd], t[:, qd:qd + kd], t[:, qd + kd:])                # noqa: E731
     (qh, kh, vh), (ql, kl, vl) = cut(hi), cut(lo)
     scale = D ** -0.5
-    o = K.attn_fwd_pair((qh, ql), (kh, kl), (vh, vl), K.make_segments(segs, dev), max(s[1] for s in segs), Hq, Hkv, D, causal, scale)
+    lse = torch.full((Hq, T), float("nan"), device=dev)
+    o = K.attn_fwd_pair((qh, ql), (kh, kl), (vh, vl), K.make_segments(segs, dev), max(s[1] for s in segs), Hq, Hkv, D, causal, scale, lse=lse)
     q64, k64, v64 = cut(pair_f64((hi, lo)))
     mask = dense_mask(segs, T, causal)
     # fp64 reference (attn_ref of test_kernels_gpu.py computes in fp32): two orders below the pair error
@@ -126,8 +127,41 @@ def test_attention_pair_matches_fp64(dev, case):
     err = rel_err(pair_f64(o), want)
     # score error 2^-16 |s| with |s| ~ 10 moves a probability by ~1e-4 relative: the bound is on O's scale
     assert err <= 3e-4, (name, err)
+    # the log-sum-exp rows the fast backward reads (round 4: a taped precise forward), on the rows some segment owns
+    owned = torch.zeros(T, dtype=torch.bool)
+    for qs, ql_, _, _ in segs:
+        owned[qs:qs + ql_] = True
+    want_lse = torch.logsumexp(s, -1)[:, owned.to(dev)]
+    assert float((lse.double()[:, owned.to(dev)] - want_lse).abs().max()) <= 2e-4, name
     o16, _ = K.attn_fwd(qh, kh, vh, K.make_segments(segs, dev), max(s[1] for s in segs), Hq, Hkv, D, causal, scale)
     assert rel_err(o16.double(), want) > 10 * err                                # and far below the bf16 kernel's
+
+
+def test_pair_producers_emit_the_tape_entries_of_the_fast_backward(dev):
+    """Round 4: norm statistics, bf16 pre-activations (what act_bwd / swiglu_bwd differentiate at) from the pair producers."""
+    g = torch.Generator(device="cpu").manual_seed(4)
+    x = (torch.randn(70, 3584, generator=g) * 3 + 0.5).to(dev)
+    w = (1 + 0.2 * torch.randn(3584, generator=g)).to(dev).to(BF)
+    b = (0.1 * torch.randn(3584, generator=g)).to(dev).to(BF)
+    mean, rstd = torch.empty(70, device=dev), torch.empty(70, device=dev)
+    K.norm_pair(x, w, b, 1e-6, mean=mean, rstd=rstd)
+    xd = x.double()
+    assert float((mean.double() - xd.mean(-1)).abs().max()) <= 1e-5
+    assert rel_err(rstd.double(), torch.rsqrt(xd.var(-1, unbiased=False) + 1e-6)) <= 1e-5
+    K.norm_pair(x, w, None, 1e-6, rstd=rstd)
+    assert rel_err(rstd.double(), torch.rsqrt(xd.pow(2).mean(-1) + 1e-6)) <= 1e-5
+    # the fast path's own norm kernels report the same statistics
+    r_fast = torch.empty(70, device=dev)
+    K.rmsnorm_fwd(x, w, 1e-6, rstd=r_fast)
+    assert rel_err(rstd.double(), r_fast.double()) <= 1e-5
+    f = (torch.randn(33, 5120, generator=g) * 2).to(dev)
+    pre = torch.empty(33, 5120, device=dev, dtype=BF)
+    K.act_pair(f, K.SPACER_ACT_QUICK_GELU, pre_out=pre)
+    assert torch.equal(pre, f.to(BF))
+    gu = (torch.randn(33, 2 * 2560, generator=g) * 2).to(dev)
+    gu16 = torch.empty(33, 2 * 2560, device=dev, dtype=BF)
+    a = K.swiglu_pair(gu, gu_out=gu16)
+    assert torch.equal(gu16, gu.to(BF)) and torch.equal(a[0], K.swiglu_pair(gu)[0])
 
 
 # ----------------------------------------------------------------------------------------------- model level
@@ -223,3 +257,120 @@ def test_precise_logps_hold_1e3_at_qwen2vl_7b_depth(dev):
           f"{time.time() - t0:.0f} s on the host")
     assert torch.isfinite(lp).all()
     assert float(e.max()) <= 1e-3, float(e.max())
+
+
+# ----------------------------------------------------------------------------------------------- round 4: the precise TRAINING step
+@pytest.mark.parametrize("which", ["tiny", "tiny_tied", "tiny25"])
+@pytest.mark.parametrize("recompute", [False, True], ids=["stored", "recompute"])
+def test_taped_precise_forward_feeds_the_production_backward(dev, which, recompute):
+    """``score_groups(precise=True, tape=...)``: (i) the taped forward gives the log-probs of the untaped precise forward bit for bit
+    (the tape only redirects the residual-stream updates into their own buffers and switches the statistic / pre-activation outputs
+    on); (ii) the production backward kernels on that tape -- hi halves as the bf16 activations, the pair attention's log-sum-exp,
+    the pair norms' statistics -- give the gradients of oracle autograd within the fast path's own tolerance (4 % of max |g|);
+    Qwen2.5-VL: the vision gradient arrives in the tower's window order (no gather back)."""
+    g, wb, eng, pix, rows, grid = _tiny_setup(dev, which)
+    eng.recompute = recompute
+    comps = g["completions"]
+    Kn, C = comps.shape
+    prompt = g["prompt"].to(dev)
+    lp = eng.score_group(prompt, comps.to(dev), pix, [grid], precise=True)
+    tape = {}
+    lp_t = eng.score_group(prompt, comps.to(dev), pix, [grid], precise=True, tape=tape)
+    assert torch.equal(lp, lp_t)
+    dlogp = torch.randn(Kn, C, generator=torch.Generator().manual_seed(5)) * 0.5
+    wr = {k: v.clone().requires_grad_(True) for k, v in wb.items()}
+    lp_o = O.completion_logps(wr, g["cfg"], g["prompt"], comps, rows, [grid])
+    assert float((lp_t.cpu() - lp_o.detach()).abs().max()) <= 1e-4
+    (lp_o * dlogp).sum().backward()
+    G = eng.W.like(torch.float32)
+    eng.backward_group(tape, dlogp.to(dev), G)
+    got = export_state_dict(G)
+    got["visual.patch_embed.proj.weight"] = got["visual.patch_embed.proj.weight"].reshape(eng.cfg.vit_dim, -1)
+    bad, worst = [], 0.0
+    for name, ref in wr.items():
+        gr = ref.grad if ref.grad is not None else torch.zeros_like(ref)
+        ge = got[name].float().cpu()
+        scale, err = float(gr.abs().max()), float((ge - gr).abs().max())
+        worst = max(worst, err / (scale + 1e-6))
+        if not err <= 0.04 * scale + 2e-4:
+            bad.append((name, err, scale))
+    print(f"{which} ({'recompute' if recompute else 'stored'}): worst gradient error on a precise tape {worst:.3f} of max |g|")
+    assert not bad, bad
+    # text-only group: same code, no vision tape
+    tape2 = {}
+    lp2 = eng.score_group(prompt[-9:], comps.to(dev), None, None, precise=True, tape=tape2)
+    eng.backward_group(tape2, dlogp.to(dev), eng.W.like(torch.float32))
+    assert float((lp2.cpu() - O.completion_logps(wb, g["cfg"], g["prompt"][-9:], comps, None, None)).abs().max()) <= 1e-4
+
+
+def test_precise_grpo_step_matches_the_cpu_oracle_at_qwen2vl_2b_depth(dev):
+    """ONE FULL GRPO step (reference + policy scoring, k3 KL, loss, backward) with ``GRPOHyper.precise_logps`` at
+    Qwen2-VL-2B depth (28 + 32 layers, tied lm_head), the frozen reference model DIFFERENT from the policy (as after optimizer steps;
+    KL > 0), against the CPU restatement of TR:353-366 (log-probs), TR:493-498 (mask), TR:551-552 (KL) and TR:640-643 (loss) on the
+    same weights: policy / reference log-probs, loss and KL within the north-star's 1e-3, and the gradient that the production
+    backward takes from the precise tape within the depth test's 6 % of oracle autograd.  The fast step's numbers are printed."""
+    import time
+    from oracle import grpo_ref as GR
+    from spacer_amd.grpo import GRPOEngine, GRPOHyper
+    from spacer_amd.rollout import PromptInput
+    cfg = QWEN2_VL_2B
+    torch.cuda.empty_cache()
+    params = FlatParams.empty(cfg, dev)
+    random_init_(params, seed=1234)
+    ref = FlatParams(cfg, params.flat.clone(), params.specs)
+    noise = torch.randn(ref.flat.numel(), device=dev, generator=torch.Generator(device=dev).manual_seed(7))
+    ref.flat.copy_((ref.flat.float() * (1.0 + 0.03 * noise)).to(BF))
+    del noise
+    prompt, frames = make_prompt(cfg, 5, 4, 112, 140, 200, dev)
+    comps = torch.randint(1000, 150000, (2, 24), generator=torch.Generator().manual_seed(9))
+    comps[1, 15] = cfg.eos_token_id                                   # a finished rollout: the mask ends row 1 after 16 tokens
+    adv = torch.tensor([1.0, -1.0])
+    names = ["model.layers.27.mlp.down_proj.weight", "model.layers.13.self_attn.q_proj.weight", "model.embed_tokens.weight",
+             "visual.blocks.0.attn.qkv.weight"]
+    ocfg = cfg.as_oracle_dict()
+    rows, grid = O.patchify_frames(frames.cpu(), ocfg)
+    rows = rows.to(BF).float()
+
+    def host(p):
+        w = {k: v.float().cpu() for k, v in export_state_dict(p).items()}
+        w["visual.patch_embed.proj.weight"] = w["visual.patch_embed.proj.weight"].reshape(cfg.vit_dim, -1)
+        return w
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    t0 = time.time()
+    w_pol, w_ref = host(params), host(ref)
+    for n in names:
+        w_pol[n].requires_grad_(True)
+    with torch.no_grad():
+        ref_o = O.completion_logps(w_ref, ocfg, prompt.ids.cpu(), comps, rows, [tuple(grid)])
+    del w_ref
+    lp_o = O.completion_logps(w_pol, ocfg, prompt.ids.cpu(), comps, rows, [tuple(grid)])
+    mask = GR.completion_mask(comps, cfg.eos_token_id)
+    loss_o = GR.grpo_loss(lp_o, ref_o, adv, mask, 0.04)
+    kl_o = float(GR.kl_metric(lp_o.detach(), ref_o, mask))
+    loss_o.backward()
+    t_oracle = time.time() - t0
+    res = {}
+    for mode in (True, False):
+        ge = GRPOEngine(cfg, params, GRPOHyper(num_generations=2, beta=0.04, precise_logps=mode), ref=ref)
+        r = ge.score_and_backward(PromptInput(prompt.ids, prompt.pix, prompt.grids), comps.to(dev), adv.to(dev))
+        res[mode] = dict(lp=r["logps"].cpu(), ref=r["ref_logps"].cpu(), loss=float(r["loss"]), kl=float(r["kl"]),
+                         G=export_state_dict(ge.G) if mode else None)
+        assert torch.equal(r["mask"].cpu(), mask)
+        del ge, r
+        torch.cuda.empty_cache()
+    for mode, tag in ((False, "fast step   "), (True, "precise step")):
+        r = res[mode]
+        print(f"   {tag}: max |logp - oracle| policy {float((r['lp'] - lp_o.detach()).abs().max()):.2e} reference "
+              f"{float((r['ref'] - ref_o).abs().max()):.2e}; loss {r['loss']:+.6f} (oracle {float(loss_o):+.6f}); kl {r['kl']:.6f} (oracle {kl_o:.6f})")
+    print(f"   oracle (2 forwards + autograd backward on the host): {t_oracle:.0f} s")
+    r = res[True]
+    assert kl_o > 1e-3                                                       # the case is not the trivial ref == policy one
+    assert float((r["lp"] - lp_o.detach()).abs().max()) <= 1e-3 and float((r["ref"] - ref_o).abs().max()) <= 1e-3
+    assert abs(r["loss"] - float(loss_o)) <= 1e-3 and abs(r["kl"] - kl_o) <= 1e-3
+    got = r["G"]
+    got["visual.patch_embed.proj.weight"] = got["visual.patch_embed.proj.weight"].reshape(cfg.vit_dim, -1)
+    for n in names:
+        gr, gg = w_pol[n].grad, got[n].float().cpu()
+        rel = float((gg - gr).norm() / (gr.norm() + 1e-30))
+        print(f"   grad {n:44s} rel Frobenius err {rel:.3e}")
+        assert rel <= 6e-2, (n, rel)
