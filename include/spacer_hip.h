@@ -367,6 +367,13 @@ int spacer_adamw_step(float* master, void* shadow_bf16, float* m, float* v, cons
  * enter KL, loss and metrics) evaluates its forward in this mode and back-propagates through the production kernels on the hi
  * halves (spacer_attn_bwd, spacer_gemm_bf16 dX / dW, spacer_rmsnorm_bwd, ...).  All such outputs are optional (NULL).
  * ---------------------------------------------------------------------------------------------- */
+/* A linear layer on a pair operand in ONE launch: C = (A_hi + A_lo) . B^T (+ bias, residual, alpha as spacer_gemm_bf16_nt; C fp32
+ * or bf16) over the K-concatenated operands [A_hi | A_lo] . [B | B]^T on the 256-tile kernel -- the fp32 output is written once
+ * instead of written, re-read and re-written by a second accumulate pass.  A_hi / A_lo share lda.  Only problems the 256 tile takes
+ * (spacer_gemm_pair_fused(M, N, K, have_workspace, plan) != 0); otherwise SPACER_EINVAL and the caller runs the two passes. */
+int spacer_gemm_pair_fused(int M, int N, int K, int have_workspace, const spacer_plan* plan);
+int spacer_gemm_bf16_pair_nt(const void* A_hi, const void* A_lo, long lda, const void* B, long ldb, void* C, long ldc, int M, int N,
+                             int K, const spacer_gemm_epilogue* epi, spacer_stream_t stream);
 /* y_hi / y_lo [rows, ldy] bf16 <- x fp32 [rows, ldx] (cols, ldx, ldy multiples of 4) */
 int spacer_split_f32_pair(const float* x, long ldx, void* y_hi, void* y_lo, long ldy, int rows, int cols, spacer_stream_t stream);
 /* y = act(x) in fp32 (enum spacer_act), as a pair; pre_bf16 [rows, ldy] (or NULL) receives bf16(x), the point spacer_act_bwd

@@ -41,6 +41,7 @@ _p, _i, _l, _f, _u64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint64
 SIGNATURES = {
     "spacer_gemm_bf16_nt": [_p, _l, _p, _l, _p, _l, _i, _i, _i, C.POINTER(GemmEpilogue), _p],
     "spacer_gemm_bf16": [_p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _i, C.POINTER(GemmEpilogue), _p],
+    "spacer_gemm_bf16_pair_nt": [_p, _p, _l, _p, _l, _p, _l, _i, _i, _i, C.POINTER(GemmEpilogue), _p],
     "spacer_gemm_skinny_bf16": [_p, _l, _p, _l, _p, _l, _i, _i, _i, C.POINTER(GemmEpilogue), _p],
     "spacer_pack_weight_frag": [_p, _l, _p, _i, _i, _p],
     "spacer_gemm_skinny_packed_bf16": [_p, _l, _p, _p, _l, _i, _i, _i, C.POINTER(Plan), _p],
@@ -102,7 +103,7 @@ SIGNATURES = {
     "spacer_embed_fwd_f32video": [_p, _p, _p, _p, _p, _i, _i, _p],
     "spacer_attn_fwd_pair": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _l, _l, _l, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p],
 }
-OTHER_SYMBOLS = ["spacer_last_error", "spacer_version", "spacer_sample_workspace_bytes", "spacer_attn_decode_workspace_bytes", "spacer_gemm_tile", "spacer_gemm_workspace_bytes", "spacer_gemm_swiglu_fused", "spacer_resize_workspace_bytes", "spacer_gemm_skinny_swiglu_workspace_bytes"]
+OTHER_SYMBOLS = ["spacer_last_error", "spacer_version", "spacer_sample_workspace_bytes", "spacer_attn_decode_workspace_bytes", "spacer_gemm_tile", "spacer_gemm_workspace_bytes", "spacer_gemm_swiglu_fused", "spacer_gemm_pair_fused", "spacer_resize_workspace_bytes", "spacer_gemm_skinny_swiglu_workspace_bytes"]
 
 _lib = None
 
@@ -132,6 +133,8 @@ def load() -> C.CDLL:
     lib.spacer_gemm_tile.restype = _i
     lib.spacer_gemm_swiglu_fused.argtypes = [_i, _i, _i, C.POINTER(Plan)]
     lib.spacer_gemm_swiglu_fused.restype = _i
+    lib.spacer_gemm_pair_fused.argtypes = [_i, _i, _i, _i, C.POINTER(Plan)]
+    lib.spacer_gemm_pair_fused.restype = _i
     lib.spacer_gemm_workspace_bytes.argtypes = []
     lib.spacer_gemm_workspace_bytes.restype = C.c_long
     lib.spacer_gemm_skinny_swiglu_workspace_bytes.argtypes = []

@@ -51,6 +51,10 @@ struct GemmArgs {
     // workgroups; stage_bf16 = bf16 output without a residual (and the SwiGLU form): the epilogue stages bf16 through half of the
     // LDS and the next item's first K tile is requested under it (gemm_halftile.h)
     int total_blocks, stage_bf16;
+    // K-concatenated pair form (precise mode, NT operands only): C = [A | A2] . [B | B]^T in ONE launch -- global K tiles
+    // kt < kt_wrap come from A, the others from A2 at tile kt - kt_wrap, and B's K tile index wraps at kt_wrap; K = 2 x the
+    // contraction length of one pass.  kt_wrap = INT_MAX (never reached) for every other launch.
+    const bf16_t* A2; int kt_wrap;
 };
 
 // workgroups of a persistent 256-tile launch: one per CU
@@ -339,8 +343,9 @@ extern "C" int spacer_gemm_tile(int M, int N, int K, int have_workspace, const s
 }
 
 static int launch_gemm(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K, bool ta, bool tb,
-                       const spacer_gemm_epilogue* epi, spacer_stream_t stream) {
+                       const spacer_gemm_epilogue* epi, spacer_stream_t stream, const void* A2 = nullptr) {
     SP_REQUIRE(A && B && C, SPACER_EINVAL, "gemm: null operand");
+    SP_REQUIRE(!A2 || (!ta && !tb && K % BK == 0 && ((uintptr_t)A2 % 16) == 0), SPACER_EINVAL, "gemm_pair: NT operands, K %% %d == 0, aligned A_lo", BK);
     SP_REQUIRE(M > 0 && N > 0 && K > 0, SPACER_EINVAL, "gemm: empty shape M=%d N=%d K=%d", M, N, K);
     SP_REQUIRE(!ta || tb, SPACER_EINVAL, "gemm: trans_a without trans_b is not instantiated (no caller on the hot path)");
     SP_REQUIRE(ta || K % BK == 0, SPACER_EINVAL, "gemm: K=%d must be a multiple of %d (pad the contraction dim)", K, BK);
@@ -351,6 +356,8 @@ static int launch_gemm(const void* A, long lda, const void* B, long ldb, void* C
     GemmArgs g;
     g.swiglu_inter = 0; g.C2 = nullptr; g.ldc2 = 0;
     g.k_tail_tile = -1; g.A_tail = nullptr; g.B_tail = nullptr;
+    g.A2 = (const bf16_t*)A2; g.kt_wrap = A2 ? K / BK : 0x7fffffff;
+    if (A2) K *= 2;                                   // one launch walks the K tiles of both passes
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.bias = epi ? (const bf16_t*)epi->bias : nullptr;
@@ -367,6 +374,7 @@ static int launch_gemm(const void* A, long lda, const void* B, long ldb, void* C
     // the contraction-major operand forms exist on the 256 tile only
     const spacer_plan* plan = epi ? epi->plan : nullptr;
     const bool big = tb || choose_tile(M, N, K, have_ws, plan) == 256;
+    SP_REQUIRE(!A2 || big, SPACER_EINVAL, "gemm_pair: M=%d N=%d K=%d does not run on the 256 tile; use two accumulate passes", M, N, K / 2);
     hipStream_t s = (hipStream_t)stream;
     if (ta && K % BK != 0) {
         // ragged contraction length: the last K % 64 rows of both operands go to zero-padded 64-row tail buffers
@@ -422,6 +430,19 @@ extern "C" int spacer_gemm_bf16_nt(const void* A, long lda, const void* B, long 
     return launch_gemm(A, lda, B, ldb, C, ldc, M, N, K, false, false, epi, stream);
 }
 
+// Precise mode (csrc/precise.hip): C = (A_hi + A_lo) . B^T + ... as ONE launch over the K-concatenated operands [A_hi | A_lo] and
+// [B | B] (the weights are exactly bf16, so only the activation is a pair) instead of two accumulate passes: the fp32 output is
+// written once (no read-modify-write pass) and the launch's fixed costs are paid once.
+extern "C" int spacer_gemm_pair_fused(int M, int N, int K, int have_workspace, const spacer_plan* plan) {
+    return K % BK == 0 && choose_tile(M, N, 2 * K, have_workspace != 0, plan) == 256;
+}
+
+extern "C" int spacer_gemm_bf16_pair_nt(const void* A_hi, const void* A_lo, long lda, const void* B, long ldb, void* C, long ldc, int M,
+                                        int N, int K, const spacer_gemm_epilogue* epi, spacer_stream_t stream) {
+    SP_REQUIRE(A_lo, SPACER_EINVAL, "gemm_pair: null A_lo");
+    return launch_gemm(A_hi, lda, B, ldb, C, ldc, M, N, K, false, false, epi, stream, A_lo);
+}
+
 extern "C" int spacer_gemm_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
                                 int trans_a, int trans_b, const spacer_gemm_epilogue* epi, spacer_stream_t stream) {
     return launch_gemm(A, lda, B, ldb, C, ldc, M, N, K, trans_a != 0, trans_b != 0, epi, stream);
@@ -451,6 +472,7 @@ extern "C" int spacer_gemm_swiglu_bf16(const void* A, long lda, const void* W, l
     g.bias = (const bf16_t*)bias; g.resid = nullptr; g.ldr = 0; g.out_f32 = 0; g.act = SPACER_ACT_NONE; g.alpha = 1.f;
     g.swiglu_inter = inter; g.C2 = gu; g.ldc2 = ld_gu;
     g.k_tail_tile = -1; g.A_tail = nullptr; g.B_tail = nullptr;
+    g.A2 = nullptr; g.kt_wrap = 0x7fffffff;
     g.tiles_m = cdiv(M, 256); g.tiles_n = inter / 128;
     g.full_tiles = g.tiles_m * g.tiles_n; g.splits = 1; g.slabs = nullptr;      // no K-split tail: the reduce kernel has no SwiGLU form
     g.total_blocks = g.full_tiles; g.stage_bf16 = 1;

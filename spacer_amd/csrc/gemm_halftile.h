@@ -145,8 +145,10 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
         const int kt = kt0 + (t < nt ? t : nt - 1);     // global K tile (wave-uniform)
         char* dst = smem + (par * 4 + which) * HALF + wave * 2048;
         const bf16_t* base;                             // scalar base of this K tile
-        if (which < 2) base = TA ? (kt == g.k_tail_tile ? g.A_tail : g.A + (long)kt * BK * g.lda) : g.A + kt * BK;
-        else base = TB ? (kt == g.k_tail_tile ? g.B_tail : g.B + (long)kt * BK * g.ldb) : g.B + kt * BK;
+        // (pair form: K tiles kt >= kt_wrap come from A2 / wrap around in B -- scalar selects; kt_wrap is never reached otherwise)
+        if (which < 2) base = TA ? (kt == g.k_tail_tile ? g.A_tail : g.A + (long)kt * BK * g.lda)
+                                 : (kt < g.kt_wrap ? g.A + kt * BK : g.A2 + (kt - g.kt_wrap) * BK);
+        else base = TB ? (kt == g.k_tail_tile ? g.B_tail : g.B + (long)kt * BK * g.ldb) : g.B + (kt < g.kt_wrap ? kt : kt - g.kt_wrap) * BK;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const bf16_t* src = base + ((which < 2) ? offA[which & 1][i] : offB[which & 1][i]);

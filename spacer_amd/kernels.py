@@ -575,9 +575,32 @@ def _pair_out(rows, cols, device):
     return (torch.empty(rows, cols, device=device, dtype=BF16), torch.empty(rows, cols, device=device, dtype=BF16))
 
 
+PAIR_TWOPASS = bool(os.environ.get("SPACER_GEMM_PAIR_TWOPASS"))        # A/B runs: two accumulate passes instead of the K-concatenated launch
+
+
 def gemm_pair(a_hi, a_lo, w, *, bias=None, residual=None, out=None):
-    """fp32 out = (a_hi + a_lo) @ w^T + bias + residual: two accumulate passes of the production GEMM (weights are exactly
-    bf16, so only the activation operand is a pair).  ``out`` may alias ``residual`` (in-place update of the stream)."""
+    """fp32 out = (a_hi + a_lo) @ w^T + bias + residual (weights are exactly bf16, so only the activation operand is a pair).
+    ONE launch over the K-concatenated operands [a_hi | a_lo] . [w | w]^T where the 256-tile kernel takes the shape
+    (spacer_gemm_bf16_pair_nt: the fp32 output is written once), else two accumulate passes of the production GEMM.  ``out`` may
+    alias ``residual`` (in-place update of the stream)."""
+    M, Kd = a_hi.shape
+    N = w.shape[0]
+    lib = _lib.load()
+    if (not PAIR_TWOPASS and a_hi.stride(0) == a_lo.stride(0) and tuple(a_lo.shape) == (M, Kd)
+            and lib.spacer_gemm_pair_fused(M, N, Kd, 1, _plan())):
+        if out is None:
+            out = torch.empty(M, N, device=a_hi.device, dtype=torch.float32)
+        assert out.dtype == torch.float32 and (residual is None or residual.dtype == torch.float32)
+        epi = GemmEpilogue(_ptr(bias), _ptr(residual), _rowmajor(residual) if residual is not None else 0, 1, SPACER_ACT_NONE, 1.0)
+        ws = _gemm_workspace(a_hi.device)
+        epi.workspace, epi.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        epi.plan = C.pointer(PLAN)
+        t0 = PROFILER.begin()
+        check(lib.spacer_gemm_bf16_pair_nt(_ptr(a_hi), _ptr(a_lo), _rowmajor(a_hi), _ptr(w), _rowmajor(w), _ptr(out), _rowmajor(out),
+                                           M, N, Kd, C.byref(epi), _stream()), "gemm_bf16_pair_nt")
+        if t0 is not None:
+            PROFILER.end("gemm_bf16_nt_256h_kernel<true, false, false, false>", t0, 4.0 * M * N * Kd, 2.0 * (2 * M * Kd + N * Kd) + 4.0 * M * N)
+        return out
     out = gemm_nt(a_hi, w, bias=bias, residual=residual, out=out, out_dtype=torch.float32)
     return gemm_nt(a_lo, w, residual=out, out=out, out_dtype=torch.float32)
 

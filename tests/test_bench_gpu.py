@@ -32,9 +32,14 @@ def test_bench_json_contract_tiny(dev):
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "samples/s" and cb["sample"]
     v = d["variants"]
-    assert set(v) == {"temporal", "free_running", "through_trainer", "precise_scoring", "decode_cfg4_rows"}, set(v)
-    assert all("samples_per_s" in v[k] for k in ("temporal", "free_running", "through_trainer")), v
+    assert set(v) == {"temporal", "free_running", "through_trainer", "precise_scoring", "decode_cfg4_rows", "precise_step"}, set(v)
+    assert all("samples_per_s" in v[k] for k in ("temporal", "free_running", "through_trainer", "precise_step")), v
     assert v["through_trainer"]["gradient_accumulation_steps"] == 2 and v["through_trainer"]["vs_headline"] > 0
+    assert v["through_trainer"]["steps"] == 4 and v["precise_step"]["vs_headline_step_time"] > 0
+    assert d["config"]["precise_logps"] is False and d["config"]["groups_per_gpu"] == 2 and "launch_shape" in d["config"]
+    rh = d["roofline_hbm"]
+    assert rh["bound"] == "hbm" and rh["unit"] == "GB/s" and rh["achieved"] > 0 and rh["avg_launch_us"] > 0 and "skinny" in rh["kernel"]
+    assert "value_kind" in cb
     assert v["precise_scoring"]["ratio"] > 0 and v["decode_cfg4_rows"]["ms_per_token_step"] > 0
 
 
@@ -62,6 +67,7 @@ def test_bench_two_ranks_control_flow_on_one_gpu(dev, algo):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["rccl_world"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["grad_algo"] == algo
     assert d["config"]["global_batch"] == 2 * 2 * 4 and d["value"] > 0 and "cpu_baseline" not in d and "variants" not in d
+    assert d["comm"]["rccl_world"] == 2 and d["comm"]["bytes_on_wire_per_gpu_per_step"] > 0 and algo.split("_")[0] in d["comm"]["algo"]
 
 
 @pytest.mark.parametrize("algo", ["allreduce", "rs_ag"])
@@ -77,3 +83,5 @@ def test_bench_rccl_branch_with_a_world_of_one(dev, algo):
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["config"]["backend"] == "nccl" and d["config"]["grad_algo"] == algo and d["value"] > 0
+    # the exchange's exposed time is measured with HIP events on the compute stream (world of one: nothing on the wire)
+    assert d["comm"]["rccl_world"] == 1 and d["comm"]["exposed_events"] > 0 and d["comm"]["exposed_ms"] >= 0 and d["comm"]["bytes_on_wire_per_gpu_per_step"] == 0

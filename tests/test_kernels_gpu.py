@@ -104,7 +104,7 @@ def test_gemm_trans_b_is_dx(dev, M, N, Kd):
     got = K.gemm(dy, w, trans_b=True)
     ref = K.gemm_nt(dy, w.t().contiguous())
     from spacer_amd import _lib
-    if _lib.load().spacer_gemm_tile(M, N, Kd, 1) == 256:           # same tile, same split plan -> the same bits
+    if _lib.load().spacer_gemm_tile(M, N, Kd, 1, None) == 256:           # same tile, same split plan -> the same bits
         assert torch.equal(got, ref), f"trans_b differs from NT-on-transposed: max {float((got.float() - ref.float()).abs().max())}"
     else:                                                          # the NT call ran on the 128 tile: fp32 summation order may differ
         assert_close(got, ref, atol=2e-2, rtol=1e-2, what="dX vs NT (128 tile)")
@@ -130,7 +130,7 @@ def test_gemm_trans_ab_is_dw(dev, T, Nout, Kin):
     dyt, xt = K.transpose_pad(dy), K.transpose_pad(x)
     K.gemm_nt(dyt, xt, out=old, residual=old)
     from spacer_amd import _lib
-    if _lib.load().spacer_gemm_tile(Nout, Kin, dyt.shape[1], 1) == 256 and dyt.shape[1] // 64 == (T + 63) // 64:
+    if _lib.load().spacer_gemm_tile(Nout, Kin, dyt.shape[1], 1, None) == 256 and dyt.shape[1] // 64 == (T + 63) // 64:
         assert torch.equal(acc, old), f"in-place dW differs from the transpose route: max {float((acc - old).abs().max())}"
     else:
         assert_close(acc, old, atol=1e-3, rtol=1e-4, what="dW vs transpose route (128 tile)")
@@ -447,7 +447,7 @@ def test_gemm_swiglu_epilogue_is_the_two_step_path(dev):
         a = rnd((M, Kd), dev, 1, 0.5)
         w = rnd((2 * I, Kd), dev, 2, 0.05)
         b = rnd((2 * I,), dev, 3, 0.2) if with_bias else None
-        assert K._lib.load().spacer_gemm_swiglu_fused(M, I, Kd) == 1
+        assert K._lib.load().spacer_gemm_swiglu_fused(M, I, Kd, None) == 1
         gu_ref = K.gemm_nt(a, w, bias=b, split_k=False)
         act_ref = K.swiglu_fwd(gu_ref)
         act, gu = K.gemm_swiglu(a, w, bias=b, keep_gu=True)
@@ -457,7 +457,7 @@ def test_gemm_swiglu_epilogue_is_the_two_step_path(dev):
         assert none is None and torch.equal(act2, act_ref)
     # a shape the 256 tile does not take falls back to the two launches
     a, w = rnd((40, 128), dev, 4, 0.5), rnd((2 * 192, 128), dev, 5, 0.05)
-    assert K._lib.load().spacer_gemm_swiglu_fused(40, 192, 128) == 0
+    assert K._lib.load().spacer_gemm_swiglu_fused(40, 192, 128, None) == 0
     act, gu = K.gemm_swiglu(a, w)
     assert torch.equal(act, K.swiglu_fwd(K.gemm_nt(a, w)))
 

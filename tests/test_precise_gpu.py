@@ -102,6 +102,32 @@ def test_gemm_pair_matches_fp64(dev):
     assert rel_err(single.double(), want) > 20 * rel_err(x.double(), want)      # the pair is what buys the precision
 
 
+@pytest.mark.parametrize("M,N,Kd", [(4096, 4096, 1024), (4100, 4096, 1024), (5498, 4608, 3584)])
+def test_gemm_pair_one_launch_over_k_concatenated_operands(dev, M, N, Kd, monkeypatch):
+    """Round 4: where the 256-tile kernel takes the shape, the pair GEMM is ONE launch over [A_hi | A_lo] . [W | W]^T
+    (spacer_gemm_bf16_pair_nt: K tiles past the wrap point come from A_lo and re-walk W) -- same numbers as the two accumulate
+    passes up to fp32 summation order, the pair precision against fp64, with bias + in-place residual and through the K-split tail
+    (4100 x 4096 leaves a 16-tile tail round)."""
+    assert K._lib.load().spacer_gemm_pair_fused(M, N, Kd, 1, None) == 1
+    g = torch.Generator(device="cpu").manual_seed(11)
+    a = (torch.randn(M, Kd, generator=g) * 0.7).to(dev)
+    w = (torch.randn(N, Kd, generator=g) * 0.05).to(dev).to(BF)
+    bias = torch.randn(N, generator=g).to(dev).to(BF)
+    res = torch.randn(M, N, generator=g).to(dev)
+    hi, lo = K.split_pair(a)
+    x = res.clone()
+    K.gemm_pair(hi, lo, w, bias=bias, residual=x, out=x)
+    monkeypatch.setattr(K, "PAIR_TWOPASS", True)
+    two = K.gemm_pair(hi, lo, w, bias=bias, residual=res)
+    monkeypatch.setattr(K, "PAIR_TWOPASS", False)
+    assert float((x - two).abs().max()) <= 2e-5 * float(two.abs().max())
+    rows = torch.randint(0, M, (64,), generator=g).to(dev)                                   # fp64 check on a row sample
+    want = (hi[rows].double() + lo[rows].double()) @ w.double().t() + bias.double() + res[rows].double()
+    assert rel_err(x[rows].double(), want) <= PAIR_EPS
+    fresh = K.gemm_pair(hi, lo, w)                                                           # no bias / residual, new output
+    assert rel_err(fresh[rows].double(), (hi[rows].double() + lo[rows].double()) @ w.double().t()) <= PAIR_EPS
+
+
 @pytest.mark.parametrize("case", ATTN_CASES, ids=[c[0] for c in ATTN_CASES])
 def test_attention_pair_matches_fp64(dev, case):
     name, D, Hq, Hkv, causal, segs = case
