@@ -176,9 +176,11 @@ class RolloutEngine:
     # ------------------------------------------------------------------ public
     @torch.no_grad()
     def generate(self, prompts: List[PromptInput], num_generations: int, sp: SamplingParams, *, use_graph: bool = True,
-                 stats: Optional[dict] = None) -> torch.Tensor:
+                 stats: Optional[dict] = None, on_decode_start=None) -> torch.Tensor:
         """Returns completion ids int64 [len(prompts) * num_generations, C] (EOS kept, pad_token_id after it),
-        rows ordered prompt-major like HF's num_return_sequences expansion."""
+        rows ordered prompt-major like HF's num_return_sequences expansion.  ``on_decode_start()`` is called once, right after
+        the decode step has been captured (graph capture synchronises the device, so work meant to run BESIDE the decode loop on
+        another stream must be enqueued after it): the hook for prompt-only work of the step that can overlap the HBM-bound loop."""
         cfg = self.cfg
         nP, Kn, C = len(prompts), num_generations, sp.max_new_tokens
         B = nP * Kn
@@ -186,7 +188,8 @@ class RolloutEngine:
             outs = []
             per = max(1, self.MAX_ROWS // Kn)
             for a in range(0, nP, per):
-                outs.append(self.generate(prompts[a:a + per], Kn, sp, use_graph=use_graph, stats=stats))
+                outs.append(self.generate(prompts[a:a + per], Kn, sp, use_graph=use_graph, stats=stats,
+                                          on_decode_start=on_decode_start if a == 0 else None))
             return torch.cat(outs, 0)
         dev = self.dev
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if stats is not None else None
@@ -229,10 +232,16 @@ class RolloutEngine:
                 with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     self._decode_step(st, sp)
                 graph.replay()                                # capture records only; this runs step 2
+                if on_decode_start is not None:
+                    on_decode_start()
+                    on_decode_start = None
             elif graph is not None:
                 graph.replay()
             else:
                 self._decode_step(st, sp)
+                if on_decode_start is not None and (not use_graph or s >= 2):
+                    on_decode_start()
+                    on_decode_start = None
             n_steps += 1
             if not sp.suppress_eos and s % 32 == 0 and bool(st["finished"].all()):
                 break
