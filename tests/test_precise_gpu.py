@@ -366,10 +366,11 @@ def test_precise_grpo_step_matches_the_cpu_oracle_at_qwen2vl_2b_depth(dev):
     w_pol, w_ref = host(params), host(ref)
     for n in names:
         w_pol[n].requires_grad_(True)
+    from oracle import cpu_path as CP                      # the whole-step CPU restatement: its scoring function (shared-prompt packed pass)
     with torch.no_grad():
-        ref_o = O.completion_logps(w_ref, ocfg, prompt.ids.cpu(), comps, rows, [tuple(grid)])
+        ref_o = CP.group_logps(w_ref, ocfg, prompt.ids.cpu(), comps, rows, [tuple(grid)])
     del w_ref
-    lp_o = O.completion_logps(w_pol, ocfg, prompt.ids.cpu(), comps, rows, [tuple(grid)])
+    lp_o = CP.group_logps(w_pol, ocfg, prompt.ids.cpu(), comps, rows, [tuple(grid)])
     mask = GR.completion_mask(comps, cfg.eos_token_id)
     loss_o = GR.grpo_loss(lp_o, ref_o, adv, mask, 0.04)
     kl_o = float(GR.kl_metric(lp_o.detach(), ref_o, mask))
