@@ -254,3 +254,35 @@ def test_mixed_text_and_vision_rows_fall_back_to_separate_passes(dev, tmp_path):
     assert any("separate passes" in line for line in trainer._log_lines)
     lg = json.loads(open(os.path.join(str(tmp_path), "trainer_log.jsonl")).readline())
     assert lg["loss"] == lg["loss"] and lg["grad_norm"] > 0
+
+
+def test_precise_logps_flag_trains_through_the_trainer(dev, tmp_path, monkeypatch):
+    """--precise_logps true (GRPOConfig.precise_logps -> GRPOHyper.precise_logps): the trainer's step takes its log-probs, KL and loss
+    from the precise mode and still moves the weights; the logged loss / KL of step 1 differ from the fast trainer's by less than the
+    fast path's own log-prob floor, and the injected-engine check refuses a mismatching engine."""
+    monkeypatch.setattr(K.PLAN, "skinny_blocks", 1)          # decode GEMMs without split-K atomics: the two runs sample the same rollouts
+    g = load_tiny()
+    rows = _video_rows(2, seed0=40)
+    logs = {}
+    for mode in (False, True):
+        params = FlatParams.empty(TINY, dev)
+        load_state_dict(params, g["w"])
+        before = params.flat.clone()
+        out = tmp_path / ("precise" if mode else "fast")
+        args = GRPOConfig(output_dir=str(out), max_completion_length=6, num_generations=4, learning_rate=1e-4, max_steps=2,
+                          gradient_accumulation_steps=2, logging_steps=1, save_steps=0, seed=21, precise_logps=mode)
+        trainer = SGRLVRTrainer(model=params, reward_funcs=[accuracy_reward, format_reward], args=args,
+                                script_args=GRPOScriptArguments(temporal=False, len_control=True), train_dataset=rows,
+                                processing_class=FakeProcessor(TINY), device=dev)
+        assert trainer.engine.h.precise_logps is mode
+        assert trainer.train()["global_step"] == 2
+        assert not torch.equal(before, trainer.engine.policy.flat)
+        logs[mode] = [json.loads(line) for line in open(os.path.join(str(out), "trainer_log.jsonl"))]
+        if mode:
+            assert any("precise_logps" in line for line in trainer._log_lines)
+            with pytest.raises(ValueError):
+                SGRLVRTrainer(model=params, reward_funcs=[format_reward], args=GRPOConfig(output_dir=str(out), num_generations=4),
+                              train_dataset=rows, processing_class=FakeProcessor(TINY), device=dev, engine=trainer.engine)
+    a, b = logs[False][0], logs[True][0]
+    assert a["completion_length"] == b["completion_length"] and a["reward"] == b["reward"]          # same rollouts (same seeds, step 1)
+    assert abs(a["loss"] - b["loss"]) < 5e-3 and abs(a["kl"] - b["kl"]) < 5e-3 and b["grad_norm"] > 0
