@@ -190,7 +190,7 @@ def pmc_traffic(workload: str, kernel: str, live: bool):
     """HBM-side (L2-miss, fabric) bytes per launch of the dominant kernel.  ``live``: measured in THIS session by two rocprofv3
     --pmc passes (FETCH_SIZE, WRITE_SIZE: MI355X_MICROARCH.md HBM section) over the step's GEMM shapes (scripts/pmc_gemm_table.py;
     PMC collection around the whole 7B step crashes rocprofv3, so the shapes are replayed stand-alone).  Otherwise, or when
-    rocprofv3 is unavailable / fails, the committed table of the same procedure (profiles/r02_gemm_pmc.json).  Returns
+    rocprofv3 is unavailable / fails, the committed table of the same procedure (profiles/r04_gemm_pmc.json).  Returns
     (bytes or None, source)."""
     if workload not in ("cfg3", "cfg4"):
         return None, "not collected for this workload"
@@ -209,12 +209,13 @@ def pmc_traffic(workload: str, kernel: str, live: bool):
             err = f"{type(exc).__name__}: {exc}"[:120]
     else:
         err = "rocprofv3 not used"
-    path = os.path.join(ROOT, "profiles", "r02_gemm_pmc.json")
-    if os.path.exists(path):
-        with open(path) as f:
-            pk = json.load(f)["per_kernel"].get(kernel)
-        if pk:
-            return round(pk["hbm_bytes_per_launch"]), f"profiles/r02_gemm_pmc.json ({err})"
+    for fname in ("r04_gemm_pmc.json", "r02_gemm_pmc.json"):      # the committed table of the same procedure (r04: the two-groups-per-pass shapes)
+        path = os.path.join(ROOT, "profiles", fname)
+        if os.path.exists(path):
+            with open(path) as f:
+                pk = json.load(f)["per_kernel"].get(kernel)
+            if pk:
+                return round(pk["hbm_bytes_per_launch"]), f"profiles/{fname} ({err})"
     return None, err
 
 

@@ -10,22 +10,25 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-# (kind, M, N, K, launches per cfg3 step, fp32 output (+ residual)?)
+# (kind, M, N, K, launches per cfg3 step, fp32 output?, accumulate into the output (fp32 residual == C)?) -- the step as `bench.py`
+# runs it since round 2: two prompt groups per scoring pass (T = 10 996 rows, 4 passes per step for the reference and the policy
+# each), the lm_head in vocabulary chunks of 8192 rows, ViT over two groups' patches (8320 rows); counts from `bench.py --gemm-shapes`
 SHAPES = [
-    ("swiglu", 5498, 37888, 3584, 448, 0), ("nt", 5498, 3584, 18944, 448, 1), ("nt", 5498, 4608, 3584, 448, 0), ("nt", 5498, 3584, 3584, 448, 1),
-    ("nt", 4096, 152064, 3584, 16, 1), ("swiglu", 11216, 37888, 3584, 28, 0), ("nt", 11216, 3584, 18944, 28, 1),
-    ("nt", 11216, 4608, 3584, 28, 0), ("nt", 11216, 3584, 3584, 28, 1),
-    ("dx", 5498, 3584, 37888, 224, 0), ("dx", 5498, 18944, 3584, 224, 0), ("dx", 5498, 3584, 4608, 224, 0), ("dx", 5498, 3584, 3584, 224, 0),
-    ("dx", 4096, 3584, 152064, 8, 0), ("dx", 4160, 5120, 1280, 256, 0), ("dx", 4160, 1280, 5120, 256, 0), ("dx", 4160, 1280, 3840, 256, 0),
-    ("dw", 37888, 3584, 5498, 224, 1), ("dw", 3584, 18944, 5498, 224, 1), ("dw", 4608, 3584, 5498, 224, 1), ("dw", 3584, 3584, 5498, 224, 1),
-    ("dw", 152064, 3584, 4096, 8, 1), ("dw", 1280, 5120, 4160, 256, 1), ("dw", 5120, 1280, 4160, 256, 1), ("dw", 3840, 1280, 4160, 256, 1),
+    ("swiglu", 10996, 37888, 3584, 224, 0, 0), ("nt", 10996, 3584, 18944, 224, 1, 1), ("nt", 10996, 4608, 3584, 224, 0, 0),
+    ("nt", 10996, 3584, 3584, 224, 1, 1), ("nt", 8192, 8192, 3584, 144, 1, 0),
+    ("swiglu", 11216, 37888, 3584, 28, 0, 0), ("nt", 11216, 3584, 18944, 28, 1, 1), ("nt", 11216, 4608, 3584, 28, 0, 0), ("nt", 11216, 3584, 3584, 28, 1, 1),
+    ("nt", 8320, 5120, 1280, 256, 0, 0), ("nt", 8320, 3840, 1280, 256, 0, 0), ("nt", 8320, 1280, 5120, 256, 1, 1),
+    ("dx", 10996, 3584, 37888, 112, 0, 0), ("dx", 10996, 18944, 3584, 112, 0, 0), ("dx", 10996, 3584, 4608, 112, 0, 0), ("dx", 10996, 3584, 3584, 112, 0, 0),
+    ("dx", 8192, 3584, 8192, 72, 1, 1), ("dx", 8320, 5120, 1280, 128, 0, 0), ("dx", 8320, 1280, 5120, 128, 0, 0), ("dx", 8320, 1280, 3840, 128, 0, 0),
+    ("dw", 37888, 3584, 10996, 112, 1, 1), ("dw", 3584, 18944, 10996, 112, 1, 1), ("dw", 4608, 3584, 10996, 112, 1, 1), ("dw", 3584, 3584, 10996, 112, 1, 1),
+    ("dw", 8192, 3584, 8192, 72, 1, 1), ("dw", 1280, 5120, 8320, 128, 1, 1), ("dw", 5120, 1280, 8320, 128, 1, 1), ("dw", 3840, 1280, 8320, 128, 1, 1),
 ]
 
 
 def run(reps: int, kinds=None):
     from spacer_amd import kernels as K
     dev = torch.device("cuda:0")
-    for kind, M, N, Kd, _, f32 in SHAPES:
+    for kind, M, N, Kd, _, f32, acc in SHAPES:
         if kinds and kind not in kinds:
             continue
         nb = 2 if (M + N) * Kd * 2 > 3e8 else 4
@@ -42,11 +45,11 @@ def run(reps: int, kinds=None):
         for r in range(reps):
             x, y = a[r % nb], b[r % nb]
             if kind == "swiglu":      # gate|up themselves are written on the policy pass only (1 of 2 launches)
-                K.gemm_swiglu(x, y, keep_gu=(r % 2 == 0) and M == 5498)
+                K.gemm_swiglu(x, y, keep_gu=(r % 2 == 0) and M == 10996)
             elif kind == "nt":
-                K.gemm_nt(x, y, out=out, residual=out if f32 and N != 152064 else None)
+                K.gemm_nt(x, y, out=out, residual=out if acc else None)
             elif kind == "dx":
-                K.gemm(x, y, trans_b=True, out=out)
+                K.gemm(x, y, trans_b=True, out=out, residual=out if acc else None)
             else:
                 K.gemm(x, y, trans_a=True, trans_b=True, out=out, residual=out)
         torch.cuda.synchronize()

@@ -23,7 +23,9 @@ def inst(kind: str, f32: int) -> str:
         return "gemm_bf16_nt_256h_kernel<true, false, false, true>"
     if kind == "nt":
         return "gemm_bf16_nt_256h_kernel<true, false, false, false>"
-    return "gemm_bf16_nt_256h_kernel<true, false, true, true>" if kind == "dx" else "gemm_bf16_nt_256h_kernel<true, true, true, false>"
+    if kind == "dx":
+        return "gemm_bf16_nt_256h_kernel<true, false, true, false>" if f32 else "gemm_bf16_nt_256h_kernel<true, false, true, true>"
+    return "gemm_bf16_nt_256h_kernel<true, true, true, false>"
 
 
 def _per_dispatch(db, counter):
@@ -56,19 +58,19 @@ def _pass(counter, reps, kinds, tmp, timeout):
     raise FileNotFoundError("rocprofv3 left no .db")
 
 
-def collect(kinds=None, reps=2, timeout=240):
+def collect(kinds=None, reps=2, timeout=420):
     shapes = [s for s in SHAPES if not kinds or s[0] in kinds]
     with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
         (fetch, fx), (write, wx) = (_per_dispatch(_pass(c, reps, kinds, tmp, timeout), c) for c in ("FETCH_SIZE", "WRITE_SIZE"))
     assert len(fetch) == len(write) == reps * len(shapes), (len(fetch), len(write), len(shapes))
     table, tot = [], {}
-    for i, (kind, M, N, K, launches, f32) in enumerate(shapes):
+    for i, (kind, M, N, K, launches, f32, acc) in enumerate(shapes):
         idx = range(i * reps, (i + 1) * reps)
         f = sum(fetch[k] + fx.get(k, 0.0) for k in idx) / reps
         w = sum(write[k] + wx.get(k, 0.0) for k in idx) / reps
         hbm = (2.0 * f + w) * 1024.0
         out_b = (2.0 * M * (N // 2) if kind == "swiglu" else (4 if f32 else 2) * M * N)
-        algo = 2.0 * (M * K + N * K) + out_b + ((4.0 * M * N) if (kind == "dw" or (kind == "nt" and f32 and N != 152064)) else 0.0)
+        algo = 2.0 * (M * K + N * K) + out_b + ((4.0 * M * N) if acc else 0.0)
         table.append(dict(kind=kind, M=M, N=N, K=K, launches_per_step=launches, fetch_kib=f, write_kib=w, hbm_bytes=hbm,
                           algorithmic_bytes=algo, ratio=hbm / algo))
         t = tot.setdefault(inst(kind, f32), [0.0, 0, 0.0])
