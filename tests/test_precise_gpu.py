@@ -388,12 +388,12 @@ def test_precise_grpo_step_matches_the_cpu_oracle_at_qwen2vl_2b_depth(dev):
     for mode, tag in ((False, "fast step   "), (True, "precise step")):
         r = res[mode]
         print(f"   {tag}: max |logp - oracle| policy {float((r['lp'] - lp_o.detach()).abs().max()):.2e} reference "
-              f"{float((r['ref'] - ref_o).abs().max()):.2e}; loss {r['loss']:+.6f} (oracle {float(loss_o):+.6f}); kl {r['kl']:.6f} (oracle {kl_o:.6f})")
+              f"{float((r['ref'] - ref_o).abs().max()):.2e}; loss {r['loss']:+.6f} (oracle {float(loss_o.detach()):+.6f}); kl {r['kl']:.6f} (oracle {kl_o:.6f})")
     print(f"   oracle (2 forwards + autograd backward on the host): {t_oracle:.0f} s")
     r = res[True]
     assert kl_o > 1e-3                                                       # the case is not the trivial ref == policy one
     assert float((r["lp"] - lp_o.detach()).abs().max()) <= 1e-3 and float((r["ref"] - ref_o).abs().max()) <= 1e-3
-    assert abs(r["loss"] - float(loss_o)) <= 1e-3 and abs(r["kl"] - kl_o) <= 1e-3
+    assert abs(r["loss"] - float(loss_o.detach())) <= 1e-3 and abs(r["kl"] - kl_o) <= 1e-3
     got = r["G"]
     got["visual.patch_embed.proj.weight"] = got["visual.patch_embed.proj.weight"].reshape(cfg.vit_dim, -1)
     for n in names:
