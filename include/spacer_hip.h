@@ -89,8 +89,9 @@ long spacer_gemm_workspace_bytes(void);
 /* SwiGLU MLP input half in one launch (HF Qwen2MLP.forward: act_fn(gate_proj(x)) * up_proj(x), modeling_qwen2_vl.py Qwen2MLP;
  * Qwen2.5-VL vision MLP with biases): W bf16 [2*inter, K] = [gate_proj rows | up_proj rows], bias bf16 [2*inter] or NULL.
  *   act bf16 [M, inter] = silu(A.Wgate^T + bgate) * (A.Wup^T + bup);   gu bf16 [M, 2*inter] (or NULL) = the rounded gate|up.
- * Same bits as spacer_gemm_bf16_nt into gu + spacer_swiglu_fwd.  Only shapes the 256-tile kernel takes:
- * spacer_gemm_swiglu_fused(M, inter, K) != 0 (inter % 128 == 0, K % 64 == 0, large enough M); otherwise SPACER_EINVAL. */
+ * Same bits as spacer_gemm_bf16_nt into gu + spacer_swiglu_fwd.  Always the 256-tile kernel: needs inter % 128 == 0 and K % 64 == 0
+ * (SPACER_EINVAL otherwise); spacer_gemm_swiglu_fused(M, inter, K, plan) != 0 says whether the cost model WOULD put the problem on
+ * that tile (large enough M) -- callers take the two-step path (GEMM + spacer_swiglu_fwd) when it returns 0. */
 int spacer_gemm_swiglu_fused(int M, int inter, int K, const spacer_plan* plan);
 int spacer_gemm_swiglu_bf16(const void* A, long lda, const void* W, long ldb, const void* bias, void* act, long ld_act, void* gu,
                             long ld_gu, int M, int inter, int K, spacer_stream_t stream);

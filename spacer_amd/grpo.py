@@ -271,6 +271,11 @@ class ShardedExchange:
     def shard(self, flat: torch.Tensor) -> torch.Tensor:
         return flat[self.lo:self.hi]
 
+    def drop_buffers(self, dtype) -> None:
+        """Release the wire buffers of one dtype (the fp32 ones exist only around a full-state checkpoint)."""
+        for key in [k for k in self._bufs if k[1] == dtype]:
+            del self._bufs[key]
+
     def _buf(self, kind: str, shape, dtype, dev) -> torch.Tensor:
         key = (kind, dtype, str(dev))
         b = self._bufs.get(key)
@@ -504,6 +509,7 @@ class GRPOEngine:
         if self.sharded is not None:
             for t in (self.master.flat, self.m, self.v):
                 self.sharded.all_gather_(t)
+            self.sharded.drop_buffers(torch.float32)
 
     def grad_norm(self, world_size: int = 1) -> float:
         return float(self._sumsq.sqrt()) / world_size
