@@ -653,7 +653,7 @@ def main():
             out["phase_seconds_per_step"] = {k: round(v / args.steps, 3) for k, v in phase.items()}
         if world == 1:
             out["roofline"]["traffic"], out["roofline"]["traffic_source"] = pmc_traffic(args.workload, dom_name, not args.no_pmc)
-        if roll_stats.get("decode_steps") and groups * Kgen <= 64:
+        if world == 1 and roll_stats.get("decode_steps") and groups * Kgen <= 64:      # N = 1 only: ranks of a job stay in step after the timed region
             try:
                 out["roofline_hbm"] = skinny_roofline(ge, cfg, dev, groups * Kgen, elapsed / args.steps,
                                                       cfg.layers * roll_stats["decode_steps"] // max(1, args.steps))
