@@ -329,24 +329,29 @@ def test_taped_precise_forward_feeds_the_production_backward(dev, which, recompu
     assert float((lp2.cpu() - O.completion_logps(wb, g["cfg"], g["prompt"][-9:], comps, None, None)).abs().max()) <= 1e-4
 
 
-def test_precise_grpo_step_matches_the_cpu_oracle_at_qwen2vl_2b_depth(dev):
+@pytest.mark.parametrize("depth", ["2b", "7b"])
+def test_precise_grpo_step_matches_the_cpu_oracle_at_full_depth(dev, depth):
     """ONE FULL GRPO step (reference + policy scoring, k3 KL, loss, backward) with ``GRPOHyper.precise_logps`` at
-    Qwen2-VL-2B depth (28 + 32 layers, tied lm_head), the frozen reference model DIFFERENT from the policy (as after optimizer steps;
-    KL > 0), against the CPU restatement of TR:353-366 (log-probs), TR:493-498 (mask), TR:551-552 (KL) and TR:640-643 (loss) on the
-    same weights: policy / reference log-probs, loss and KL within the north-star's 1e-3, and the gradient that the production
-    backward takes from the precise tape within the depth test's 6 % of oracle autograd.  The fast step's numbers are printed."""
+    Qwen2-VL-2B depth (28 + 32 layers, tied lm_head) and on the headline model itself, Qwen2-VL-7B (8.29 B parameters, untied lm_head;
+    the whole GRPOEngine with fp32 master / Adam state / gradients: 165 GB), the frozen reference model DIFFERENT from the policy (as
+    after optimizer steps; KL > 0), against the CPU restatement of TR:353-366 (log-probs), TR:493-498 (mask), TR:551-552 (KL) and
+    TR:640-643 (loss) on the same weights: policy / reference log-probs, loss and KL within the north-star's 1e-3, and the gradient
+    that the production backward takes from the precise tape within the depth test's 6 % of oracle autograd.  The fast step's
+    numbers are printed."""
     import time
     from oracle import grpo_ref as GR
     from spacer_amd.grpo import GRPOEngine, GRPOHyper
+    from spacer_amd.qwen2vl.config import QWEN2_VL_7B
     from spacer_amd.rollout import PromptInput
-    cfg = QWEN2_VL_2B
+    cfg = QWEN2_VL_2B if depth == "2b" else QWEN2_VL_7B
     torch.cuda.empty_cache()
     params = FlatParams.empty(cfg, dev)
     random_init_(params, seed=1234)
     ref = FlatParams(cfg, params.flat.clone(), params.specs)
-    noise = torch.randn(ref.flat.numel(), device=dev, generator=torch.Generator(device=dev).manual_seed(7))
-    ref.flat.copy_((ref.flat.float() * (1.0 + 0.03 * noise)).to(BF))
-    del noise
+    gen7 = torch.Generator(device=dev).manual_seed(7)
+    for a in range(0, ref.flat.numel(), 1 << 28):                    # in slices: no 33 GB temporaries at 7B
+        sl = ref.flat[a:a + (1 << 28)]
+        sl.copy_((sl.float() * (1.0 + 0.03 * torch.randn(sl.numel(), device=dev, generator=gen7))).to(BF))
     prompt, frames = make_prompt(cfg, 5, 4, 112, 140, 200, dev)
     comps = torch.randint(1000, 150000, (2, 24), generator=torch.Generator().manual_seed(9))
     comps[1, 15] = cfg.eos_token_id                                   # a finished rollout: the mask ends row 1 after 16 tokens
@@ -389,7 +394,7 @@ def test_precise_grpo_step_matches_the_cpu_oracle_at_qwen2vl_2b_depth(dev):
         r = res[mode]
         print(f"   {tag}: max |logp - oracle| policy {float((r['lp'] - lp_o.detach()).abs().max()):.2e} reference "
               f"{float((r['ref'] - ref_o).abs().max()):.2e}; loss {r['loss']:+.6f} (oracle {float(loss_o.detach()):+.6f}); kl {r['kl']:.6f} (oracle {kl_o:.6f})")
-    print(f"   oracle (2 forwards + autograd backward on the host): {t_oracle:.0f} s")
+    print(f"   Qwen2-VL-{depth.upper()}: oracle (2 forwards + autograd backward on the host, weight export): {t_oracle:.0f} s")
     r = res[True]
     assert kl_o > 1e-3                                                       # the case is not the trivial ref == policy one
     assert float((r["lp"] - lp_o.detach()).abs().max()) <= 1e-3 and float((r["ref"] - ref_o).abs().max()) <= 1e-3
