@@ -10,8 +10,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from spacer_amd import kernels as K   # noqa: E402
 
 dev = torch.device("cuda:0")
-for I, Kd, tag in ((18944, 3584, "real: 592 groups x 14 slices (tail balance)"), (16384, 4096, "512 groups x 16 slices (same bytes)"),
-                   (16384, 3584, "512 groups x 14 slices"), (18944, 4096, "592 groups x 16 slices")):
+CASES = [(18944, 3584, "real: 592 groups x 14 slices (tail balance)")] + [(16384, k, f"512 groups x {k // 256} slices") for k in
+                                                                             (3072, 3328, 3584, 3840, 4096, 4352, 4608, 5120)]
+for I, Kd, tag in CASES:
     a = torch.randn(64, Kd, device=dev).bfloat16()
     ws = [K.pack_weight_frag_swiglu((torch.randn(2 * I, Kd, device=dev) * 0.02).bfloat16()) for _ in range(4)]     # > 256 MiB in rotation
     out = torch.empty(64, I, device=dev, dtype=torch.bfloat16)
@@ -26,5 +27,5 @@ for I, Kd, tag in ((18944, 3584, "real: 592 groups x 14 slices (tail balance)"),
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 40 * 1e3
     mb = 2 * I * Kd * 2 / 1e6
-    print(f"  {tag:48s} {mb:6.1f} MB  {us:6.1f} us  {mb / us / 1e3 * 1e3 / 1e3:5.2f} TB/s", flush=True)
+    print(f"  {tag:48s} {mb:6.1f} MB  {us:6.1f} us  {mb / us / 1e6 * 1e6 / 1e6:6.3f} TB/s  (fragment-column stride {Kd * 32 // 1024} KB)", flush=True)
     del ws
