@@ -33,6 +33,13 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 // whole-K blocks instead of after them); their partial sums meet in an fp32 scratch tile through agent-scope atomics, an
 // agent-scope ticket per column group counts arrivals, and the last arriver takes the totals back with atomic exchanges (read +
 // re-zero in one read-modify-write: both sides atomics on the same words, so no fence is needed) and applies the SwiGLU epilogue.
+// SWIGLU one-round form (wide_groups > 0, MT = 1; round 4): when the N / 16 column fragments number between 4 and 5 per resident
+// workgroup slot (7B gate|up: 2368 fragments on 512 slots), the launch is EXACTLY one resident round of 512 workgroups: the first
+// `wide_groups` (= fragments - 4 * slots) own FIVE fragments, the others four.  Wave w of a wide workgroup streams its own fragment
+// over all of K as before plus k-steps 2w, 2w + 1 of every slice of the fifth fragment (one quarter of its weights); the four partial
+// sums of the fifth fragment meet in LDS after the K loop and wave w finishes rows 16w .. 16w + 15 of it.  No atomics, no ticket,
+// no second round: time = 9.4 us + bytes / 6.75 TB/s like any one-round launch of this kernel (scripts/probes/swiglu_equal_work.py)
+// instead of the 1.16 rounds of the 64-column decomposition (58.7 us with the tail balance, 49.6 us by that law).
 // NORMA (packed weights, MT = 1, K-split form): A is the fp32 residual stream x [M, K] itself and the RMSNorm in front of the
 // projection is folded in:  norm(x) W^T = rstd[m] * (bf16(x) (W diag(w))^T)  -- exact algebra; W diag(w) is folded into the packed
 // weights by the caller, the staging threads round x to bf16 on the way into LDS, and the workgroups of column group 0 also sum x^2 per
@@ -46,7 +53,7 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __res
                                                              int slices_per_range, int mflush, int overwrite,
                                                              int split_groups = 0, int split_ranges = 1,
                                                              float* __restrict__ scratch = nullptr, int* __restrict__ tickets = nullptr,
-                                                             float* __restrict__ rowss = nullptr) {
+                                                             float* __restrict__ rowss = nullptr, int wide_groups = 0) {
     constexpr int KS = 256 / MT, ROWB = KS * 2;            // LDS row bytes (512 / 256); 16-byte chunk index ^= row & 15
     constexpr int NU = KS / 32, MF = 4 * MT;               // MFMA k-steps per slice, 16-row A fragments
     constexpr int CH = KS / 8, CHS = (MT == 1) ? 5 : 4;    // 16-byte chunks per LDS row and log2
@@ -68,7 +75,17 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __res
             cgroup = bx - n_split_blocks;
         }
     }
-    const int n0 = cgroup * 64 + wave * 16;
+    int n0 = cgroup * 64 + wave * 16;
+    // one-round form: workgroup bx owns fragments [f0, f0 + 5) (bx < wide_groups) or [f0, f0 + 4)
+    const bool wide = SWIGLU && MT == 1 && wide_groups > 0 && (int)blockIdx.x < wide_groups;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);        // scalar copy: the fifth-fragment branch below is wave-uniform
+    int n5 = 0;
+    if (SWIGLU && MT == 1 && wide_groups > 0) {
+        const int bx = (int)blockIdx.x;
+        const int f0 = bx < wide_groups ? 5 * bx : 5 * wide_groups + 4 * (bx - wide_groups);
+        n0 = (f0 + wave) * 16;
+        n5 = (f0 + 4) * 16;
+    }
     if (s_begin >= s_end) return;
 
     // ---- staging map: instruction j of a thread covers row (tid >> CHS) + (256 / CH) j, 16-byte chunk tid & (CH - 1)
@@ -119,10 +136,17 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __res
             w[u] = __builtin_nontemporal_load((const u32x4*)p);
         }
     };
-    f32x4 acc[MF];
+    // fifth fragment of a wide workgroup: this wave's two k-steps (2 wave, 2 wave + 1) of every slice
+    const bf16_t* bbase5 = B + ((long)min(n5 >> 4, (N >> 4) - 1) * (K >> 5)) * 512 + lane * 8;
+    auto load_w5 = [&](u32x4 (&w)[2], int slice) {
 #pragma unroll
-    for (int i = 0; i < MF; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    auto compute = [&](const u32x4 (&w)[NU], const char* buf) {
+        for (int q = 0; q < 2; ++q)
+            w[q] = __builtin_nontemporal_load((const u32x4*)(bbase5 + ((long)slice * NU + 2 * wave_u + q) * 512));
+    };
+    f32x4 acc[MF], acc5[MF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i) { acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc5[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    auto compute = [&](const u32x4 (&w)[NU], const u32x4 (&w5)[2], const char* buf) {
         // A fragments double-buffered by hand and the scheduler fenced per k-step (left alone hipcc hoists all 32
         // fragment reads of the slice and spills)
         bf16x8 af[2][MF];
@@ -142,24 +166,33 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __res
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf)
                 acc[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][mf], wf, acc[mf], 0, 0, 0);   // D[m][n]
+            if (SWIGLU && MT == 1 && wide && (u >> 1) == wave_u) {     // wave-uniform: this wave's share of the fifth fragment
+                const bf16x8 wf5 = __builtin_bit_cast(bf16x8, w5[u & 1]);
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf)
+                    acc5[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][mf], wf5, acc5[mf], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
 
-    u32x4 wa[NU], wb[NU];
+    u32x4 wa[NU], wb[NU], wa5[2], wb5[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { wa5[q] = (u32x4){0u, 0u, 0u, 0u}; wb5[q] = (u32x4){0u, 0u, 0u, 0u}; }
     load_a(s_begin);
     load_w(wa, s_begin);
+    if (wide) load_w5(wa5, s_begin);
     int s = s_begin;
     while (true) {
         store_a(smem[0]);
         __syncthreads();
-        if (s + 1 < s_end) { load_a(s + 1); load_w(wb, s + 1); }
-        compute(wa, smem[0]);
+        if (s + 1 < s_end) { load_a(s + 1); load_w(wb, s + 1); if (wide) load_w5(wb5, s + 1); }
+        compute(wa, wa5, smem[0]);
         if (++s >= s_end) break;
         store_a(smem[1]);
         __syncthreads();
-        if (s + 1 < s_end) { load_a(s + 1); load_w(wa, s + 1); }
-        compute(wb, smem[1]);
+        if (s + 1 < s_end) { load_a(s + 1); load_w(wa, s + 1); if (wide) load_w5(wa5, s + 1); }
+        compute(wb, wb5, smem[1]);
         if (++s >= s_end) break;
     }
     if (NORMA && sums) {
@@ -218,6 +251,30 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __res
                     Y[(long)m * ldc + col] = f2bf(gv / (1.f + __expf(-gv)) * other);
                 }
             }
+        if (MT == 1 && wide) {
+            // fifth fragment: the four waves' K quarters meet in LDS ([wave][row block][lane] float4, 16 KiB of the A buffers, which
+            // every wave has left: barrier first), wave w sums row block w in wave order and runs the same epilogue on it
+            __syncthreads();
+            float4* part = (float4*)&smem[0][0];
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf)
+                part[(wave * MF + mf) * 64 + lane] = make_float4(acc5[mf][0], acc5[mf][1], acc5[mf][2], acc5[mf][3]);
+            __syncthreads();
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float4 t = part[(w * MF + wave) * 64 + lane];
+                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+            }
+            const int col5 = (n5 >> 1) + (l15 & 7);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float other = __shfl_xor(v[r], 8);
+                const int m = wave * 16 + g * 4 + r;
+                if (l15 < 8 && m < mflush && n5 + l15 < N)
+                    Y[(long)m * ldc + col5] = f2bf(v[r] / (1.f + __expf(-v[r])) * other);
+            }
+        }
         return;
     }
     const bool whole_k = (s_begin == 0 && s_end == total_slices);
@@ -829,6 +886,17 @@ static int launch_skinny_swiglu(const void* A, long lda, const void* Bpacked, vo
     if (M > 64) {
         hipLaunchKernelGGL((gemm_skinny_kernel<true, true, 2>), dim3(col_groups, 1), dim3(256), 0, stream,
                            (const bf16_t*)A, lda, (const bf16_t*)Bpacked, 0L, (float*)Y, ldy, M, N, K, K / 128, M, 0);
+        SP_CHECK_LAUNCH();
+        return SPACER_OK;
+    }
+    // one-round form (round 4): between 4 and 5 column fragments per resident slot -> exactly `slots` workgroups, the first
+    // `wide` of them five fragments wide (gemm_skinny_kernel: wide_groups)
+    const int slots1 = 2 * plan_cus(plan), frags = N / 16;
+    if (N % 16 == 0 && frags > 4 * slots1 && frags < 5 * slots1 && !(plan && (plan->skinny_no_balance || plan->skinny_blocks))) {
+        const int wide = frags - 4 * slots1;
+        hipLaunchKernelGGL((gemm_skinny_kernel<true, true, 1>), dim3(slots1, 1), dim3(256), 0, stream, (const bf16_t*)A, lda,
+                           (const bf16_t*)Bpacked, 0L, (float*)Y, ldy, M, N, K, K / 256, M, 0, 0, 1, (float*)nullptr, (int*)nullptr,
+                           (float*)nullptr, wide);
         SP_CHECK_LAUNCH();
         return SPACER_OK;
     }

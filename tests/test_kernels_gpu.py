@@ -182,17 +182,31 @@ def test_gemm_skinny_swiglu_tail_balance_leaves_workspace_clean(dev):
     wp = K.pack_weight_frag_swiglu(w)
     gu = a.float() @ w.float().t()
     want = torch.nn.functional.silu(gu[:, :I]) * gu[:, I:]
+    # default plan at this shape (2368 column fragments on 512 slots): the ONE-ROUND form -- 320 workgroups five fragments wide, 192
+    # four; no atomics, so it is bit-reproducible
     outs = [K.gemm_skinny_swiglu(a, wp, I).clone() for _ in range(5)]
     for o in outs:
-        assert_close(o, want, 2e-2, 1e-2, "skinny swiglu (tail-balanced)")
+        assert_close(o, want, 2e-2, 1e-2, "skinny swiglu (one-round form)")
+        assert torch.equal(o, outs[0])
     ws = K._SWIGLU_WS[a.device]
     torch.cuda.synchronize()
     assert int(ws.abs().sum()) == 0
     with K.plan(skinny_no_balance=1):
         plain = K.gemm_skinny_swiglu(a, wp, I).clone()
-    # whole-K columns are bit-identical; the 80 split groups differ only by fp32 summation order before the bf16 rounding
-    assert torch.equal(outs[0][:, :(512 * 64) // 2], plain[:, :(512 * 64) // 2])
-    assert_close(outs[0], plain, 1e-2, 1e-2, "balanced vs plain")
+    # fragments owned by ONE wave sum over K in the same order as the plain 64-column launch: bit-identical; the fifth fragment of a wide
+    # workgroup (fragment 5 i + 4, i < 320 = output columns 8 (5 i + 4) .. + 7) is summed as four K quarters: fp32 order differs
+    fifth = torch.zeros(I, dtype=torch.bool)
+    for i in range(2368 - 4 * 512):
+        fifth[8 * (5 * i + 4):8 * (5 * i + 4) + 8] = True
+    assert torch.equal(outs[0][:, ~fifth.to(dev)], plain[:, ~fifth.to(dev)])
+    assert_close(outs[0], plain, 1e-2, 1e-2, "one-round vs plain")
+    # a CU budget of 224 (co-running stream beside the decode loop) keeps the old tail-balanced 64-column form: 2368 > 5 x 448
+    with K.plan(cus=224):
+        bal = K.gemm_skinny_swiglu(a, wp, I).clone()
+    assert_close(bal, want, 2e-2, 1e-2, "skinny swiglu (tail-balanced, 448 slots)")
+    # fewer rows (cfg4's 8-row decode batch) through the same one-round launch
+    o8 = K.gemm_skinny_swiglu(a[:8].contiguous(), wp, I)
+    assert torch.equal(o8, outs[0][:8])
 
 
 @pytest.mark.parametrize("M,N,Kd", [(128, 3584, 3584), (96, 4608, 3584), (65, 512, 18944), (100, 1008, 256)])
