@@ -33,10 +33,10 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 // whole-K blocks instead of after them); their partial sums meet in an fp32 scratch tile through agent-scope atomics, an
 // agent-scope ticket per column group counts arrivals, and the last arriver takes the totals back with atomic exchanges (read +
 // re-zero in one read-modify-write: both sides atomics on the same words, so no fence is needed) and applies the SwiGLU epilogue.
-// SWIGLU one-round form (wide_groups > 0, MT = 1; round 4): when the N / 16 column fragments number between 4 and 5 per resident
+// SWIGLU one-round form (wide_groups > 0; round 4): when the N / 16 column fragments number between 4 and 5 per resident
 // workgroup slot (7B gate|up: 2368 fragments on 512 slots), the launch is EXACTLY one resident round of 512 workgroups: the first
 // `wide_groups` (= fragments - 4 * slots) own FIVE fragments, the others four.  Wave w of a wide workgroup streams its own fragment
-// over all of K as before plus k-steps 2w, 2w + 1 of every slice of the fifth fragment (one quarter of its weights); the four partial
+// over all of K as before plus one quarter of the k-steps of every slice of the fifth fragment (MT = 1: k-steps 2w, 2w + 1; MT = 2: k-step w); the four partial
 // sums of the fifth fragment meet in LDS after the K loop and wave w finishes rows 16w .. 16w + 15 of it.  No atomics, no ticket,
 // no second round: time = 9.4 us + bytes / 6.75 TB/s like any one-round launch of this kernel (scripts/probes/swiglu_equal_work.py)
 // instead of the 1.16 rounds of the 64-column decomposition (58.7 us with the tail balance, 49.6 us by that law).
@@ -77,10 +77,10 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __res
     }
     int n0 = cgroup * 64 + wave * 16;
     // one-round form: workgroup bx owns fragments [f0, f0 + 5) (bx < wide_groups) or [f0, f0 + 4)
-    const bool wide = SWIGLU && MT == 1 && wide_groups > 0 && (int)blockIdx.x < wide_groups;
+    const bool wide = SWIGLU && wide_groups > 0 && (int)blockIdx.x < wide_groups;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);        // scalar copy: the fifth-fragment branch below is wave-uniform
     int n5 = 0;
-    if (SWIGLU && MT == 1 && wide_groups > 0) {
+    if (SWIGLU && wide_groups > 0) {
         const int bx = (int)blockIdx.x;
         const int f0 = bx < wide_groups ? 5 * bx : 5 * wide_groups + 4 * (bx - wide_groups);
         n0 = (f0 + wave) * 16;
@@ -136,17 +136,18 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __res
             w[u] = __builtin_nontemporal_load((const u32x4*)p);
         }
     };
-    // fifth fragment of a wide workgroup: this wave's two k-steps (2 wave, 2 wave + 1) of every slice
+    // fifth fragment of a wide workgroup: this wave's quarter of the k-steps (N5 * wave .. + N5 - 1) of every slice
+    constexpr int N5 = NU / 4;
     const bf16_t* bbase5 = B + ((long)min(n5 >> 4, (N >> 4) - 1) * (K >> 5)) * 512 + lane * 8;
-    auto load_w5 = [&](u32x4 (&w)[2], int slice) {
+    auto load_w5 = [&](u32x4 (&w)[N5], int slice) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
-            w[q] = __builtin_nontemporal_load((const u32x4*)(bbase5 + ((long)slice * NU + 2 * wave_u + q) * 512));
+        for (int q = 0; q < N5; ++q)
+            w[q] = __builtin_nontemporal_load((const u32x4*)(bbase5 + ((long)slice * NU + N5 * wave_u + q) * 512));
     };
     f32x4 acc[MF], acc5[MF];
 #pragma unroll
     for (int i = 0; i < MF; ++i) { acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc5[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-    auto compute = [&](const u32x4 (&w)[NU], const u32x4 (&w5)[2], const char* buf) {
+    auto compute = [&](const u32x4 (&w)[NU], const u32x4 (&w5)[N5], const char* buf) {
         // A fragments double-buffered by hand and the scheduler fenced per k-step (left alone hipcc hoists all 32
         // fragment reads of the slice and spills)
         bf16x8 af[2][MF];
@@ -166,8 +167,8 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __res
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf)
                 acc[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][mf], wf, acc[mf], 0, 0, 0);   // D[m][n]
-            if (SWIGLU && MT == 1 && wide && (u >> 1) == wave_u) {     // wave-uniform: this wave's share of the fifth fragment
-                const bf16x8 wf5 = __builtin_bit_cast(bf16x8, w5[u & 1]);
+            if (SWIGLU && wide && (u / N5) == wave_u) {                // wave-uniform: this wave's share of the fifth fragment
+                const bf16x8 wf5 = __builtin_bit_cast(bf16x8, w5[u % N5]);
 #pragma unroll
                 for (int mf = 0; mf < MF; ++mf)
                     acc5[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][mf], wf5, acc5[mf], 0, 0, 0);
@@ -176,9 +177,9 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __res
         }
     };
 
-    u32x4 wa[NU], wb[NU], wa5[2], wb5[2];
+    u32x4 wa[NU], wb[NU], wa5[N5], wb5[N5];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) { wa5[q] = (u32x4){0u, 0u, 0u, 0u}; wb5[q] = (u32x4){0u, 0u, 0u, 0u}; }
+    for (int q = 0; q < N5; ++q) { wa5[q] = (u32x4){0u, 0u, 0u, 0u}; wb5[q] = (u32x4){0u, 0u, 0u, 0u}; }
     load_a(s_begin);
     load_w(wa, s_begin);
     if (wide) load_w5(wa5, s_begin);
@@ -251,28 +252,32 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __res
                     Y[(long)m * ldc + col] = f2bf(gv / (1.f + __expf(-gv)) * other);
                 }
             }
-        if (MT == 1 && wide) {
-            // fifth fragment: the four waves' K quarters meet in LDS ([wave][row block][lane] float4, 16 KiB of the A buffers, which
-            // every wave has left: barrier first), wave w sums row block w in wave order and runs the same epilogue on it
+        if (wide) {
+            // fifth fragment: the four waves' K quarters meet in LDS ([wave][row block][lane] float4, 16 KiB x MT of the A buffers,
+            // which every wave has left: barrier first), wave w sums row blocks w, w + 4, .. in wave order and runs the same epilogue
             __syncthreads();
             float4* part = (float4*)&smem[0][0];
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf)
                 part[(wave * MF + mf) * 64 + lane] = make_float4(acc5[mf][0], acc5[mf][1], acc5[mf][2], acc5[mf][3]);
             __syncthreads();
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const float4 t = part[(w * MF + wave) * 64 + lane];
-                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-            }
             const int col5 = (n5 >> 1) + (l15 & 7);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float other = __shfl_xor(v[r], 8);
-                const int m = wave * 16 + g * 4 + r;
-                if (l15 < 8 && m < mflush && n5 + l15 < N)
-                    Y[(long)m * ldc + col5] = f2bf(v[r] / (1.f + __expf(-v[r])) * other);
+            for (int b = 0; b < MT; ++b) {
+                const int mf = wave + 4 * b;                                 // MF = 4 MT row blocks, MT per wave
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const float4 t = part[(w * MF + mf) * 64 + lane];
+                    v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float other = __shfl_xor(v[r], 8);
+                    const int m = mf * 16 + g * 4 + r;
+                    if (l15 < 8 && m < mflush && n5 + l15 < N)
+                        Y[(long)m * ldc + col5] = f2bf(v[r] / (1.f + __expf(-v[r])) * other);
+                }
             }
         }
         return;
@@ -883,17 +888,19 @@ static int launch_skinny_swiglu(const void* A, long lda, const void* Bpacked, vo
     SP_REQUIRE(K % 256 == 0 && inter % 32 == 0 && lda % 8 == 0, SPACER_EINVAL,
                "gemm_skinny_swiglu: need K %% 256 == 0, inter %% 32 == 0, lda %% 8 == 0");
     const int N = 2 * inter, col_groups = cdiv(N, 64);
+    // one-round form (round 4): between 4 and 5 column fragments per resident slot -> exactly `slots` workgroups, the first
+    // `wide` of them five fragments wide (gemm_skinny_kernel: wide_groups); 65..128 rows: the same with two row blocks per pass
+    const int slots1 = 2 * plan_cus(plan), frags = N / 16;
+    const bool one_round = N % 16 == 0 && frags > 4 * slots1 && frags < 5 * slots1 && !(plan && (plan->skinny_no_balance || plan->skinny_blocks));
+    const int wide = one_round ? frags - 4 * slots1 : 0;
     if (M > 64) {
-        hipLaunchKernelGGL((gemm_skinny_kernel<true, true, 2>), dim3(col_groups, 1), dim3(256), 0, stream,
-                           (const bf16_t*)A, lda, (const bf16_t*)Bpacked, 0L, (float*)Y, ldy, M, N, K, K / 128, M, 0);
+        hipLaunchKernelGGL((gemm_skinny_kernel<true, true, 2>), dim3(one_round ? slots1 : col_groups, 1), dim3(256), 0, stream,
+                           (const bf16_t*)A, lda, (const bf16_t*)Bpacked, 0L, (float*)Y, ldy, M, N, K, K / 128, M, 0, 0, 1, (float*)nullptr,
+                           (int*)nullptr, (float*)nullptr, wide);
         SP_CHECK_LAUNCH();
         return SPACER_OK;
     }
-    // one-round form (round 4): between 4 and 5 column fragments per resident slot -> exactly `slots` workgroups, the first
-    // `wide` of them five fragments wide (gemm_skinny_kernel: wide_groups)
-    const int slots1 = 2 * plan_cus(plan), frags = N / 16;
-    if (N % 16 == 0 && frags > 4 * slots1 && frags < 5 * slots1 && !(plan && (plan->skinny_no_balance || plan->skinny_blocks))) {
-        const int wide = frags - 4 * slots1;
+    if (one_round) {
         hipLaunchKernelGGL((gemm_skinny_kernel<true, true, 1>), dim3(slots1, 1), dim3(256), 0, stream, (const bf16_t*)A, lda,
                            (const bf16_t*)Bpacked, 0L, (float*)Y, ldy, M, N, K, K / 256, M, 0, 0, 1, (float*)nullptr, (int*)nullptr,
                            (float*)nullptr, wide);

@@ -164,7 +164,8 @@ def test_gemm_skinny(dev, M, N, K):
         assert_close(c2, c0 + a.float() @ b.float().t(), 5e-3, 2e-3, "skinny packed")
 
 
-@pytest.mark.parametrize("M,I,Kd", [(64, 18944, 3584), (8, 512, 256), (33, 96, 1536), (128, 2048, 1024), (97, 96, 512)])
+@pytest.mark.parametrize("M,I,Kd", [(64, 18944, 3584), (8, 512, 256), (33, 96, 1536), (128, 2048, 1024), (97, 96, 512), (128, 18944, 3584),
+                                    (96, 18944, 3584), (40, 17024, 512)])
 def test_gemm_skinny_swiglu(dev, M, I, Kd):
     a, w = rnd((M, Kd), dev, 1, 0.5), rnd((2 * I, Kd), dev, 2, 0.05)
     y = K.gemm_skinny_swiglu(a, K.pack_weight_frag_swiglu(w), I)
@@ -207,6 +208,16 @@ def test_gemm_skinny_swiglu_tail_balance_leaves_workspace_clean(dev):
     # fewer rows (cfg4's 8-row decode batch) through the same one-round launch
     o8 = K.gemm_skinny_swiglu(a[:8].contiguous(), wp, I)
     assert torch.equal(o8, outs[0][:8])
+    # 65..128 rows (T-GRPO twin rollouts in the same decode batch): two row blocks per weight pass, the same one-round decomposition
+    a2 = rnd((128, Kd), dev, 33, 0.5)
+    want2 = a2.float() @ w.float().t()
+    want2 = torch.nn.functional.silu(want2[:, :I]) * want2[:, I:]
+    y2 = K.gemm_skinny_swiglu(a2, wp, I)
+    assert_close(y2, want2, 2e-2, 1e-2, "skinny swiglu, 128 rows, one-round form")
+    with K.plan(skinny_no_balance=1):
+        plain2 = K.gemm_skinny_swiglu(a2, wp, I)
+    assert torch.equal(y2[:, ~fifth.to(dev)], plain2[:, ~fifth.to(dev)])
+    assert_close(y2, plain2, 1e-2, 1e-2, "one-round vs plain, 128 rows")
 
 
 @pytest.mark.parametrize("M,N,Kd", [(128, 3584, 3584), (96, 4608, 3584), (65, 512, 18944), (100, 1008, 256)])
