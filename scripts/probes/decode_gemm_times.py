@@ -9,23 +9,32 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from spacer_amd import kernels as K   # noqa: E402
 
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+FLAGS = [int(f) for f in sys.argv[2].split(',')] if len(sys.argv) > 2 else [0]
 dev = torch.device("cuda:0")
 H, I, QKV, V = 3584, 18944, 4608, 152064
 NC = 10
 
 
 def timed(fn, n=60):
-    for i in range(NC):
-        fn(i)
-    torch.cuda.synchronize()
-    ev = []
-    for r in range(n):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); fn(r); e1.record()
-        ev.append((e0, e1))
-    torch.cuda.synchronize()
-    t = sorted(a.elapsed_time(b) * 1e3 for a, b in ev)
-    return t[len(t) // 2], sum(t) / len(t)
+    out = []
+    for rep in range(2):                                   # flags alternate twice: drift of the box shows as a difference between repeats
+        for fl in FLAGS:
+            if hasattr(K.PLAN, 'skinny_flags'):
+                K.PLAN.skinny_flags = fl
+            for i in range(NC):
+                fn(i)
+            torch.cuda.synchronize()
+            ev = []
+            for r in range(n):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); fn(r); e1.record()
+                ev.append((e0, e1))
+            torch.cuda.synchronize()
+            t = sorted(a.elapsed_time(b) * 1e3 for a, b in ev)
+            out.append((fl, t[len(t) // 2], sum(t) / len(t)))
+    if hasattr(K.PLAN, 'skinny_flags'):
+        K.PLAN.skinny_flags = 0
+    return out
 
 
 def mk(n, k):
@@ -53,5 +62,5 @@ del w
 w = [K.pack_weight_frag((torch.randn(V, H, device=dev) * 0.02).bfloat16()) for _ in range(2)]
 lg = torch.empty(rows, V, device=dev)
 res["lm_head (1090 MB)"] = timed(lambda i: K.gemm_skinny_packed_store(xb, w[i % 2], lg, V), n=20)
-for k, (med, mean) in res.items():
-    print(f"  {k:34s} median {med:7.1f} us   mean {mean:7.1f} us", flush=True)
+for k, rows_ in res.items():
+    print(f"  {k:34s} " + "   ".join(f"flags {fl}: median {med:6.1f} mean {mean:6.1f}" for fl, med, mean in rows_), flush=True)
