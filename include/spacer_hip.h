@@ -127,7 +127,10 @@ int spacer_gemm_skinny_swiglu_bf16(const void* A, long lda, const void* Bpacked,
 /* The same with a caller-owned workspace of spacer_gemm_skinny_swiglu_workspace_bytes() bytes, ZERO-FILLED ONCE by the caller
  * (the kernel leaves it zeroed; launches sharing it must be ordered on one stream).  With it, when N/64 column groups leave a
  * short last round on the 512 resident workgroup slots (7B: 592), the tail groups are cut along K into small blocks that run
- * beside the whole-K blocks and meet through agent-scope atomics + a ticket (last arriver runs the SwiGLU epilogue). */
+ * beside the whole-K blocks and meet through agent-scope atomics + a ticket (last arriver runs the SwiGLU epilogue).
+ * Round 4: when the 2*inter/16 column fragments number between 4 and 5 per resident slot (2 x plan->cus; 7B: 2368 on 512) both
+ * entries launch EXACTLY one resident round instead -- `fragments - 4 x slots` workgroups five fragments wide, the rest four; the
+ * fifth fragment's K quarters are summed in LDS, no atomics, no workspace use, bit-reproducible (M <= 128). */
 long spacer_gemm_skinny_swiglu_workspace_bytes(void);
 int spacer_gemm_skinny_swiglu_bf16_ws(const void* A, long lda, const void* Bpacked, void* Y, long ldy, int M, int inter, int K,
                                       void* workspace, long workspace_bytes, const spacer_plan* plan, spacer_stream_t stream);
