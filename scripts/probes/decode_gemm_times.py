@@ -19,8 +19,7 @@ def timed(fn, n=60):
     out = []
     for rep in range(2):                                   # flags alternate twice: drift of the box shows as a difference between repeats
         for fl in FLAGS:
-            if hasattr(K.PLAN, 'skinny_flags'):
-                K.PLAN.skinny_flags = fl
+            K.PLAN.skinny_skew = fl
             for i in range(NC):
                 fn(i)
             torch.cuda.synchronize()
@@ -32,8 +31,7 @@ def timed(fn, n=60):
             torch.cuda.synchronize()
             t = sorted(a.elapsed_time(b) * 1e3 for a, b in ev)
             out.append((fl, t[len(t) // 2], sum(t) / len(t)))
-    if hasattr(K.PLAN, 'skinny_flags'):
-        K.PLAN.skinny_flags = 0
+    K.PLAN.skinny_skew = 0
     return out
 
 
@@ -63,4 +61,4 @@ w = [K.pack_weight_frag((torch.randn(V, H, device=dev) * 0.02).bfloat16()) for _
 lg = torch.empty(rows, V, device=dev)
 res["lm_head (1090 MB)"] = timed(lambda i: K.gemm_skinny_packed_store(xb, w[i % 2], lg, V), n=20)
 for k, rows_ in res.items():
-    print(f"  {k:34s} " + "   ".join(f"flags {fl}: median {med:6.1f} mean {mean:6.1f}" for fl, med, mean in rows_), flush=True)
+    print(f"  {k:34s} " + "   ".join(f"skew {fl}: median {med:6.1f} mean {mean:6.1f}" for fl, med, mean in rows_), flush=True)

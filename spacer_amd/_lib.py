@@ -22,7 +22,7 @@ class SpacerError(RuntimeError):
 class Plan(C.Structure):
     """include/spacer_hip.h: spacer_plan -- launch-plan switches handed to the library explicitly (it reads no environment)."""
     _fields_ = [("gemm_tile", C.c_int), ("gemm_no_split", C.c_int), ("skinny_blocks", C.c_int), ("skinny_no_balance", C.c_int),
-                ("cus", C.c_int)]
+                ("cus", C.c_int), ("skinny_skew", C.c_int)]
 
 
 class GemmEpilogue(C.Structure):

@@ -62,6 +62,16 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __res
     const int l15 = lane & 15, g = lane >> 4;
     const int total_slices = K / KS;
     int cgroup = blockIdx.x, s_begin = blockIdx.y * slices_per_range, s_end = min(total_slices, s_begin + slices_per_range);
+    if (slices_per_range < 0) {
+        // skewed K ranges (spacer_plan::skinny_skew = k + 1, passed as -(k + 1)): range r of R gets a share proportional to
+        // 1 + alpha (2 r / (R - 1) - 1), alpha = k / 16 -- the ranges of a column group finish at different times, so their atomic
+        // flushes overlap the other ranges' weight streaming instead of all landing when the stream ends; k = 0: an even split
+        const int R = (int)gridDim.y, r = (int)blockIdx.y;
+        const float al = (float)(-slices_per_range - 1) * (1.f / 16.f);
+        auto st = [&](int q) { const float c = (float)q + (R > 1 ? al * (float)q * (float)(q - R) / (float)(R - 1) : 0.f);
+                               return (int)((float)total_slices * c / (float)R + 0.5f); };
+        s_begin = st(r); s_end = st(r + 1);
+    }
     bool split_block = false;
     if (SWIGLU && split_groups > 0) {
         const int n_split_blocks = split_groups * split_ranges, whole = (N >> 6) - split_groups;
@@ -788,6 +798,18 @@ static inline int skinny_target_blocks(const spacer_plan* plan) {
     return plan && plan->skinny_blocks > 0 ? plan->skinny_blocks : 2 * plan_cus(plan);
 }
 
+// K-range shape of a K-split launch: 0 = equal ranges of ceil(slices / ranges); k + 1 = shares 1 + (k / 16)(2 r / (R - 1) - 1) (kernel).
+// Default rule (plan->skinny_skew == 0): a launch that fills the resident slots with SHORT ranges (<= 2 slices each: the 7B q|k|v
+// projection, 72 column groups x 7 ranges of 2) ends with every workgroup flushing its atomics at the same moment; skewing the ranges
+// (alpha = 0.5: 1,1,2,2,2,3,3 slices) staggers the flushes under the other ranges' streaming: 16.6 -> 15.6 us (norm-folded), 14.7 -> 13.4 us
+// (scripts/probes/decode_gemm_times.py, A/B in one process).  Launches that do not fill the slots (o: 392 workgroups) or have long
+// ranges (down: 8-9 slices) measured slower with a skew and keep equal ranges.  plan->skinny_skew < 0 forces equal ranges.
+static inline int skinny_skew(const spacer_plan* plan, int col_groups, int ranges, int slices, int target_blocks) {
+    if (ranges <= 1) return 0;
+    if (plan && plan->skinny_skew != 0) return plan->skinny_skew > 0 ? plan->skinny_skew : 0;
+    return (col_groups * ranges >= target_blocks - target_blocks / 16 && cdiv(slices, ranges) <= 2 && slices >= 2 * ranges) ? 9 : 0;
+}
+
 static int launch_skinny(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
                          const spacer_gemm_epilogue* epi, bool packed, const spacer_plan* plan, hipStream_t s, bool overwrite = false) {
     SP_REQUIRE(A && B && C, SPACER_EINVAL, "gemm_skinny: null operand");
@@ -806,8 +828,10 @@ static int launch_skinny(const void* A, long lda, const void* B, long ldb, void*
     // as many K ranges as keep the whole launch in ONE resident round (2 workgroups x 256 CUs): down-proj at 7B (56 column
     // groups x 74 slices) ran as 560 blocks = a full round + a 48-block tail before; now 9 ranges = 504 blocks
     if (col_groups < target_blocks - target_blocks / 8) ranges = max(1, min(slices, target_blocks / col_groups));
-    const int spr = cdiv(slices, ranges);
-    ranges = cdiv(slices, spr);
+    int spr = cdiv(slices, ranges);
+    const int skew = skinny_skew(plan, col_groups, ranges, slices, target_blocks);
+    if (skew > 0) spr = -skew;                 // skewed / even ranges: the kernel derives them from gridDim.y
+    else ranges = cdiv(slices, spr);
     SP_REQUIRE(!overwrite || ranges == 1, SPACER_EINVAL, "gemm_skinny: C = A.B^T (store form) needs whole-K workgroups; N=%d splits K %d ways", N, ranges);
     const int mflush = M;
     if (packed && MTv == 2)
@@ -843,8 +867,10 @@ extern "C" int spacer_gemm_skinny_packed_normed(const float* X32, long ldx, cons
     const int col_groups = cdiv(N, 64), slices = K / 256;
     const int target_blocks = skinny_target_blocks(plan);
     int ranges = col_groups < target_blocks - target_blocks / 8 ? max(1, min(slices, target_blocks / col_groups)) : 1;
-    const int spr = cdiv(slices, ranges);
-    ranges = cdiv(slices, spr);
+    int spr = cdiv(slices, ranges);
+    const int skew = skinny_skew(plan, col_groups, ranges, slices, target_blocks);
+    if (skew > 0) spr = -skew;
+    else ranges = cdiv(slices, spr);
     hipLaunchKernelGGL((gemm_skinny_kernel<true, false, 1, true>), dim3(col_groups, ranges), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)X32, ldx, (const bf16_t*)Bpacked, 0L, C, ldc, M, N, K, spr, M, 0, 0, 1, (float*)nullptr,
                        (int*)nullptr, rowss);

@@ -27,7 +27,7 @@ def _plan_from_env() -> Plan:
     e = os.environ
     return Plan(gemm_tile=int(e.get("SPACER_GEMM_TILE", "0") or 0), gemm_no_split=int(bool(e.get("SPACER_GEMM_NOSPLIT"))),
                 skinny_blocks=int(e.get("SPACER_SKINNY_BLOCKS", "0") or 0), skinny_no_balance=int(bool(e.get("SPACER_SKINNY_NOBALANCE"))),
-                cus=int(e.get("SPACER_CUS", "0") or 0))
+                cus=int(e.get("SPACER_CUS", "0") or 0), skinny_skew=int(e.get("SPACER_SKINNY_SKEW", "0") or 0))
 
 
 PLAN = _plan_from_env()
