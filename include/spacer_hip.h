@@ -53,7 +53,7 @@ typedef struct spacer_plan {
     int skinny_no_balance; /* 1 = decode gate|up GEMM without the tail balance */
     int cus;               /* compute units the launch may count on; 0 = 256 (all of MI355X).  A caller that runs a second,
                             * CU-masked stream beside the decode loop passes the decode loop's share */
-    int skinny_skew;       /* K-split decode GEMMs: 0 = the library's rule (equal K ranges, except a skew of alpha = 0.5 for launches that
+    int skinny_skew;       /* K-split decode GEMMs: 0 = the library's rule (equal K ranges, except a skew of alpha = 0.375 for launches that
                             * fill the resident slots with ranges of <= 2 slices); < 0 = always equal ranges; k + 1 = ranges with shares
                             * 1 + (k / 16) (2 r / (R - 1) - 1): k = 0 an even split, k > 0 skewed so that the ranges' atomic flushes do
                             * not all land when the weight stream ends */

@@ -801,13 +801,14 @@ static inline int skinny_target_blocks(const spacer_plan* plan) {
 // K-range shape of a K-split launch: 0 = equal ranges of ceil(slices / ranges); k + 1 = shares 1 + (k / 16)(2 r / (R - 1) - 1) (kernel).
 // Default rule (plan->skinny_skew == 0): a launch that fills the resident slots with SHORT ranges (<= 2 slices each: the 7B q|k|v
 // projection, 72 column groups x 7 ranges of 2) ends with every workgroup flushing its atomics at the same moment; skewing the ranges
-// (alpha = 0.5: 1,1,2,2,2,3,3 slices) staggers the flushes under the other ranges' streaming: 16.6 -> 15.6 us (norm-folded), 14.7 -> 13.4 us
+// (alpha = 0.375: 1,2,2,2,2,2,3 slices; 0.5 and more measured worse) staggers the flushes under the other ranges' streaming: 16.8 -> 15.0 us
+// (norm-folded), 14.7 -> 13.3 us (bf16 A)
 // (scripts/probes/decode_gemm_times.py, A/B in one process).  Launches that do not fill the slots (o: 392 workgroups) or have long
 // ranges (down: 8-9 slices) measured slower with a skew and keep equal ranges.  plan->skinny_skew < 0 forces equal ranges.
 static inline int skinny_skew(const spacer_plan* plan, int col_groups, int ranges, int slices, int target_blocks) {
     if (ranges <= 1) return 0;
     if (plan && plan->skinny_skew != 0) return plan->skinny_skew > 0 ? plan->skinny_skew : 0;
-    return (col_groups * ranges >= target_blocks - target_blocks / 16 && cdiv(slices, ranges) <= 2 && slices >= 2 * ranges) ? 9 : 0;
+    return (col_groups * ranges >= target_blocks - target_blocks / 16 && cdiv(slices, ranges) <= 2 && slices >= 2 * ranges) ? 7 : 0;
 }
 
 static int launch_skinny(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
