@@ -83,15 +83,16 @@ def cpu_fulldepth_measure(model: str, C: int = 32):
     return json.loads(out.stdout.strip().splitlines()[-1])
 
 
-def cpu_baseline(cfg, workload, fulldepth: bool = False):
+def cpu_baseline(cfg, workload, fulldepth: bool = True):
     """The reference path's CPU stand-in (SURVEY 8(d) "CPU baseline"): ONE prompt group through the WHOLE step on the host
     (oracle/cpu_path.py: ViT + prefill, KV-cache decode, reference + policy scoring with the prompt shared, GRPO loss,
     autograd backward; fp32 torch) on a BOUNDED sample of the workload: the model's real widths and REAL VOCABULARY with the depth
     cut to 2 decoder layers + 2 vision blocks, the workload's real frames / prompt length, K = 2 rollouts of 8 tokens.  Every phase
     is then scaled to the full depth, K and C by its own cost law (stated in "extrapolation"); the lm_head, which does not scale
-    with depth, is timed on its own and scaled by rows only.  The FULL-DEPTH run of the same group at C = 32
-    (scripts/run_cpu_fulldepth.py, minutes of host time) and BASELINE configs[0] in full (scripts/run_cfg1_cpu.py) are recorded
-    files under profiles/, attached as "full_depth_C32" / "cfg1" with their source named -- they are not re-measured here."""
+    with depth, is timed on its own and scaled by rows only.  Round 5: that sample is the labelled CROSS-CHECK ("value_from_sample");
+    ``value`` comes from the FULL-DEPTH run of the same group at C = 32 (scripts/run_cpu_fulldepth.py, ~3 min of host time for 7B),
+    measured IN THIS RUN unless --no-cpu-fulldepth ("full_depth_C32.source" says which).  BASELINE configs[0] in full
+    (scripts/run_cfg1_cpu.py) stays a recorded file under profiles/, attached as "cfg1" with its source named."""
     from oracle import cpu_path as CP
     from oracle import qwen2vl_fp32 as O
     preset, F, Hpx, Wpx, n_text, Kgen, C, groups = workload
@@ -173,9 +174,12 @@ def cpu_baseline(cfg, workload, fulldepth: bool = False):
                 rec = json.load(f)
             rec["source"] = f"profiles/{fname}: recorded on an MI355X box's host, NOT re-measured in this run"
             res[key] = rec
-    if fulldepth and preset in ("Qwen2-VL-7B", "Qwen2-VL-2B"):
-        # --cpu-fulldepth: the full-depth group re-measured in THIS run; its C = 512 extrapolation becomes ``value``
+    if fulldepth and preset in ("Qwen2-VL-7B", "Qwen2-VL-2B") and (F, Hpx, Wpx, n_text, Kgen) == (16, 280, 364, 360, 8):
+        # the full-depth group measured in THIS run (cfg3 / cfg4 shapes); its C = 512 extrapolation becomes ``value``
         rec = cpu_fulldepth_measure("7b" if preset == "Qwen2-VL-7B" else "2b")
+        if "error" in rec:
+            res["full_depth_C32_error"] = rec["error"]          # keep the recorded file and the sample's value
+            return res
         rec["source"] = "measured in this run (scripts/run_cpu_fulldepth.py on this host)"
         res["full_depth_C32"] = rec
         if "extrapolated_to_C512" in rec:
@@ -335,8 +339,10 @@ def main():
                     help="selective activation recompute in the policy backward (--gradient_checkpointing true of the shipped script): "
                          "MLP intermediates and lm_head logits are recomputed, which makes room for more groups per pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-fulldepth", action="store_true",
-                    help="cpu_baseline: also re-measure the FULL-DEPTH group on the host (minutes) and quote value from it")
+    ap.add_argument("--cpu-fulldepth", action="store_true", help="(default since round 5; kept for old command lines)")
+    ap.add_argument("--no-cpu-fulldepth", action="store_true",
+                    help="cpu_baseline: skip the FULL-DEPTH group on the host (~3 min for the 7B presets) and quote value from the "
+                         "extrapolated 2-layer sample instead")
     ap.add_argument("--precise-logps", action="store_true",
                     help="the headline step with GRPOHyper.precise_logps: policy / reference log-probs, KL and loss in the precise mode "
                          "(<= 1e-3 of fp32 at full depth); default: the fast bf16-operand path, precise step reported under variants")
@@ -555,15 +561,17 @@ def main():
                 # precise mode, gradient from the production backward on the precise forward's tape
                 try:
                     ge.h.precise_logps = True
-                    step(20_000)
+                    for i in range(max(1, args.warmup)):                  # the headline's warm-up
+                        step(20_000 + i)
                     torch.cuda.synchronize()
                     t_v = time.perf_counter()
-                    n_v = 2
+                    n_v = max(5, min(args.steps, 10))                     # >= 5 timed steps
                     for i in range(n_v):
-                        step(20_001 + i)
+                        step(20_100 + i)
                     torch.cuda.synchronize()
                     dt_v = (time.perf_counter() - t_v) / n_v
                     variants["precise_step"] = {"samples_per_s": round(groups * Kgen / dt_v, 3), "ms_per_step": round(1e3 * dt_v, 1), "steps": n_v,
+                                                "warmup": max(1, args.warmup),
                                                 "vs_headline_step_time": round(dt_v / (elapsed / args.steps), 3),
                                                 "what": "policy + reference log-probs, KL, loss in the precise mode (<= 1e-3 of the fp32 oracle at full 7B "
                                                         "depth: tests/test_precise_gpu.py); gradient = production backward on the precise tape"}
@@ -596,7 +604,8 @@ def main():
         # NT with bf16 output and no residual (q|k|v, gate|up + SwiGLU: bf16 staging, persistent), forward NT with an fp32
         # residual (o, down, lm_head), dX (trans_b) and dW (trans_a + trans_b, fp32 read-modify-write epilogue); the roofline
         # object is for the one with the most time in the step
-        fams = {k: v for k, v in prof.items() if k.startswith("gemm_bf16_nt_256h_kernel")}
+        # (--precise-logps: the pair forms of the same tile, gemm_bf16_pair_256h_kernel<MODE>, are rows of their own since round 5)
+        fams = {k: v for k, v in prof.items() if k.startswith("gemm_bf16_nt_256h_kernel") or k.startswith("gemm_bf16_pair_256h_kernel")}
         dom = max(fams, key=lambda k: fams[k]["seconds"]) if fams else "gemm_bf16_nt_256h_kernel"
         gemm = prof.get(dom, dict(tflops=0.0, launches=0, seconds=0.0, flops=0.0, bytes=0.0))
         dom_name = dom if "<" in dom else dom + "<true, false, false, true>"
@@ -664,7 +673,8 @@ def main():
         if variants:
             out["variants"] = variants
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg, (preset, F, Hpx, Wpx, n_text, Kgen, C, groups), fulldepth=args.cpu_fulldepth)
+            # the full-depth C = 32 group is MEASURED in this run (after every GPU measurement: the host is idle then)
+            out["cpu_baseline"] = cpu_baseline(cfg, (preset, F, Hpx, Wpx, n_text, Kgen, C, groups), fulldepth=not args.no_cpu_fulldepth)
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist_on:

@@ -43,9 +43,12 @@ int spacer_version(void);
  * K must be a multiple of 64 (pad the contraction dim with zeros); M, N arbitrary.
  * out_f32 selects the dtype of C and residual (0 = bf16, 1 = fp32).  residual == C gives C += ...
  * ---------------------------------------------------------------------------------------------- */
-/* Launch-plan switches.  NULL (or a zeroed struct) = the defaults the benchmark runs with.  The Python layer fills one from the
+/* Launch-plan switches.  NULL (or a struct whose switches are all zero, with struct_bytes set) = the defaults the benchmark runs with.  The Python layer fills one from the
  * SPACER_* environment variables ONCE at import (spacer_amd/kernels.py:PLAN); the library itself never calls getenv. */
 typedef struct spacer_plan {
+    int struct_bytes;      /* = sizeof(spacer_plan) as the CALLER declares it.  The library reads a plan only when this equals its own
+                            * sizeof(spacer_plan) and fails with SPACER_EINVAL otherwise: a binding that is a field short (round 4: the
+                            * documented ctypes stub) is rejected instead of over-read.  tests/test_abi_layout.py pins the layouts */
     int gemm_tile;         /* 0 = cost model; 128 / 256 = force that tile kernel (tests run every shape through both) */
     int gemm_no_split;     /* 1 = no split-K tail in the 256-tile GEMM: one fp32 summation order per output (bit-exact comparisons) */
     int skinny_blocks;     /* decode GEMMs: target workgroups per launch; 0 = 2 x cus (one resident round); 1 = ONE K range per
@@ -375,13 +378,30 @@ int spacer_adamw_step(float* master, void* shadow_bf16, float* m, float* v, cons
  * enter KL, loss and metrics) evaluates its forward in this mode and back-propagates through the production kernels on the hi
  * halves (spacer_attn_bwd, spacer_gemm_bf16 dX / dW, spacer_rmsnorm_bwd, ...).  All such outputs are optional (NULL).
  * ---------------------------------------------------------------------------------------------- */
-/* A linear layer on a pair operand in ONE launch: C = (A_hi + A_lo) . B^T (+ bias, residual, alpha as spacer_gemm_bf16_nt; C fp32
- * or bf16) over the K-concatenated operands [A_hi | A_lo] . [B | B]^T on the 256-tile kernel -- the fp32 output is written once
+/* A linear layer on a pair operand in ONE launch: C = (A_hi + A_lo) . B^T (+ bias, residual, alpha as spacer_gemm_bf16_nt; C fp32,
+ * out_f32 = 1) over the K-concatenated operands [A_hi | A_lo] . [B | B]^T on the 256-tile kernel -- the fp32 output is written once
  * instead of written, re-read and re-written by a second accumulate pass.  A_hi / A_lo share lda.  Only problems the 256 tile takes
  * (spacer_gemm_pair_fused(M, N, K, have_workspace, plan) != 0); otherwise SPACER_EINVAL and the caller runs the two passes. */
 int spacer_gemm_pair_fused(int M, int N, int K, int have_workspace, const spacer_plan* plan);
 int spacer_gemm_bf16_pair_nt(const void* A_hi, const void* A_lo, long lda, const void* B, long ldb, void* C, long ldc, int M, int N,
                              int K, const spacer_gemm_epilogue* epi, spacer_stream_t stream);
+/* Round 5: the pair GEMM with the PRODUCER that used to follow it in the epilogue -- the fp32 [M, N] tensor between them (1.67 GB per
+ * decoder layer for gate|up at two cfg3 prompt groups, written by the GEMM and re-read by spacer_swiglu_f32_pair) is never written:
+ *   SPACER_PAIR_SWIGLU  W = [gate rows | up rows] ([N = 2 inter, K]); (y_hi, y_lo) [M, inter] = pair(silu(g) * u) of
+ *                       [g | u] = (A_hi + A_lo) . W^T + bias; tape_bf16 [M, 2 inter] (or NULL) = bf16(g | u)        HF Qwen2MLP.forward
+ *   SPACER_PAIR_ROPE    (y_hi, y_lo) [M, N] = pair(x) with rotate_half rotary (fp32 tables rope_cos / rope_sin [M, 128]) applied to the
+ *                       first rope_heads heads of x = (A_hi + A_lo) . W^T + bias; head_dim must be 128                HF apply_multimodal_rotary_pos_emb
+ *   SPACER_PAIR_ACT     (y_hi, y_lo) [M, N] = pair(act(x)); tape_bf16 [M, N] (or NULL) = bf16(x)                       ViT fc1 + quick-GELU, merger GELU
+ * Same sums as spacer_gemm_bf16_pair_nt and the same producer arithmetic as spacer_swiglu_f32_pair / spacer_rope_f32_pair /
+ * spacer_act_f32_pair applied to them.  256-tile problems only: spacer_gemm_pair_epilogue_fused(kind, M, N, K, head_dim,
+ * have_workspace, plan) != 0, else SPACER_EINVAL (callers then run the pair GEMM and the producer kernel).  workspace: the split-K scratch of
+ * the spacer_gemm_epilogue struct, passed directly; may be NULL. */
+enum spacer_pair_epilogue { SPACER_PAIR_SWIGLU = 2, SPACER_PAIR_ROPE = 3, SPACER_PAIR_ACT = 4 };
+int spacer_gemm_pair_epilogue_fused(int kind, int M, int N, int K, int head_dim, int have_workspace, const spacer_plan* plan);
+int spacer_gemm_bf16_pair_epilogue(int kind, const void* A_hi, const void* A_lo, long lda, const void* W, long ldb, const void* bias,
+                                   void* y_hi, void* y_lo, long ld_y, void* tape_bf16, long ld_tape, const float* rope_cos,
+                                   const float* rope_sin, int rope_heads, int head_dim, int act, int M, int N, int K, void* workspace,
+                                   long workspace_bytes, const spacer_plan* plan, spacer_stream_t stream);
 /* y_hi / y_lo [rows, ldy] bf16 <- x fp32 [rows, ldx] (cols, ldx, ldy multiples of 4) */
 int spacer_split_f32_pair(const float* x, long ldx, void* y_hi, void* y_lo, long ldy, int rows, int cols, spacer_stream_t stream);
 /* y = act(x) in fp32 (enum spacer_act), as a pair; pre_bf16 [rows, ldy] (or NULL) receives bf16(x), the point spacer_act_bwd

@@ -49,7 +49,11 @@ for (a, name), (b, _) in zip(starts, starts[1:]):
     inner = kloops[0] if kloops else (0, 0)
     n_in = sum(inner[0] < x < inner[1] for x in scr)
     flags = re.search(r"ILb(\d)ELb(\d)ELb(\d)ELb(\d)E", name)
-    tag = "<" + ", ".join("true" if f == "1" else "false" for f in flags.groups()) + ">"
+    if flags:
+        tag = "<" + ", ".join("true" if f == "1" else "false" for f in flags.groups()) + ">"
+    else:                                             # gemm_bf16_pair_256h_kernel<MODE> (round 5)
+        mode = re.search(r"ILi(\d)E", name)
+        tag = "pair<" + {"1": "PAIR_PLAIN", "2": "PAIR_SWIGLU", "3": "PAIR_ROPE", "4": "PAIR_ACT"}.get(mode.group(1) if mode else "", "?") + ">"
     u = usage.get(name, {})
     print(f"| `{tag}` | {u.get('VGPRs', '?')} | {u.get('ScratchSize [bytes/lane]', '?')} | {len(scr)} | {n_in} | {len(scr) - n_in} |")
 print("\nReading: every spill / reload of every instantiation sits OUTSIDE the K loop (0 scratch operations between the loop's 128 MFMAs): the\n"

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspacer_hip.so")
 
 SPACER_ACT_NONE, SPACER_ACT_QUICK_GELU, SPACER_ACT_GELU_ERF, SPACER_ACT_SILU = 0, 1, 2, 3
+SPACER_PAIR_SWIGLU, SPACER_PAIR_ROPE, SPACER_PAIR_ACT = 2, 3, 4          # enum spacer_pair_epilogue
 
 
 class SpacerError(RuntimeError):
@@ -21,8 +22,12 @@ class SpacerError(RuntimeError):
 
 class Plan(C.Structure):
     """include/spacer_hip.h: spacer_plan -- launch-plan switches handed to the library explicitly (it reads no environment)."""
-    _fields_ = [("gemm_tile", C.c_int), ("gemm_no_split", C.c_int), ("skinny_blocks", C.c_int), ("skinny_no_balance", C.c_int),
-                ("cus", C.c_int), ("skinny_skew", C.c_int)]
+    _fields_ = [("struct_bytes", C.c_int), ("gemm_tile", C.c_int), ("gemm_no_split", C.c_int), ("skinny_blocks", C.c_int),
+                ("skinny_no_balance", C.c_int), ("cus", C.c_int), ("skinny_skew", C.c_int)]
+
+    def __init__(self, **switches):
+        super().__init__(**switches)
+        self.struct_bytes = C.sizeof(Plan)      # the library rejects a plan of another size (a stale, shorter binding)
 
 
 class GemmEpilogue(C.Structure):
@@ -42,6 +47,7 @@ SIGNATURES = {
     "spacer_gemm_bf16_nt": [_p, _l, _p, _l, _p, _l, _i, _i, _i, C.POINTER(GemmEpilogue), _p],
     "spacer_gemm_bf16": [_p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _i, C.POINTER(GemmEpilogue), _p],
     "spacer_gemm_bf16_pair_nt": [_p, _p, _l, _p, _l, _p, _l, _i, _i, _i, C.POINTER(GemmEpilogue), _p],
+    "spacer_gemm_bf16_pair_epilogue": [_i, _p, _p, _l, _p, _l, _p, _p, _p, _l, _p, _l, _p, _p, _i, _i, _i, _i, _i, _i, _p, _l, C.POINTER(Plan), _p],
     "spacer_gemm_skinny_bf16": [_p, _l, _p, _l, _p, _l, _i, _i, _i, C.POINTER(GemmEpilogue), _p],
     "spacer_pack_weight_frag": [_p, _l, _p, _i, _i, _p],
     "spacer_gemm_skinny_packed_bf16": [_p, _l, _p, _p, _l, _i, _i, _i, C.POINTER(Plan), _p],
@@ -103,7 +109,7 @@ SIGNATURES = {
     "spacer_embed_fwd_f32video": [_p, _p, _p, _p, _p, _i, _i, _p],
     "spacer_attn_fwd_pair": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _l, _l, _l, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p],
 }
-OTHER_SYMBOLS = ["spacer_last_error", "spacer_version", "spacer_sample_workspace_bytes", "spacer_attn_decode_workspace_bytes", "spacer_gemm_tile", "spacer_gemm_workspace_bytes", "spacer_gemm_swiglu_fused", "spacer_gemm_pair_fused", "spacer_resize_workspace_bytes", "spacer_gemm_skinny_swiglu_workspace_bytes"]
+OTHER_SYMBOLS = ["spacer_last_error", "spacer_version", "spacer_sample_workspace_bytes", "spacer_attn_decode_workspace_bytes", "spacer_gemm_tile", "spacer_gemm_workspace_bytes", "spacer_gemm_swiglu_fused", "spacer_gemm_pair_fused", "spacer_gemm_pair_epilogue_fused", "spacer_resize_workspace_bytes", "spacer_gemm_skinny_swiglu_workspace_bytes"]
 
 _lib = None
 
@@ -135,6 +141,8 @@ def load() -> C.CDLL:
     lib.spacer_gemm_swiglu_fused.restype = _i
     lib.spacer_gemm_pair_fused.argtypes = [_i, _i, _i, _i, C.POINTER(Plan)]
     lib.spacer_gemm_pair_fused.restype = _i
+    lib.spacer_gemm_pair_epilogue_fused.argtypes = [_i, _i, _i, _i, _i, _i, C.POINTER(Plan)]
+    lib.spacer_gemm_pair_epilogue_fused.restype = _i
     lib.spacer_gemm_workspace_bytes.argtypes = []
     lib.spacer_gemm_workspace_bytes.restype = C.c_long
     lib.spacer_gemm_skinny_swiglu_workspace_bytes.argtypes = []

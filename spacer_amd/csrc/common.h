@@ -30,6 +30,12 @@ void spacer_set_error(const char* fmt, ...);
         }                                                                      \
     } while (0)
 
+// a caller's launch plan is read only when it declares the struct size this library was compiled with (include/spacer_hip.h)
+static inline bool plan_size_ok(const spacer_plan* p) { return !p || p->struct_bytes == (int)sizeof(spacer_plan); }
+#define SP_REQUIRE_PLAN(p)                                                                                              \
+    SP_REQUIRE(plan_size_ok(p), SPACER_EINVAL, "spacer_plan: struct_bytes = %d but this library's spacer_plan has %d bytes (stale binding?)", \
+               (p) ? (p)->struct_bytes : 0, (int)sizeof(spacer_plan))
+
 // ---- bf16 <-> f32 ----
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 // f32 -> bf16 is the gfx950 hardware conversion (v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN), one

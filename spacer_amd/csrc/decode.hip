@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __res
         const float al = (float)(-slices_per_range - 1) * (1.f / 16.f);
         auto st = [&](int q) { const float c = (float)q + (R > 1 ? al * (float)q * (float)(q - R) / (float)(R - 1) : 0.f);
                                return (int)((float)total_slices * c / (float)R + 0.5f); };
-        s_begin = st(r); s_end = st(r + 1);
+        s_begin = max(0, min(total_slices, st(r))); s_end = max(0, min(total_slices, st(r + 1)));     // (alpha <= 1 is enforced by the launchers)
     }
     bool split_block = false;
     if (SWIGLU && split_groups > 0) {
@@ -807,13 +807,15 @@ static inline int skinny_target_blocks(const spacer_plan* plan) {
 // ranges (down: 8-9 slices) measured slower with a skew and keep equal ranges.  plan->skinny_skew < 0 forces equal ranges.
 static inline int skinny_skew(const spacer_plan* plan, int col_groups, int ranges, int slices, int target_blocks) {
     if (ranges <= 1) return 0;
-    if (plan && plan->skinny_skew != 0) return plan->skinny_skew > 0 ? plan->skinny_skew : 0;
+    if (plan && plan->skinny_skew != 0) return plan->skinny_skew > 0 ? plan->skinny_skew : 0;       // range-checked by the launchers
     return (col_groups * ranges >= target_blocks - target_blocks / 16 && cdiv(slices, ranges) <= 2 && slices >= 2 * ranges) ? 7 : 0;
 }
 
 static int launch_skinny(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
                          const spacer_gemm_epilogue* epi, bool packed, const spacer_plan* plan, hipStream_t s, bool overwrite = false) {
     SP_REQUIRE(A && B && C, SPACER_EINVAL, "gemm_skinny: null operand");
+    SP_REQUIRE_PLAN(plan);
+    SP_REQUIRE(!plan || plan->skinny_skew <= 17, SPACER_EINVAL, "gemm_skinny: plan.skinny_skew = %d out of range (<= 17: alpha = (skew - 1) / 16 <= 1 keeps the K ranges monotone)", plan->skinny_skew);
     SP_REQUIRE(M > 0 && M <= (packed ? 128 : 64), SPACER_EINVAL, "gemm_skinny: M=%d must be in 1..%d", M, packed ? 128 : 64);
     SP_REQUIRE(K % 256 == 0, SPACER_EINVAL, "gemm_skinny: K=%d must be a multiple of 256", K);
     const int MTv = M > 64 ? 2 : 1, KSv = 256 / MTv;          // 65..128 rows: two 64-row blocks per weight pass, 128-wide K slices
@@ -863,6 +865,8 @@ extern "C" int spacer_gemm_skinny_packed_bf16(const void* A, long lda, const voi
 extern "C" int spacer_gemm_skinny_packed_normed(const float* X32, long ldx, const void* Bpacked, float* C, long ldc, float* rowss,
                                                 int M, int N, int K, const spacer_plan* plan, spacer_stream_t stream) {
     SP_REQUIRE(X32 && Bpacked && C && rowss, SPACER_EINVAL, "gemm_skinny_normed: null operand");
+    SP_REQUIRE_PLAN(plan);
+    SP_REQUIRE(!plan || plan->skinny_skew <= 17, SPACER_EINVAL, "gemm_skinny_normed: plan.skinny_skew = %d out of range (<= 17)", plan->skinny_skew);
     SP_REQUIRE(M > 0 && M <= 64 && K % 256 == 0 && N % 16 == 0 && ldx % 4 == 0, SPACER_EINVAL,
                "gemm_skinny_normed: need 0 < M <= 64, K %% 256 == 0, N %% 16 == 0, ldx %% 4 == 0 (M=%d N=%d K=%d)", M, N, K);
     const int col_groups = cdiv(N, 64), slices = K / 256;
@@ -911,6 +915,7 @@ extern "C" long spacer_gemm_skinny_swiglu_workspace_bytes(void) { return (long)S
 static int launch_skinny_swiglu(const void* A, long lda, const void* Bpacked, void* Y, long ldy, int M, int inter, int K, void* ws,
                                 long ws_bytes, const spacer_plan* plan, hipStream_t stream) {
     SP_REQUIRE(A && Bpacked && Y, SPACER_EINVAL, "gemm_skinny_swiglu: null operand");
+    SP_REQUIRE_PLAN(plan);
     SP_REQUIRE(M > 0 && M <= 128, SPACER_EINVAL, "gemm_skinny_swiglu: M=%d must be in 1..128", M);
     SP_REQUIRE(K % 256 == 0 && inter % 32 == 0 && lda % 8 == 0, SPACER_EINVAL,
                "gemm_skinny_swiglu: need K %% 256 == 0, inter %% 32 == 0, lda %% 8 == 0");

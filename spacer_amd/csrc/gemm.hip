@@ -55,6 +55,11 @@ struct GemmArgs {
     // kt < kt_wrap come from A, the others from A2 at tile kt - kt_wrap, and B's K tile index wraps at kt_wrap; K = 2 x the
     // contraction length of one pass.  kt_wrap = INT_MAX (never reached) for every other launch.
     const bf16_t* A2; int kt_wrap;
+    // pair forms with a fused producer epilogue (gemm_halftile.h: PAIR_SWIGLU / PAIR_ROPE / PAIR_ACT): C = hi, C2 = lo (bf16, same ld);
+    // C3 = bf16 tape output (gate | up, or the pre-activation) or null; rotary tables fp32 [M, 128], heads below rope_heads are rotated
+    int pair_mode;
+    void* C3; long ldc3;
+    const float* rope_cos; const float* rope_sin; int rope_heads;
 };
 
 // workgroups of a persistent 256-tile launch: one per CU
@@ -339,6 +344,7 @@ static int choose_tile(int M, int N, int K, bool have_ws, const spacer_plan* pla
 extern "C" long spacer_gemm_workspace_bytes(void) { return WS_MAX_SLABS * WS_SLAB_BYTES + WS_TAIL_BYTES; }
 
 extern "C" int spacer_gemm_tile(int M, int N, int K, int have_workspace, const spacer_plan* plan) {
+    SP_REQUIRE_PLAN(plan);
     return choose_tile(M, N, K, have_workspace != 0, plan);
 }
 
@@ -357,6 +363,7 @@ static int launch_gemm(const void* A, long lda, const void* B, long ldb, void* C
     g.swiglu_inter = 0; g.C2 = nullptr; g.ldc2 = 0;
     g.k_tail_tile = -1; g.A_tail = nullptr; g.B_tail = nullptr;
     g.A2 = (const bf16_t*)A2; g.kt_wrap = A2 ? K / BK : 0x7fffffff;
+    g.pair_mode = A2 ? PAIR_PLAIN : PAIR_NONE; g.C3 = nullptr; g.ldc3 = 0; g.rope_cos = g.rope_sin = nullptr; g.rope_heads = 0;
     if (A2) K *= 2;                                   // one launch walks the K tiles of both passes
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
@@ -373,7 +380,9 @@ static int launch_gemm(const void* A, long lda, const void* B, long ldb, void* C
     SP_REQUIRE(!(epi && epi->workspace) || ((uintptr_t)epi->workspace % 16) == 0, SPACER_EINVAL, "gemm: workspace misaligned");
     // the contraction-major operand forms exist on the 256 tile only
     const spacer_plan* plan = epi ? epi->plan : nullptr;
+    SP_REQUIRE_PLAN(plan);
     const bool big = tb || choose_tile(M, N, K, have_ws, plan) == 256;
+    SP_REQUIRE(!A2 || g.out_f32, SPACER_EINVAL, "gemm_pair: the output is fp32 (out_f32 = 1)");
     SP_REQUIRE(!A2 || big, SPACER_EINVAL, "gemm_pair: M=%d N=%d K=%d does not run on the 256 tile; use two accumulate passes", M, N, K / 2);
     hipStream_t s = (hipStream_t)stream;
     if (ta && K % BK != 0) {
@@ -395,7 +404,8 @@ static int launch_gemm(const void* A, long lda, const void* B, long ldb, void* C
                               + hipFuncSetAttribute((const void*)gemm_bf16_nt_256h_kernel<true, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)
                               + hipFuncSetAttribute((const void*)gemm_bf16_nt_256h_kernel<true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)
                               + hipFuncSetAttribute((const void*)gemm_bf16_nt_256h_kernel<true, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)
-                              + hipFuncSetAttribute((const void*)gemm_bf16_nt_256h_kernel<true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+                              + hipFuncSetAttribute((const void*)gemm_bf16_nt_256h_kernel<true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)
+                              + hipFuncSetAttribute((const void*)gemm_bf16_pair_256h_kernel<PAIR_PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         (void)once;
         g.tiles_m = cdiv(M, 256); g.tiles_n = cdiv(N, 256);
         const long tiles = (long)g.tiles_m * g.tiles_n;
@@ -413,6 +423,7 @@ static int launch_gemm(const void* A, long lda, const void* B, long ldb, void* C
         } else {
             if (ta) hipLaunchKernelGGL((gemm_bf16_nt_256h_kernel<true, true, true, false>), grid, dim3(512), LDS, s, g);
             else if (tb) hipLaunchKernelGGL((gemm_bf16_nt_256h_kernel<true, false, true, false>), grid, dim3(512), LDS, s, g);
+            else if (A2) hipLaunchKernelGGL((gemm_bf16_pair_256h_kernel<PAIR_PLAIN>), grid, dim3(512), LDS, s, g);
             else hipLaunchKernelGGL((gemm_bf16_nt_256h_kernel<true, false, false, false>), grid, dim3(512), LDS, s, g);
         }
         if (g.splits > 1) hipLaunchKernelGGL(gemm_tail_reduce_kernel, dim3((unsigned)(tail_tiles * 32)), dim3(512), 0, s, g);
@@ -434,6 +445,7 @@ extern "C" int spacer_gemm_bf16_nt(const void* A, long lda, const void* B, long 
 // [B | B] (the weights are exactly bf16, so only the activation is a pair) instead of two accumulate passes: the fp32 output is
 // written once (no read-modify-write pass) and the launch's fixed costs are paid once.
 extern "C" int spacer_gemm_pair_fused(int M, int N, int K, int have_workspace, const spacer_plan* plan) {
+    SP_REQUIRE_PLAN(plan);
     return K % BK == 0 && choose_tile(M, N, 2 * K, have_workspace != 0, plan) == 256;
 }
 
@@ -441,6 +453,76 @@ extern "C" int spacer_gemm_bf16_pair_nt(const void* A_hi, const void* A_lo, long
                                         int N, int K, const spacer_gemm_epilogue* epi, spacer_stream_t stream) {
     SP_REQUIRE(A_lo, SPACER_EINVAL, "gemm_pair: null A_lo");
     return launch_gemm(A_hi, lda, B, ldb, C, ldc, M, N, K, false, false, epi, stream, A_lo);
+}
+
+// ---- pair GEMMs whose epilogue is the producer that used to follow them (round 5).  One launch:
+//   kind SPACER_PAIR_SWIGLU: (y_hi, y_lo)[M, inter] = pair(silu(g) * u), [g | u] = (A_hi + A_lo) . W^T + bias, W = [gate rows | up rows];
+//                            tape = bf16(g | u) [M, 2 inter] or NULL
+//   kind SPACER_PAIR_ROPE:   (y_hi, y_lo)[M, N] = pair(rotary((A_hi + A_lo) . W^T + bias)) on the first rope_heads heads of 128 dims
+//   kind SPACER_PAIR_ACT:    (y_hi, y_lo)[M, N] = pair(act((A_hi + A_lo) . W^T + bias)); tape = bf16(pre-activation) or NULL
+// Same sums as spacer_gemm_bf16_pair_nt (same K walk), same producer arithmetic as spacer_swiglu_f32_pair / spacer_rope_f32_pair /
+// spacer_act_f32_pair on its fp32 output -- which is never written.
+static bool pair_epilogue_ok(int kind, int M, int N, int K, int head_dim, bool have_ws, const spacer_plan* plan) {
+    if (K % BK != 0 || N % 4 != 0) return false;
+    if (kind == SPACER_PAIR_SWIGLU && (N % 256 != 0)) return false;            // N = 2 * inter, inter % 128 == 0
+    if (kind == SPACER_PAIR_ROPE && (head_dim != 128 || N % 128 != 0)) return false;
+    if (kind < SPACER_PAIR_SWIGLU || kind > SPACER_PAIR_ACT) return false;
+    return choose_tile(M, N, 2 * K, have_ws, plan) == 256;
+}
+
+extern "C" int spacer_gemm_pair_epilogue_fused(int kind, int M, int N, int K, int head_dim, int have_workspace, const spacer_plan* plan) {
+    SP_REQUIRE_PLAN(plan);
+    return pair_epilogue_ok(kind, M, N, K, head_dim, have_workspace != 0, plan) ? 1 : 0;
+}
+
+extern "C" int spacer_gemm_bf16_pair_epilogue(int kind, const void* A_hi, const void* A_lo, long lda, const void* W, long ldb,
+                                              const void* bias, void* y_hi, void* y_lo, long ld_y, void* tape_bf16, long ld_tape,
+                                              const float* rope_cos, const float* rope_sin, int rope_heads, int head_dim, int act,
+                                              int M, int N, int K, void* workspace, long workspace_bytes, const spacer_plan* plan,
+                                              spacer_stream_t stream) {
+    SP_REQUIRE(A_hi && A_lo && W && y_hi && y_lo, SPACER_EINVAL, "gemm_pair_epilogue: null operand");
+    SP_REQUIRE_PLAN(plan);
+    SP_REQUIRE(M > 0 && N > 0 && K > 0, SPACER_EINVAL, "gemm_pair_epilogue: empty shape M=%d N=%d K=%d", M, N, K);
+    const bool have_ws = workspace && workspace_bytes >= spacer_gemm_workspace_bytes();
+    SP_REQUIRE(pair_epilogue_ok(kind, M, N, K, head_dim, have_ws, plan), SPACER_EINVAL,
+               "gemm_pair_epilogue: kind %d, M=%d N=%d K=%d head_dim=%d does not run fused (spacer_gemm_pair_epilogue_fused == 0): use "
+               "spacer_gemm_bf16_pair_nt + the producer kernel", kind, M, N, K, head_dim);
+    SP_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ld_y % 4 == 0 && (!tape_bf16 || ld_tape % 4 == 0), SPACER_EINVAL, "gemm_pair_epilogue: leading dimensions");
+    SP_REQUIRE(((uintptr_t)A_hi % 16) == 0 && ((uintptr_t)A_lo % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)y_hi % 8) == 0
+               && ((uintptr_t)y_lo % 8) == 0 && ((uintptr_t)tape_bf16 % 8) == 0 && ((uintptr_t)workspace % 16) == 0, SPACER_EINVAL,
+               "gemm_pair_epilogue: misaligned operand");
+    SP_REQUIRE(kind != SPACER_PAIR_ROPE || (rope_cos && rope_sin && rope_heads >= 0 && rope_heads * 128 <= N && ((uintptr_t)rope_cos % 16) == 0
+               && ((uintptr_t)rope_sin % 16) == 0), SPACER_EINVAL, "gemm_pair_epilogue: rotary tables / rope_heads=%d", rope_heads);
+    SP_REQUIRE(kind != SPACER_PAIR_ACT || (act >= SPACER_ACT_NONE && act <= SPACER_ACT_SILU), SPACER_EINVAL, "gemm_pair_epilogue: unknown activation %d", act);
+    GemmArgs g;
+    g.A = (const bf16_t*)A_hi; g.A2 = (const bf16_t*)A_lo; g.B = (const bf16_t*)W; g.C = y_hi; g.C2 = y_lo; g.C3 = tape_bf16;
+    g.lda = lda; g.ldb = ldb; g.ldc = ld_y; g.ldc2 = ld_y; g.ldc3 = ld_tape;
+    g.M = M; g.N = N; g.K = 2 * K; g.kt_wrap = K / BK;
+    g.bias = (const bf16_t*)bias; g.resid = nullptr; g.ldr = 0; g.out_f32 = 1; g.act = kind == SPACER_PAIR_ACT ? act : SPACER_ACT_NONE; g.alpha = 1.f;
+    g.swiglu_inter = kind == SPACER_PAIR_SWIGLU ? N / 2 : 0;
+    g.k_tail_tile = -1; g.A_tail = nullptr; g.B_tail = nullptr;
+    g.pair_mode = kind == SPACER_PAIR_SWIGLU ? PAIR_SWIGLU : kind == SPACER_PAIR_ROPE ? PAIR_ROPE : PAIR_ACT;
+    g.rope_cos = rope_cos; g.rope_sin = rope_sin; g.rope_heads = rope_heads;
+    g.tiles_m = cdiv(M, 256); g.tiles_n = N / 256 + (kind != SPACER_PAIR_SWIGLU && N % 256 ? 1 : 0);
+    const long tiles = (long)g.tiles_m * g.tiles_n;
+    tail_plan(tiles, g.K / BK, have_ws && !(plan && plan->gemm_no_split), &g.full_tiles, &g.splits);
+    g.slabs = have_ws ? (float*)workspace : nullptr;
+    const long tail_tiles = tiles - g.full_tiles;
+    g.total_blocks = (int)(g.full_tiles + tail_tiles * g.splits);
+    g.stage_bf16 = 0;
+    constexpr int LDS = 8 * 128 * BK * 2;
+    static const int once = hipFuncSetAttribute((const void*)gemm_bf16_pair_256h_kernel<PAIR_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)
+                          + hipFuncSetAttribute((const void*)gemm_bf16_pair_256h_kernel<PAIR_ROPE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)
+                          + hipFuncSetAttribute((const void*)gemm_bf16_pair_256h_kernel<PAIR_ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)once;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)g.total_blocks);
+    if (kind == SPACER_PAIR_SWIGLU) hipLaunchKernelGGL((gemm_bf16_pair_256h_kernel<PAIR_SWIGLU>), grid, dim3(512), LDS, s, g);
+    else if (kind == SPACER_PAIR_ROPE) hipLaunchKernelGGL((gemm_bf16_pair_256h_kernel<PAIR_ROPE>), grid, dim3(512), LDS, s, g);
+    else hipLaunchKernelGGL((gemm_bf16_pair_256h_kernel<PAIR_ACT>), grid, dim3(512), LDS, s, g);
+    if (g.splits > 1) hipLaunchKernelGGL(gemm_tail_reduce_kernel, dim3((unsigned)(tail_tiles * 32)), dim3(512), 0, s, g);
+    SP_CHECK_LAUNCH();
+    return SPACER_OK;
 }
 
 extern "C" int spacer_gemm_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
@@ -454,6 +536,7 @@ extern "C" int spacer_gemm_bf16(const void* A, long lda, const void* B, long ldb
 // spacer_gemm_bf16_nt into gu followed by spacer_swiglu_fwd.  Returns SPACER_EINVAL when the problem would not run on the
 // 256 tile (spacer_gemm_swiglu_fused(M, inter, K) == 0): the caller then takes the two-step path.
 extern "C" int spacer_gemm_swiglu_fused(int M, int inter, int K, const spacer_plan* plan) {
+    SP_REQUIRE_PLAN(plan);
     return inter > 0 && inter % 128 == 0 && K % BK == 0 && choose_tile(M, 2 * inter, K, false, plan) == 256;
 }
 
@@ -473,6 +556,7 @@ extern "C" int spacer_gemm_swiglu_bf16(const void* A, long lda, const void* W, l
     g.swiglu_inter = inter; g.C2 = gu; g.ldc2 = ld_gu;
     g.k_tail_tile = -1; g.A_tail = nullptr; g.B_tail = nullptr;
     g.A2 = nullptr; g.kt_wrap = 0x7fffffff;
+    g.pair_mode = PAIR_NONE; g.C3 = nullptr; g.ldc3 = 0; g.rope_cos = g.rope_sin = nullptr; g.rope_heads = 0;
     g.tiles_m = cdiv(M, 256); g.tiles_n = inter / 128;
     g.full_tiles = g.tiles_m * g.tiles_n; g.splits = 1; g.slabs = nullptr;      // no K-split tail: the reduce kernel has no SwiGLU form
     g.total_blocks = g.full_tiles; g.stage_bf16 = 1;

@@ -74,8 +74,37 @@ __device__ __forceinline__ void xpose4_rows(uint32_t (&x)[4]) {
 }
 
 // STG16: bf16 staging epilogue + early prologue (bf16 output without a residual, SwiGLU); else the fp32 staging of round 1
-template <bool BALANCED, bool TA = false, bool TB = false, bool STG16 = false>
-__global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
+// PAIR (round 5; NT operands, fp32 staging only): the K-concatenated pair form of the precise mode as its OWN instantiations, so that
+// the scalar selects of the pair walk (kt_wrap / A2) are compiled out of every other launch.  Modes:
+//     PAIR_PLAIN   C fp32 = [A | A2] . [B | B]^T (+ bias, + residual)                      o / down / proj / fc2 / lm_head chunks
+//     PAIR_SWIGLU  (hi, lo) bf16 pair of silu(gate) * up straight from the fp32 staging rows (B rows mapped as in the bf16 SwiGLU
+//                  form: tile columns 0..127 = gate, 128..255 = up of the same 128 outputs); C3 = bf16(gate | up) for the tape
+//     PAIR_ROPE    (hi, lo) pair of the rotary-embedded q | k | v row (head_dim 128: a 256-column tile = two whole heads, the partner
+//                  of column d is d +- 64 in the same staged row); heads >= rope_heads (v) are split as they are
+//     PAIR_ACT     (hi, lo) pair of act(x) (+ C3 = bf16(x), what act_bwd differentiates at)
+// The fp32 [T, N] tensor that the unfused path writes and a separate producer kernel re-reads (1.67 GB per layer for gate|up at two
+// cfg3 groups) never exists.
+enum { PAIR_NONE = 0, PAIR_PLAIN = 1, PAIR_SWIGLU = 2, PAIR_ROPE = 3, PAIR_ACT = 4 };
+
+// precise-mode scalar helpers of the pair epilogues (the same expressions as csrc/precise.hip's producer kernels)
+__device__ __forceinline__ float pair_sigm(float v) { return 1.f / (1.f + expf(-v)); }
+__device__ __forceinline__ float pair_act(float v, int act) {
+    if (act == SPACER_ACT_QUICK_GELU) return v * pair_sigm(1.702f * v);
+    if (act == SPACER_ACT_GELU_ERF) return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+    if (act == SPACER_ACT_SILU) return v * pair_sigm(v);
+    return v;
+}
+// 4 fp32 values -> 4 bf16 hi + 4 bf16 lo (lo = bf16(x - hi); x - hi is exact in fp32), 8-byte stores
+__device__ __forceinline__ void pair_store4(bf16_t* __restrict__ yh, bf16_t* __restrict__ yl, long idx, const float v[4]) {
+    const uint32_t h0 = pack_bf2(v[0], v[1]), h1 = pack_bf2(v[2], v[3]);
+    const uint32_t l0 = pack_bf2(v[0] - bf_lo(h0), v[1] - bf_hi(h0)), l1 = pack_bf2(v[2] - bf_lo(h1), v[3] - bf_hi(h1));
+    *(uint2*)(yh + idx) = make_uint2(h0, h1);
+    *(uint2*)(yl + idx) = make_uint2(l0, l1);
+}
+
+template <bool BALANCED, bool TA, bool TB, bool STG16, int PAIR>
+__device__ __forceinline__ void gemm_256h_body(const GemmArgs g) {
+    static_assert(PAIR == PAIR_NONE || (!TA && !TB && !STG16), "the pair forms are NT launches with the fp32 staging epilogue");
     constexpr int BM = 256, BN = 256;
     constexpr int HALF = 128 * BK * 2;                 // one half-tile image
     enum { A_LO = 0, A_HI = 1, B_LO = 2, B_HI = 3 };
@@ -145,10 +174,11 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
         const int kt = kt0 + (t < nt ? t : nt - 1);     // global K tile (wave-uniform)
         char* dst = smem + (par * 4 + which) * HALF + wave * 2048;
         const bf16_t* base;                             // scalar base of this K tile
-        // (pair form: K tiles kt >= kt_wrap come from A2 / wrap around in B -- scalar selects; kt_wrap is never reached otherwise)
+        // (pair forms only: K tiles kt >= kt_wrap come from A2 / wrap around in B -- two scalar selects, compiled out of every other form)
         if (which < 2) base = TA ? (kt == g.k_tail_tile ? g.A_tail : g.A + (long)kt * BK * g.lda)
-                                 : (kt < g.kt_wrap ? g.A + kt * BK : g.A2 + (kt - g.kt_wrap) * BK);
-        else base = TB ? (kt == g.k_tail_tile ? g.B_tail : g.B + (long)kt * BK * g.ldb) : g.B + (kt < g.kt_wrap ? kt : kt - g.kt_wrap) * BK;
+                                 : (PAIR ? (kt < g.kt_wrap ? g.A + kt * BK : g.A2 + (kt - g.kt_wrap) * BK) : g.A + kt * BK);
+        else base = TB ? (kt == g.k_tail_tile ? g.B_tail : g.B + (long)kt * BK * g.ldb)
+                       : g.B + (PAIR ? (kt < g.kt_wrap ? kt : kt - g.kt_wrap) : kt) * BK;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const bf16_t* src = base + ((which < 2) ? offA[which & 1][i] : offB[which & 1][i]);
@@ -460,17 +490,80 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
                 for (int i = 0; i < 8; ++i) {
                     const int row = i * 16 + (lane & 15);
                     f32x4 v = acc[i][j] * e.alpha + (f32x4){b4[0], b4[1], b4[2], b4[3]};
-                    if (e.act != SPACER_ACT_NONE) v = apply_act4(v, e.act);          // out of line: see the bf16 staging form
+                    if (PAIR <= PAIR_PLAIN && e.act != SPACER_ACT_NONE) v = apply_act4(v, e.act);          // out of line: see the bf16 staging form
                     *(float4*)(smem + row * 1024 + (((nl >> 2) ^ (row & 7)) << 4)) = make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
         }
         __syncthreads();
+        if constexpr (PAIR == PAIR_SWIGLU) {
+            // half a wave per staged row: lane l reads gate chunk l and up chunk l + 32 (fp32, never rounded), writes silu(gate) * up
+            // as a (hi, lo) pair and -- for a taped forward -- bf16(gate | up), the point swiglu_bwd differentiates at
+            for (int it = 0; it < 8; ++it) {
+                const int row = it * 16 + wave * 2 + (lane >> 5), l = lane & 31;
+                const float4 gv = *(const float4*)(smem + row * 1024 + ((l ^ (row & 7)) << 4));
+                const float4 uv = *(const float4*)(smem + row * 1024 + (((l + 32) ^ (row & 7)) << 4));
+                const int m = cm0 + pass * 128 + row;
+                if (m < e.M) {
+                    const long n = (long)ctn * 128 + l * 4;
+                    const float o[4] = {gv.x * pair_sigm(gv.x) * uv.x, gv.y * pair_sigm(gv.y) * uv.y, gv.z * pair_sigm(gv.z) * uv.z,
+                                        gv.w * pair_sigm(gv.w) * uv.w};
+                    pair_store4((bf16_t*)e.C, (bf16_t*)g.C2, (long)m * e.ldc + n, o);
+                    if (g.C3) {
+                        bf16_t* c3 = (bf16_t*)g.C3 + (long)m * g.ldc3 + n;
+                        *(uint2*)c3 = make_uint2(pack_bf2(gv.x, gv.y), pack_bf2(gv.z, gv.w));
+                        *(uint2*)(c3 + sw) = make_uint2(pack_bf2(uv.x, uv.y), pack_bf2(uv.z, uv.w));
+                    }
+                }
+            }
+        } else if constexpr (PAIR == PAIR_ROPE) {
+            // head_dim 128: the staged row holds two whole heads; lane l of a half wave takes dims 4c .. 4c + 3 of the first half of head
+            // hh and the matching dims of the second half (HF rotate_half convention, fp32 tables [tokens, 128])
+            for (int it = 0; it < 8; ++it) {
+                const int row = it * 16 + wave * 2 + (lane >> 5), l = lane & 31;
+                const int hh = l >> 4, c = l & 15, ch1 = hh * 32 + c, ch2 = ch1 + 16;
+                const float4 a = *(const float4*)(smem + row * 1024 + ((ch1 ^ (row & 7)) << 4));
+                const float4 b = *(const float4*)(smem + row * 1024 + ((ch2 ^ (row & 7)) << 4));
+                const int m = cm0 + pass * 128 + row, n1 = cn0 + ch1 * 4;
+                if (m < e.M && n1 < e.N) {
+                    const float x1[4] = {a.x, a.y, a.z, a.w}, x2[4] = {b.x, b.y, b.z, b.w};
+                    float r1[4], r2[4];
+                    if ((n1 >> 7) < g.rope_heads) {
+                        const float4 c1 = *(const float4*)(g.rope_cos + (long)m * 128 + c * 4), c2 = *(const float4*)(g.rope_cos + (long)m * 128 + 64 + c * 4);
+                        const float4 s1 = *(const float4*)(g.rope_sin + (long)m * 128 + c * 4), s2 = *(const float4*)(g.rope_sin + (long)m * 128 + 64 + c * 4);
+                        const float cc1[4] = {c1.x, c1.y, c1.z, c1.w}, cc2[4] = {c2.x, c2.y, c2.z, c2.w};
+                        const float ss1[4] = {s1.x, s1.y, s1.z, s1.w}, ss2[4] = {s2.x, s2.y, s2.z, s2.w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            r1[q] = x1[q] * cc1[q] - x2[q] * ss1[q];
+                            r2[q] = x2[q] * cc2[q] + x1[q] * ss2[q];
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { r1[q] = x1[q]; r2[q] = x2[q]; }
+                    }
+                    pair_store4((bf16_t*)e.C, (bf16_t*)g.C2, (long)m * e.ldc + n1, r1);
+                    pair_store4((bf16_t*)e.C, (bf16_t*)g.C2, (long)m * e.ldc + n1 + 64, r2);
+                }
+            }
+        } else if constexpr (PAIR == PAIR_ACT) {
+            for (int it = 0; it < 16; ++it) {
+                const int row = it * 8 + wave;                                // one wave = one tile row
+                const float4 v = *(const float4*)(smem + row * 1024 + ((lane ^ (row & 7)) << 4));
+                const int m = cm0 + pass * 128 + row, n = cn0 + lane * 4;
+                if (m < e.M && n < e.N) {
+                    if (g.C3) *(uint2*)((bf16_t*)g.C3 + (long)m * g.ldc3 + n) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+                    const float o[4] = {pair_act(v.x, e.act), pair_act(v.y, e.act), pair_act(v.z, e.act), pair_act(v.w, e.act)};
+                    pair_store4((bf16_t*)e.C, (bf16_t*)g.C2, (long)m * e.ldc + n, o);
+                }
+            }
+        } else {
         for (int it = 0; it < 16; ++it) {
             const int row = it * 8 + wave;                                // one wave = one tile row
             const float4 v = *(const float4*)(smem + row * 1024 + ((lane ^ (row & 7)) << 4));
             const int m = cm0 + pass * 128 + row, n = cn0 + lane * 4;
             if (m < e.M && n < e.N) store_row4(e, m, n, v);
+        }
         }
         if (pass == 0) __syncthreads();
     }
@@ -478,6 +571,17 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
     if (!more) return;
     __syncthreads();                                                         // staging reads done before the next item's DMA lands there
   }
+}
+
+// The kernels rocprof names.  gemm_bf16_nt_256h_kernel<BALANCED, TA, TB, STG16>: every production form (no pair selects compiled in);
+// gemm_bf16_pair_256h_kernel<MODE>: the K-concatenated pair forms of the precise mode (MODE = PAIR_PLAIN .. PAIR_ACT).
+template <bool BALANCED, bool TA = false, bool TB = false, bool STG16 = false>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_nt_256h_kernel(GemmArgs g) {
+    gemm_256h_body<BALANCED, TA, TB, STG16, PAIR_NONE>(g);
+}
+template <int MODE>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_pair_256h_kernel(GemmArgs g) {
+    gemm_256h_body<true, false, false, false, MODE>(g);
 }
 
 // Sums the K-split partial tiles of the tail (written by gemm_bf16_nt_256h_kernel) in split order -- deterministic --
@@ -496,5 +600,54 @@ __global__ __launch_bounds__(512) void gemm_tail_reduce_kernel(GemmArgs g) {
         sum[0] += v.x; sum[1] += v.y; sum[2] += v.z; sum[3] += v.w;
     }
     const EpiArgs e = {g.C, g.bias, g.resid, g.ldc, g.ldr, g.M, g.N, g.out_f32, g.act, g.alpha};
-    store_frag(e, tm * 256 + wr * 128 + i * 16 + (lane & 15), tn * 256 + wc * 64 + j * 16 + (lane >> 4) * 4, sum);
+    const int m = tm * 256 + wr * 128 + i * 16 + (lane & 15), nl = wc * 64 + j * 16 + (lane >> 4) * 4;      // row, column inside the tile
+    if (g.pair_mode <= PAIR_PLAIN) {
+        store_frag(e, m, tn * 256 + nl, sum);
+        return;
+    }
+    // ---- pair epilogues on a tail tile (the same arithmetic as the staged epilogue of gemm_256h_body): the partner value of a
+    // SwiGLU output (gate <-> up: tile column +- 128) or of a rotary pair (d <-> d +- 64) sits in the same lane of another wave
+    const int sw = g.swiglu_inter;
+    float v[4] = {sum[0], sum[1], sum[2], sum[3]};
+    if (g.bias) {
+        const int nb = sw ? (nl < 128 ? 0 : sw - 128) + tn * 128 + nl : tn * 256 + nl;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += (nb + q < g.N) ? bf2f(g.bias[nb + q]) : 0.f;
+    }
+    __shared__ float4 ex[512];
+    ex[tid] = make_float4(v[0], v[1], v[2], v[3]);
+    __syncthreads();
+    bf16_t* yh = (bf16_t*)g.C; bf16_t* yl = (bf16_t*)g.C2;
+    if (g.pair_mode == PAIR_SWIGLU) {
+        const float4 pt = ex[tid ^ 128];
+        if (m >= g.M) return;
+        const long n = (long)tn * 128 + (nl & 127);
+        if (nl < 128) {
+            const float u[4] = {pt.x, pt.y, pt.z, pt.w};
+            float o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = v[q] * pair_sigm(v[q]) * u[q];
+            pair_store4(yh, yl, (long)m * g.ldc + n, o);
+        }
+        if (g.C3) *(uint2*)((bf16_t*)g.C3 + (long)m * g.ldc3 + (nl < 128 ? 0 : sw) + n) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+    } else if (g.pair_mode == PAIR_ROPE) {
+        const float4 pt = ex[tid ^ 64];
+        const int n = tn * 256 + nl;
+        if (m >= g.M || n >= g.N) return;
+        float r[4] = {v[0], v[1], v[2], v[3]};
+        if ((n >> 7) < g.rope_heads) {
+            const int d = nl & 127;
+            const float4 c4 = *(const float4*)(g.rope_cos + (long)m * 128 + d), s4 = *(const float4*)(g.rope_sin + (long)m * 128 + d);
+            const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w}, p[4] = {pt.x, pt.y, pt.z, pt.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r[q] = d < 64 ? v[q] * cc[q] - p[q] * ss[q] : v[q] * cc[q] + p[q] * ss[q];
+        }
+        pair_store4(yh, yl, (long)m * g.ldc + n, r);
+    } else {                                                                 // PAIR_ACT
+        const int n = tn * 256 + nl;
+        if (m >= g.M || n >= g.N) return;
+        if (g.C3) *(uint2*)((bf16_t*)g.C3 + (long)m * g.ldc3 + n) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+        const float o[4] = {pair_act(v[0], g.act), pair_act(v[1], g.act), pair_act(v[2], g.act), pair_act(v[3], g.act)};
+        pair_store4(yh, yl, (long)m * g.ldc + n, o);
+    }
 }

@@ -599,10 +599,69 @@ def gemm_pair(a_hi, a_lo, w, *, bias=None, residual=None, out=None):
         check(lib.spacer_gemm_bf16_pair_nt(_ptr(a_hi), _ptr(a_lo), _rowmajor(a_hi), _ptr(w), _rowmajor(w), _ptr(out), _rowmajor(out),
                                            M, N, Kd, C.byref(epi), _stream()), "gemm_bf16_pair_nt")
         if t0 is not None:
-            PROFILER.end("gemm_bf16_nt_256h_kernel<true, false, false, false>", t0, 4.0 * M * N * Kd, 2.0 * (2 * M * Kd + N * Kd) + 4.0 * M * N)
+            PROFILER.end("gemm_bf16_pair_256h_kernel<1>", t0, 4.0 * M * N * Kd, 2.0 * (2 * M * Kd + N * Kd) + 4.0 * M * N)
         return out
     out = gemm_nt(a_hi, w, bias=bias, residual=residual, out=out, out_dtype=torch.float32)
     return gemm_nt(a_lo, w, residual=out, out=out, out_dtype=torch.float32)
+
+
+PAIR_EPILOGUE_UNFUSED = bool(os.environ.get("SPACER_PAIR_EPILOGUE_UNFUSED"))   # A/B runs: pair GEMM + separate producer kernel (round 4's path)
+
+
+def _pair_epilogue(kind, a_hi, a_lo, w, bias, n_out, *, tape=None, cos=None, sin=None, rope_heads=0, head_dim=0, act=SPACER_ACT_NONE):
+    """One launch of spacer_gemm_bf16_pair_epilogue (the pair GEMM with its producer in the epilogue); None when the problem does not
+    run fused (small shapes on the 128 tile, head_dim != 128, operands with different strides, or the A/B switch)."""
+    M, Kd = a_hi.shape
+    N = w.shape[0]
+    lib = _lib.load()
+    if (PAIR_EPILOGUE_UNFUSED or PAIR_TWOPASS or a_hi.stride(0) != a_lo.stride(0) or tuple(a_lo.shape) != (M, Kd)
+            or not lib.spacer_gemm_pair_epilogue_fused(kind, M, N, Kd, head_dim, 1, _plan())):
+        return None
+    hi, lo = _pair_out(M, n_out, a_hi.device)
+    ws = _gemm_workspace(a_hi.device)
+    t0 = PROFILER.begin()
+    check(lib.spacer_gemm_bf16_pair_epilogue(kind, _ptr(a_hi), _ptr(a_lo), _rowmajor(a_hi), _ptr(w), _rowmajor(w), _ptr(bias), _ptr(hi), _ptr(lo),
+                                             n_out, _ptr(tape), _rowmajor(tape) if tape is not None else 0, _ptr(cos), _ptr(sin), rope_heads,
+                                             head_dim, act, M, N, Kd, ws.data_ptr(), ws.numel() * 4, _plan(), _stream()),
+          "gemm_bf16_pair_epilogue")
+    if t0 is not None:
+        PROFILER.end(f"gemm_bf16_pair_256h_kernel<{kind}>", t0, 4.0 * M * N * Kd, 2.0 * (2 * M * Kd + N * Kd) + 4.0 * M * n_out)
+    return hi, lo
+
+
+def gemm_pair_swiglu(a_hi, a_lo, w_gu, *, bias=None, gu_out=None):
+    """(hi, lo) pair of silu(g) * u, [g | u] = (a_hi + a_lo) @ w_gu^T + bias in fp32 -- ONE launch when the 256 tile takes the shape
+    (SwiGLU + hi/lo split in the pair GEMM's epilogue; the fp32 [rows, 2I] tensor is never written), else gemm_pair + swiglu_pair.
+    ``gu_out`` (bf16 [rows, 2I]) also receives bf16(g | u), the point swiglu_bwd differentiates at."""
+    two_i = w_gu.shape[0]
+    assert gu_out is None or (gu_out.dtype == BF16 and gu_out.stride(1) == 1 and tuple(gu_out.shape) == (a_hi.shape[0], two_i))
+    out = _pair_epilogue(_lib.SPACER_PAIR_SWIGLU, a_hi, a_lo, w_gu, bias, two_i // 2, tape=gu_out) if two_i % 256 == 0 else None
+    if out is not None:
+        return out
+    return swiglu_pair(gemm_pair(a_hi, a_lo, w_gu, bias=bias), gu_out=gu_out)
+
+
+def gemm_pair_rope(a_hi, a_lo, w, cos, sin, rot_heads, heads, head_dim, *, bias=None):
+    """(hi, lo) pair of the rotary-embedded q | k | v rows of (a_hi + a_lo) @ w^T + bias: bias + rotary + split in the pair GEMM's
+    epilogue when head_dim == 128 and the 256 tile takes the shape, else gemm_pair + rope_pair."""
+    assert w.shape[0] == heads * head_dim
+    out = None
+    if head_dim == 128:
+        assert cos.dtype == torch.float32 and tuple(cos.shape) == (a_hi.shape[0], 128) and cos.is_contiguous() and sin.is_contiguous()
+        out = _pair_epilogue(_lib.SPACER_PAIR_ROPE, a_hi, a_lo, w, bias, heads * head_dim, cos=cos, sin=sin, rope_heads=rot_heads, head_dim=128)
+    if out is not None:
+        return out
+    return rope_pair(gemm_pair(a_hi, a_lo, w, bias=bias), cos, sin, rot_heads, heads, head_dim)
+
+
+def gemm_pair_act(a_hi, a_lo, w, act, *, bias=None, pre_out=None):
+    """(hi, lo) pair of act((a_hi + a_lo) @ w^T + bias); ``pre_out`` (bf16) also receives bf16 of the pre-activation (act_bwd's input)."""
+    N = w.shape[0]
+    assert pre_out is None or (pre_out.dtype == BF16 and pre_out.stride(1) == 1 and tuple(pre_out.shape) == (a_hi.shape[0], N))
+    out = _pair_epilogue(_lib.SPACER_PAIR_ACT, a_hi, a_lo, w, bias, N, tape=pre_out, act=act)
+    if out is not None:
+        return out
+    return act_pair(gemm_pair(a_hi, a_lo, w, bias=bias), act, pre_out=pre_out)
 
 
 def split_pair(x32):

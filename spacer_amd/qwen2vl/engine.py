@@ -122,9 +122,14 @@ class Qwen2VLEngine:
         for i in reversed(range(cfg.vit_depth)):
             p = f"vit.{i}."
             t = tape["blocks"][i]
-            if t["a"] is None:                                           # recompute policy: the forward's own two launches
-                t["f1"] = K.gemm_nt(t["h2"], W[p + "fc1_w"], bias=W[p + "fc1_b"])
-                t["a"] = K.act_fwd(t["f1"], K.SPACER_ACT_QUICK_GELU)
+            if t["a"] is None:                                           # recompute policy: the forward's own launches
+                if t.get("h2_lo") is not None:                           # precise tape: the pair launch, bit-identical to the stored policy
+                    t["f1"] = self._empty(Np, W[p + "fc1_w"].shape[0], dtype=BF16)
+                    t["a"] = K.gemm_pair_act(t["h2"], t["h2_lo"], W[p + "fc1_w"], K.SPACER_ACT_QUICK_GELU, bias=W[p + "fc1_b"], pre_out=t["f1"])[0]
+                    t["h2_lo"] = None
+                else:
+                    t["f1"] = K.gemm_nt(t["h2"], W[p + "fc1_w"], bias=W[p + "fc1_b"])
+                    t["a"] = K.act_fwd(t["f1"], K.SPACER_ACT_QUICK_GELU)
             dyb = K.cast_bf16(dx)
             d_a = self._dx(dyb, p + "fc2_w")
             self._dw(G[p + "fc2_w"], dyb, t["a"]); K.bias_grad_(dyb, G[p + "fc2_b"])
@@ -223,7 +228,12 @@ class Qwen2VLEngine:
             p = f"vit.{i}."
             t = tape["blocks"][i]
             if t["a"] is None:                                           # recompute policy
-                t["a"], t["gu"] = K.gemm_swiglu(t["h2"], W[p + "gu_w"], bias=W[p + "gu_b"], keep_gu=True)
+                if t.get("h2_lo") is not None:                           # precise tape: the pair launch, bit-identical to the stored policy
+                    t["gu"] = self._empty(Np, W[p + "gu_w"].shape[0], dtype=BF16)
+                    t["a"] = K.gemm_pair_swiglu(t["h2"], t["h2_lo"], W[p + "gu_w"], bias=W[p + "gu_b"], gu_out=t["gu"])[0]
+                    t["h2_lo"] = None
+                else:
+                    t["a"], t["gu"] = K.gemm_swiglu(t["h2"], W[p + "gu_w"], bias=W[p + "gu_b"], keep_gu=True)
             dyb = K.cast_bf16(dx)
             d_a = self._dx(dyb, p + "down_w")
             self._dw(G[p + "down_w"], dyb, t["a"]); K.bias_grad_(dyb, G[p + "down_b"])
@@ -291,7 +301,12 @@ class Qwen2VLEngine:
             p = f"llm.{i}."
             t = tape[i]
             if t["a"] is None:              # recompute policy: gate|up + SwiGLU again from the saved h2, same launch, same bits
-                t["a"], t["gu"] = K.gemm_swiglu(t["h2"], W[p + "gu_w"], keep_gu=True)
+                if t.get("h2_lo") is not None:      # ... of a PRECISE forward: the pair launch on (hi, lo), whose hi half / bf16 tape it kept
+                    t["gu"] = self._empty(T, W[p + "gu_w"].shape[0], dtype=BF16)
+                    t["a"] = K.gemm_pair_swiglu(t["h2"], t["h2_lo"], W[p + "gu_w"], gu_out=t["gu"])[0]
+                    t["h2_lo"] = None
+                else:
+                    t["a"], t["gu"] = K.gemm_swiglu(t["h2"], W[p + "gu_w"], keep_gu=True)
             dyb = K.cast_bf16(dx)
             d_a = self._dx(dyb, p + "down_w")
             self._dw(G[p + "down_w"], dyb, t["a"])
@@ -349,9 +364,7 @@ class Qwen2VLEngine:
             segs, max_q = (frame_segs, max_frame) if (not v25 or i in cfg.vit_fullatt) else (win_segs, max_win)
             mean1, rstd1 = (None if v25 else stat()), stat()
             h = K.norm_pair(x, W[p + "n1_w"], None if v25 else W[p + "n1_b"], 1e-6, mean=mean1, rstd=rstd1)
-            qkv32 = K.gemm_pair(*h, W[p + "qkv_w"], bias=W[p + "qkv_b"])
-            qh, ql = K.rope_pair(qkv32, cos, sin, 2 * Hh, 3 * Hh, hd)
-            del qkv32
+            qh, ql = K.gemm_pair_rope(*h, W[p + "qkv_w"], cos, sin, 2 * Hh, 3 * Hh, hd, bias=W[p + "qkv_b"])   # (head_dim 80: unfused)
             lse = self._empty(Hh, Np) if taped else None
             o = K.attn_fwd_pair((qh[:, :D], ql[:, :D]), (qh[:, D:2 * D], ql[:, D:2 * D]), (qh[:, 2 * D:], ql[:, 2 * D:]),
                                 segs, max_q, Hh, Hh, hd, False, scale, lse=lse)
@@ -361,32 +374,27 @@ class Qwen2VLEngine:
             mean2, rstd2 = (None if v25 else stat()), stat()
             h2 = K.norm_pair(x_mid, W[p + "n2_w"], None if v25 else W[p + "n2_b"], 1e-6, mean=mean2, rstd=rstd2)
             if v25:
-                gu32 = K.gemm_pair(*h2, W[p + "gu_w"], bias=W[p + "gu_b"])
-                pre = self._empty(*gu32.shape, dtype=BF16) if keep else None
-                a = K.swiglu_pair(gu32, gu_out=pre)
-                del gu32
+                pre = self._empty(Np, W[p + "gu_w"].shape[0], dtype=BF16) if keep else None
+                a = K.gemm_pair_swiglu(*h2, W[p + "gu_w"], bias=W[p + "gu_b"], gu_out=pre)   # SwiGLU + split in the pair GEMM's epilogue
                 x_out = K.gemm_pair(*a, W[p + "down_w"], bias=W[p + "down_b"], residual=x_mid, out=None if taped else x_mid)
                 if taped:
                     blocks.append(dict(x_in=x, rstd1=rstd1, h=h[0], qkv=qh, o=o[0], lse=lse, x_mid=x_mid, rstd2=rstd2, h2=h2[0], gu=pre,
-                                       a=a[0] if keep else None, segs=segs, max_q=max_q))
+                                       a=a[0] if keep else None, segs=segs, max_q=max_q, h2_lo=None if keep else h2[1]))
             else:
-                f32 = K.gemm_pair(*h2, W[p + "fc1_w"], bias=W[p + "fc1_b"])
-                pre = self._empty(*f32.shape, dtype=BF16) if keep else None
-                a = K.act_pair(f32, K.SPACER_ACT_QUICK_GELU, pre_out=pre)
-                del f32
+                pre = self._empty(Np, W[p + "fc1_w"].shape[0], dtype=BF16) if keep else None
+                a = K.gemm_pair_act(*h2, W[p + "fc1_w"], K.SPACER_ACT_QUICK_GELU, bias=W[p + "fc1_b"], pre_out=pre)
                 x_out = K.gemm_pair(*a, W[p + "fc2_w"], bias=W[p + "fc2_b"], residual=x_mid, out=None if taped else x_mid)
                 if taped:
                     blocks.append(dict(x_in=x, mean1=mean1, rstd1=rstd1, h=h[0], qkv=qh, o=o[0], lse=lse, x_mid=x_mid, mean2=mean2,
-                                       rstd2=rstd2, h2=h2[0], f1=pre, a=a[0] if keep else None))
+                                       rstd2=rstd2, h2=h2[0], f1=pre, a=a[0] if keep else None, h2_lo=None if keep else h2[1]))
             del h, o, h2, a
             x = x_out
         mean, rstd = (None if v25 else stat()), stat()
         hm = K.norm_pair(x, W["merger.ln_w"], None if v25 else W["merger.ln_b"], 1e-6, mean=mean, rstd=rstd)
         m4 = cfg.merge ** 2
         hm4 = hm[0].view(Np // m4, m4 * D)
-        m32 = K.gemm_pair(hm4, hm[1].view(Np // m4, m4 * D), W["merger.m0_w"], bias=W["merger.m0_b"])
-        m1 = self._empty(*m32.shape, dtype=BF16) if taped else None
-        g = K.act_pair(m32, K.SPACER_ACT_GELU_ERF, pre_out=m1)
+        m1 = self._empty(Np // m4, W["merger.m0_w"].shape[0], dtype=BF16) if taped else None
+        g = K.gemm_pair_act(hm4, hm[1].view(Np // m4, m4 * D), W["merger.m0_w"], K.SPACER_ACT_GELU_ERF, bias=W["merger.m0_b"], pre_out=m1)
         merged = K.gemm_pair(*g, W["merger.m2_w"], bias=W["merger.m2_b"])
         if taped:
             # unit_perm None: the gradient of the vision rows arrives in the tower's own (window) order -- the embedding maps the
@@ -408,9 +416,8 @@ class Qwen2VLEngine:
             p = f"llm.{i}."
             rstd1 = self._empty(T) if taped else None
             h = K.norm_pair(x, W[p + "ln1_w"], None, cfg.rms_eps, rstd=rstd1)
-            qkv32 = K.gemm_pair(*h, W[p + "qkv_w"], bias=W[p + "qkv_b"])
-            qh, ql = K.rope_pair(qkv32, cos, sin, Hq + Hkv, Hq + 2 * Hkv, D)
-            del qkv32
+            # bias + rotary + hi/lo split in the q|k|v pair GEMM's epilogue: no fp32 [T, qkv] round trip
+            qh, ql = K.gemm_pair_rope(*h, W[p + "qkv_w"], cos, sin, Hq + Hkv, Hq + 2 * Hkv, D, bias=W[p + "qkv_b"])
             lse = self._empty(Hq, T) if taped else None
             o = K.attn_fwd_pair((qh[:, :qd], ql[:, :qd]), (qh[:, qd:qd + kd], ql[:, qd:qd + kd]), (qh[:, qd + kd:], ql[:, qd + kd:]),
                                 segs, max_q, Hq, Hkv, D, True, scale, lse=lse)
@@ -418,14 +425,13 @@ class Qwen2VLEngine:
             x_mid = K.gemm_pair(*o, W[p + "o_w"], residual=x, out=None if taped else x)
             rstd2 = self._empty(T) if taped else None
             h2 = K.norm_pair(x_mid, W[p + "ln2_w"], None, cfg.rms_eps, rstd=rstd2)
-            gu32 = K.gemm_pair(*h2, W[p + "gu_w"])
-            gu = self._empty(*gu32.shape, dtype=BF16) if keep else None
-            a = K.swiglu_pair(gu32, gu_out=gu)
-            del gu32
+            gu = self._empty(T, W[p + "gu_w"].shape[0], dtype=BF16) if keep else None
+            a = K.gemm_pair_swiglu(*h2, W[p + "gu_w"], gu_out=gu)       # SwiGLU + split (+ bf16 gate|up tape) in the pair GEMM's epilogue
             x_out = K.gemm_pair(*a, W[p + "down_w"], residual=x_mid, out=None if taped else x_mid)
             if taped:
+                # recompute policy: the backward re-runs THIS layer's gate|up launch, which needs the lo half of its input as well
                 tape.append(dict(x_in=x, rstd1=rstd1, h=h[0], qkv=qh, o=o[0], lse=lse, x_mid=x_mid, rstd2=rstd2, h2=h2[0], gu=gu,
-                                 a=a[0] if keep else None))
+                                 a=a[0] if keep else None, h2_lo=None if keep else h2[1]))
             del h, o, h2, a
             x = x_out
         return x

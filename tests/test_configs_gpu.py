@@ -63,12 +63,11 @@ def test_cfg5_llm_side_shared_prefix_and_one_full_step(ge7, dev, monkeypatch):
     prompt, _ = make_prompt(cfg, 0, 32, 448, 448, 360, dev)
     assert tuple(prompt.grids[0]) == (16, 32, 32) and prompt.ids.numel() == 4096 + 362
     comps = torch.randint(1000, 150000, (2, 64), generator=torch.Generator().manual_seed(3)).to(dev)
-    monkeypatch.setattr(K.PLAN, "gemm_no_split", 1)
-    lp = eng.score_group(prompt.ids, comps, prompt.pix, prompt.grids)
-    for k in range(2):
-        alone = eng.score_group(prompt.ids, comps[k:k + 1], prompt.pix, prompt.grids)
-        assert torch.equal(lp[k], alone[0]), float((lp[k] - alone[0]).abs().max())
-    monkeypatch.setattr(K.PLAN, "gemm_no_split", 0)
+    with K.plan(gemm_no_split=1):
+        lp = eng.score_group(prompt.ids, comps, prompt.pix, prompt.grids)
+        for k in range(2):
+            alone = eng.score_group(prompt.ids, comps[k:k + 1], prompt.pix, prompt.grids)
+            assert torch.equal(lp[k], alone[0]), float((lp[k] - alone[0]).abs().max())
     assert torch.isfinite(lp).all()
     _full_step(ge7, [prompt], 24)
     peak = torch.cuda.max_memory_allocated() / 1e9
@@ -79,12 +78,11 @@ def test_cfg5_llm_side_shared_prefix_and_one_full_step(ge7, dev, monkeypatch):
 def test_cfg4_shape_graph_equals_eager_and_one_full_step(ge7, dev, monkeypatch):
     cfg = ge7.cfg
     prompt, _ = make_prompt(cfg, 1, 16, 280, 364, 360, dev)
-    monkeypatch.setattr(K.PLAN, "skinny_blocks", 1)      # decode GEMMs without split-K atomics: reproducible rollouts
-    ge7.roll.invalidate()
-    sp = SamplingParams(max_new_tokens=12, seed=9, suppress_eos=True)
-    a = ge7.roll.generate([prompt], 8, sp, use_graph=True)           # ONE prompt group: an 8-row decode batch
-    b = ge7.roll.generate([prompt], 8, sp, use_graph=False)
-    monkeypatch.setattr(K.PLAN, "skinny_blocks", 0)
+    with K.plan(skinny_blocks=1):      # decode GEMMs without split-K atomics: reproducible rollouts
+        ge7.roll.invalidate()
+        sp = SamplingParams(max_new_tokens=12, seed=9, suppress_eos=True)
+        a = ge7.roll.generate([prompt], 8, sp, use_graph=True)           # ONE prompt group: an 8-row decode batch
+        b = ge7.roll.generate([prompt], 8, sp, use_graph=False)
     assert tuple(a.shape) == (8, 12) and torch.equal(a, b)
     assert len({tuple(r.tolist()) for r in a}) > 1                    # sampled rollouts differ from one another
     _full_step(ge7, [prompt], 16, step_idx=1)
@@ -98,18 +96,16 @@ def test_cfg2_workload_shapes(dev, monkeypatch):
     prompts = [make_prompt(cfg, g, 8, 280, 364, 360, dev)[0] for g in range(2)]
     assert tuple(prompts[0].grids[0]) == (4, 20, 26) and prompts[0].ids.numel() == 520 + 362
     comps = [torch.randint(1000, 150000, (4, 512), generator=torch.Generator().manual_seed(3 + g)).to(dev) for g in range(2)]
-    monkeypatch.setattr(K.PLAN, "gemm_no_split", 1)
-    lp = eng.score_group(prompts[0].ids, comps[0], prompts[0].pix, prompts[0].grids)
-    alone = eng.score_group(prompts[0].ids, comps[0][2:3], prompts[0].pix, prompts[0].grids)
-    assert torch.equal(lp[2], alone[0])
-    both = eng.score_groups([(p.ids, p.pix, p.grids) for p in prompts], comps)      # two groups per pass == group by group
-    lp1 = eng.score_group(prompts[1].ids, comps[1], prompts[1].pix, prompts[1].grids)
-    assert torch.equal(both[:4], lp) and torch.equal(both[4:], lp1)
-    monkeypatch.setattr(K.PLAN, "gemm_no_split", 0)
+    with K.plan(gemm_no_split=1):
+        lp = eng.score_group(prompts[0].ids, comps[0], prompts[0].pix, prompts[0].grids)
+        alone = eng.score_group(prompts[0].ids, comps[0][2:3], prompts[0].pix, prompts[0].grids)
+        assert torch.equal(lp[2], alone[0])
+        both = eng.score_groups([(p.ids, p.pix, p.grids) for p in prompts], comps)      # two groups per pass == group by group
+        lp1 = eng.score_group(prompts[1].ids, comps[1], prompts[1].pix, prompts[1].grids)
+        assert torch.equal(both[:4], lp) and torch.equal(both[4:], lp1)
     roll = RolloutEngine(eng)
-    monkeypatch.setattr(K.PLAN, "skinny_blocks", 1)
-    out = roll.generate([prompts[0]], 4, SamplingParams(max_new_tokens=8, top_k=1, top_p=1.0, suppress_eos=True), use_graph=True)
-    monkeypatch.setattr(K.PLAN, "skinny_blocks", 0)
+    with K.plan(skinny_blocks=1):
+        out = roll.generate([prompts[0]], 4, SamplingParams(max_new_tokens=8, top_k=1, top_p=1.0, suppress_eos=True), use_graph=True)
     assert tuple(out.shape) == (4, 8) and all(torch.equal(out[0], out[k]) for k in range(1, 4))
     sc = eng.score_group(prompts[0].ids, out, prompts[0].pix, prompts[0].grids)
     alts = out[:1].repeat(6, 1)

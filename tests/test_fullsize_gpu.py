@@ -101,20 +101,18 @@ def test_cfg3_shapes_shared_prefix_and_decode(big, monkeypatch):
     prompt, _ = make_prompt(cfg, 0, 16, 280, 364, 360, dev)
     assert prompt.ids.numel() == 1402 and tuple(prompt.grids[0]) == (8, 20, 26)
     comps = torch.randint(1000, 150000, (8, 512), generator=torch.Generator().manual_seed(3)).to(dev)
-    monkeypatch.setattr(K.PLAN, "gemm_no_split", 1)
-    lp = eng.score_group(prompt.ids, comps, prompt.pix, prompt.grids)
-    assert tuple(lp.shape) == (8, 512) and torch.isfinite(lp).all()
-    for k in (0, 5):
-        alone = eng.score_group(prompt.ids, comps[k:k + 1], prompt.pix, prompt.grids)
-        assert torch.equal(lp[k], alone[0]), f"rollout {k}: shared-prefix vs alone differ by {float((lp[k] - alone[0]).abs().max())}"
-    monkeypatch.setattr(K.PLAN, "gemm_no_split", 0)
+    with K.plan(gemm_no_split=1):
+        lp = eng.score_group(prompt.ids, comps, prompt.pix, prompt.grids)
+        assert tuple(lp.shape) == (8, 512) and torch.isfinite(lp).all()
+        for k in (0, 5):
+            alone = eng.score_group(prompt.ids, comps[k:k + 1], prompt.pix, prompt.grids)
+            assert torch.equal(lp[k], alone[0]), f"rollout {k}: shared-prefix vs alone differ by {float((lp[k] - alone[0]).abs().max())}"
     lp_split = eng.score_group(prompt.ids, comps, prompt.pix, prompt.grids)       # the shipped configuration: K-split tail on
     d = lp_split - lp
     assert float(d.pow(2).mean().sqrt()) < 3e-2 and float(d.abs().max()) < 0.15, (float(d.pow(2).mean().sqrt()), float(d.abs().max()))
     roll = RolloutEngine(eng)
-    monkeypatch.setattr(K.PLAN, "skinny_blocks", 1)     # decode GEMMs without split-K atomics: every row sums in the same order
-    out = roll.generate([prompt], 8, SamplingParams(max_new_tokens=8, top_k=1, top_p=1.0, suppress_eos=True), use_graph=True)
-    monkeypatch.setattr(K.PLAN, "skinny_blocks", 0)
+    with K.plan(skinny_blocks=1):     # decode GEMMs without split-K atomics: every row sums in the same order
+        out = roll.generate([prompt], 8, SamplingParams(max_new_tokens=8, top_k=1, top_p=1.0, suppress_eos=True), use_graph=True)
     assert tuple(out.shape) == (8, 8) and all(torch.equal(out[0], out[k]) for k in range(1, 8))
     alts = out[:1].repeat(6, 1)
     alts[1:, -1] = torch.randint(1000, 150000, (5,), generator=torch.Generator().manual_seed(4)).to(dev)

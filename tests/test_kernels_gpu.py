@@ -230,6 +230,56 @@ def test_gemm_skinny_packed_up_to_128_rows(dev, M, N, Kd):
     assert_close(c, c0 + a.float() @ b.float().t(), 5e-3, 2e-3, "skinny packed, M > 64")
 
 
+@pytest.mark.parametrize("skew", [-1, 1, 7, 17])
+@pytest.mark.parametrize("M,N,Kd", [(8, 4608, 3584), (64, 4608, 3584), (33, 1024, 1536), (5, 64, 512)])
+def test_gemm_skinny_skewed_k_ranges(dev, M, N, Kd, skew):
+    """spacer_plan::skinny_skew forced (ADVICE r4): equal ranges (-1), an even split derived in the kernel (1 -> alpha 0), the default
+    rule's alpha 0.375 (7) and the largest legal skew (17 -> alpha 1, whose first range comes out EMPTY): every K slice is summed
+    exactly once -- C against the fp32 product, and for the norm-folded launch the row sums of x^2 as well."""
+    a, b = rnd((M, Kd), dev, 1, 0.5), rnd((N, Kd), dev, 2, 0.05)
+    bp = K.pack_weight_frag(b)
+    c0 = rnd((M, N), dev, 3, dtype=torch.float32)
+    want = c0 + a.float() @ b.float().t()
+    with K.plan(skinny_skew=skew):
+        c = c0.clone()
+        K.gemm_skinny_packed_acc(a, bp, c, N)
+        assert_close(c, want, 5e-3, 2e-3, f"skinny packed, skew {skew}")
+        x32 = rnd((M, Kd), dev, 4, 0.5, torch.float32)
+        c2, rowss = c0.clone(), torch.zeros(M, device=dev)
+        K.gemm_skinny_packed_normed(x32, bp, c2, rowss, N)
+        assert_close(c2, c0 + x32.to(BF).float() @ b.float().t(), 5e-3, 2e-3, f"skinny normed, skew {skew}")
+        assert_close(rowss, x32.pow(2).sum(1), 1e-5, 1e-4, f"row sums of x^2, skew {skew}")
+    with K.plan(skinny_skew=-1):
+        ce = c0.clone()
+        K.gemm_skinny_packed_acc(a, bp, ce, N)
+    assert_close(c, ce, 1e-4, 1e-4, "skewed vs equal ranges (fp32 summation order only)")
+
+
+def test_gemm_skinny_skew_out_of_range_is_rejected(dev):
+    """alpha = (skew - 1) / 16 > 1 would make the kernel's range boundaries non-monotone (negative starts): refused at the launch."""
+    a, b = rnd((8, 512), dev, 1), rnd((64, 512), dev, 2)
+    c = torch.zeros(8, 64, device=dev)
+    with K.plan(skinny_skew=18):
+        with pytest.raises(K.SpacerError, match="skinny_skew"):
+            K.gemm_skinny_packed_acc(a, K.pack_weight_frag(b), c, 64)
+        with pytest.raises(K.SpacerError, match="skinny_skew"):
+            K.gemm_skinny_packed_normed(torch.zeros(8, 512, device=dev), K.pack_weight_frag(b), c, torch.zeros(8, device=dev), 64)
+
+
+def test_stale_plan_struct_is_rejected(dev):
+    """A plan whose struct_bytes is not the library's sizeof(spacer_plan) -- a binding that is a field short, as the round-4
+    INTEGRATION.md stub was -- fails with SPACER_EINVAL instead of being over-read."""
+    a, b = rnd((256, 64), dev, 1), rnd((256, 64), dev, 2)
+    old = K.PLAN.struct_bytes
+    try:
+        K.PLAN.struct_bytes = old - 4
+        with pytest.raises(K.SpacerError, match="struct_bytes"):
+            K.gemm_nt(a, b)
+    finally:
+        K.PLAN.struct_bytes = old
+    K.gemm_nt(a, b)
+
+
 def test_transpose_pad(dev):
     x = rnd((200, 136), dev, 1)
     t = K.transpose_pad(x, 256)
