@@ -1,0 +1,221 @@
+// Decode GEMMs for SMALL row counts (M <= 16: one prompt group of K = 8 rollouts per GPU is the reference script's own launch shape,
+// run_SpaceR_SG_RLVR.sh:21,39 = BASELINE configs[3]; cfg2's 4 groups x K = 4 are 16 rows).  Round 5.
+//
+// The 64-row kernels of decode.hip are tuned for the 64-row batch: column groups of 64 x K RANGES, so q|k|v / o / down split K
+// across workgroups and meet through fp32 atomics (2 M atomics per launch, 3-4.6 us of flush), q|k|v needs a zero-filled fp32
+// accumulator and a separate finishing kernel that reads the atomically produced sums back (bias, rotary, KV append), and every
+// workgroup re-stages A through LDS.  At <= 16 rows none of that is needed:
+//   * a workgroup owns ONE 16-column weight fragment over ALL of K: its four waves take the k-steps u = 4 j + w, so every A
+//     element is used by exactly one wave of the workgroup exactly once -- A fragments go global -> registers (row l15, 16 bytes per
+//     lane), no LDS staging, no barrier in the K loop;
+//   * the whole weight share of a wave is a handful of 1 KiB non-temporal loads (K = 3584: 28 per wave); a ring of DEPTH loads stays
+//     in flight from the first instruction on, so the launch is a pure stream after one latency;
+//   * the four K-interleaved partial sums meet in LDS, wave 0 runs the epilogue -- no atomics, no zero fill, bit-reproducible;
+//   * epilogues: ACC (C32 += sums: o / down projections into the fp32 residual stream), STORE, and QKV: the layer's input RMSNorm
+//     folded in (A = the fp32 stream, row sums of x^2 from the SAME loads, W diag(w_ln) in the packed weights), + bias, rotary,
+//     bf16 q rows and the KV-cache append in one go -- the packed q|k|v fragments hold dims [8 j .. 8 j + 7] and [64 + 8 j .. 64 + 8 j + 7]
+//     of ONE head (spacer_pack_weight_frag_rope), so a rotary pair sits in lanes l and l ^ 8 of the same wave.
+// One launch replaces {norm-folded K-split GEMM + finishing kernel} (q|k|v) and the atomic K-split launches of o / down.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned int r16_u32x4;
+
+enum { R16_ACC = 0, R16_STORE = 1, R16_QKV = 2 };
+
+struct Rows16Args {
+    const void* A; long lda;               // bf16 [M, K], or fp32 [M, K] (NORMA)
+    const bf16_t* Bp;                      // fragment-major weights [N/16][K/32][64 lanes][8]
+    float* C; long ldc;                    // ACC / STORE: fp32 [M, N]
+    int M, N, K;
+    // QKV epilogue
+    const bf16_t* bias;                    // [N] in the ORIGINAL column order (head-major), or null
+    const float* cos_t; const float* sin_t;   // [M, D]
+    bf16_t* q_out; bf16_t* tail_k; bf16_t* tail_v;
+    const int* tail_len;
+    int Hq, Hkv, D, Cmax;
+    float eps;
+};
+
+template <int EPI, bool NORMA, int DEPTH>
+__global__ __launch_bounds__(256, 2) void gemm_rows16_kernel(Rows16Args a) {
+    __shared__ float4 part[4][64];
+    __shared__ float rowss[4][16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int nb = blockIdx.x;                                  // fragment column
+    const int nsteps = a.K >> 5;
+    const bool row_ok = l15 < a.M;
+    const bf16_t* wbase = a.Bp + ((long)nb * nsteps) * 512 + lane * 8;
+    const char* abase = (const char*)a.A + (long)l15 * a.lda * (NORMA ? 4 : 2) + g * 8 * (NORMA ? 4 : 2);
+
+    r16_u32x4 w[DEPTH];
+    uint4 ab[NORMA ? 1 : DEPTH];
+    float4 af[NORMA ? DEPTH : 1][2];
+    auto issue = [&](int i, int u) {                            // k-step u into ring slot i
+        w[i] = __builtin_nontemporal_load((const r16_u32x4*)(wbase + (long)u * 512));
+        if (NORMA) {
+            const float* p = (const float*)(abase + (long)u * 32 * 4);
+            af[NORMA ? i : 0][0] = row_ok ? *(const float4*)p : make_float4(0.f, 0.f, 0.f, 0.f);
+            af[NORMA ? i : 0][1] = row_ok ? *(const float4*)(p + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            ab[NORMA ? 0 : i] = row_ok ? *(const uint4*)(abase + (long)u * 32 * 2) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i) {
+        const int u = wave + 4 * i;
+        if (u < nsteps) issue(i, u);
+    }
+    for (int j0 = 0; wave + 4 * j0 < nsteps; j0 += DEPTH) {
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) {
+            const int u = wave + 4 * (j0 + i);
+            if (u < nsteps) {
+                bf16x8 av;
+                if (NORMA) {
+                    const float4 lo = af[NORMA ? i : 0][0], hi = af[NORMA ? i : 0][1];
+                    ss += lo.x * lo.x + lo.y * lo.y + lo.z * lo.z + lo.w * lo.w + hi.x * hi.x + hi.y * hi.y + hi.z * hi.z + hi.w * hi.w;
+                    av = __builtin_bit_cast(bf16x8, make_uint4(pack_bf2(lo.x, lo.y), pack_bf2(lo.z, lo.w), pack_bf2(hi.x, hi.y), pack_bf2(hi.z, hi.w)));
+                } else {
+                    av = __builtin_bit_cast(bf16x8, ab[NORMA ? 0 : i]);
+                }
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, w[i]), acc, 0, 0, 0);   // D[m = g*4 + r][n = l15]
+                const int un = u + 4 * DEPTH;
+                if (un < nsteps) issue(i, un);
+            }
+        }
+    }
+    // ---- the four K-interleaved partial sums (and row sums of x^2) meet in LDS; wave 0 finishes
+    part[wave][lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    if (NORMA) {
+        ss += __shfl_xor(ss, 16, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        if (g == 0) rowss[wave][l15] = ss;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    float v[4];
+    {
+        const float4 p0 = part[0][lane], p1 = part[1][lane], p2 = part[2][lane], p3 = part[3][lane];
+        v[0] = (p0.x + p1.x) + (p2.x + p3.x); v[1] = (p0.y + p1.y) + (p2.y + p3.y);
+        v[2] = (p0.z + p1.z) + (p2.z + p3.z); v[3] = (p0.w + p1.w) + (p2.w + p3.w);
+    }
+    const int n = nb * 16 + l15;
+    if (EPI == R16_ACC || EPI == R16_STORE) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = g * 4 + r;
+            if (m < a.M) {
+                float* c = a.C + (long)m * a.ldc + n;
+                *c = EPI == R16_ACC ? *c + v[r] : v[r];
+            }
+        }
+        return;
+    }
+    // ---- q|k|v: rstd (norm fold) -> + bias -> rotary on q / k heads -> bf16 q rows, KV-cache append at *tail_len
+    const int D = a.D, half = D >> 1, fph = D >> 4;                  // fragments per head
+    const int head = nb / fph, j = nb % fph;
+    const int d = (l15 < 8 ? 0 : half) + j * 8 + (l15 & 7);           // this lane's dim inside the head
+    const float bv = a.bias ? bf2f(a.bias[head * D + d]) : 0.f;
+    const int pos = *a.tail_len;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = g * 4 + r;
+        float x = v[r];
+        if (NORMA) {
+            const float s2 = (rowss[0][m] + rowss[1][m]) + (rowss[2][m] + rowss[3][m]);
+            x *= rsqrtf(s2 / (float)a.K + a.eps);
+        }
+        x += bv;
+        const float other = __shfl_xor(x, 8, 64);                    // the rotary partner (dim d +- D/2), every lane takes part
+        if (m >= a.M) continue;
+        if (head < a.Hq + a.Hkv) {
+            const float c = a.cos_t[m * D + d], s = a.sin_t[m * D + d];
+            x = l15 < 8 ? x * c - other * s : x * c + other * s;
+        }
+        bf16_t* dst;
+        if (head < a.Hq) dst = a.q_out + ((long)m * a.Hq + head) * D;
+        else if (head < a.Hq + a.Hkv) dst = a.tail_k + (((long)m * a.Cmax + pos) * a.Hkv + (head - a.Hq)) * D;
+        else dst = a.tail_v + (((long)m * a.Cmax + pos) * a.Hkv + (head - a.Hq - a.Hkv)) * D;
+        dst[d] = f2bf(x);
+    }
+}
+
+// W [N, K] row-major (N = heads * D) -> fragment-major copy whose 16-column fragments pair the rotary halves of one head:
+// fragment nb = (head, j): columns p < 8 -> row head*D + 8 j + p, p >= 8 -> row head*D + D/2 + 8 j + (p - 8).
+// scale (bf16 [K], may be null): W diag(scale) is folded in (the decode path's input RMSNorm weight), rounded once to bf16.
+__global__ __launch_bounds__(256) void pack_frag_rope_kernel(const bf16_t* __restrict__ W, long ld, const bf16_t* __restrict__ scale,
+                                                             bf16_t* __restrict__ out, int N, int K, int D) {
+    const long total = (long)(N >> 4) * (K >> 5) * 64;
+    const int fph = D >> 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int lane = (int)(i & 63);
+        const long frag = i >> 6;
+        const int kb = (int)(frag % (K >> 5));
+        const long nb = frag / (K >> 5);
+        const int p = lane & 15;
+        const long row = (nb / fph) * D + (p < 8 ? 0 : D / 2) + (nb % fph) * 8 + (p & 7);
+        const int k0 = kb * 32 + (lane >> 4) * 8;
+        uint4 v = *(const uint4*)(W + row * ld + k0);
+        if (scale) {
+            const uint4 sc = *(const uint4*)(scale + k0);
+            v.x = pack_bf2(bf_lo(v.x) * bf_lo(sc.x), bf_hi(v.x) * bf_hi(sc.x));
+            v.y = pack_bf2(bf_lo(v.y) * bf_lo(sc.y), bf_hi(v.y) * bf_hi(sc.y));
+            v.z = pack_bf2(bf_lo(v.z) * bf_lo(sc.z), bf_hi(v.z) * bf_hi(sc.z));
+            v.w = pack_bf2(bf_lo(v.w) * bf_lo(sc.w), bf_hi(v.w) * bf_hi(sc.w));
+        }
+        *(uint4*)(out + i * 8) = v;
+    }
+}
+
+constexpr int R16_DEPTH = 14;
+
+}  // namespace
+
+extern "C" int spacer_pack_weight_frag_rope(const void* W, long ld, const void* scale, void* out, int N, int K, int head_dim,
+                                            spacer_stream_t stream) {
+    SP_REQUIRE(W && out, SPACER_EINVAL, "pack_weight_frag_rope: null operand");
+    SP_REQUIRE(head_dim >= 16 && head_dim % 16 == 0 && N % head_dim == 0 && K % 32 == 0 && ld % 8 == 0, SPACER_EINVAL,
+               "pack_weight_frag_rope: need head_dim %% 16 == 0, N %% head_dim == 0, K %% 32 == 0 (N=%d K=%d D=%d)", N, K, head_dim);
+    const long total = (long)(N / 16) * (K / 32) * 64;
+    hipLaunchKernelGGL(pack_frag_rope_kernel, dim3((int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192)), dim3(256), 0,
+                       (hipStream_t)stream, (const bf16_t*)W, ld, (const bf16_t*)scale, (bf16_t*)out, N, K, head_dim);
+    SP_CHECK_LAUNCH();
+    return SPACER_OK;
+}
+
+// C32[M, N] (+)= A[M, K] . Wp^T for M <= 16 rows, one whole-K workgroup per 16-column fragment (no atomics).  store != 0: C = A . Wp^T.
+extern "C" int spacer_gemm_rows16_packed_bf16(const void* A, long lda, const void* Bpacked, float* C, long ldc, int M, int N, int K,
+                                              int store, spacer_stream_t stream) {
+    SP_REQUIRE(A && Bpacked && C, SPACER_EINVAL, "gemm_rows16: null operand");
+    SP_REQUIRE(M > 0 && M <= 16 && N % 16 == 0 && N > 0 && K % 32 == 0 && K > 0 && lda % 8 == 0 && ((uintptr_t)A % 16) == 0, SPACER_EINVAL,
+               "gemm_rows16: need 0 < M <= 16, N %% 16 == 0, K %% 32 == 0, lda %% 8 == 0 (M=%d N=%d K=%d)", M, N, K);
+    Rows16Args a = {};
+    a.A = A; a.lda = lda; a.Bp = (const bf16_t*)Bpacked; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+    if (store) hipLaunchKernelGGL((gemm_rows16_kernel<R16_STORE, false, R16_DEPTH>), dim3(N / 16), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((gemm_rows16_kernel<R16_ACC, false, R16_DEPTH>), dim3(N / 16), dim3(256), 0, (hipStream_t)stream, a);
+    SP_CHECK_LAUNCH();
+    return SPACER_OK;
+}
+
+// The decode q|k|v projection of one layer for M <= 16 rows in ONE launch (HF: input_layernorm + q/k/v_proj + rotary + cache update of
+// one generate step, TR:463): x32 [M, K] = the fp32 residual stream; Wp = spacer_pack_weight_frag_rope(W, scale = the norm weight).
+extern "C" int spacer_decode_qkv_rows16(const float* x32, long ldx, const void* Wp_rope, const void* bias, const float* cos_t,
+                                        const float* sin_t, void* q_out, void* tail_k, void* tail_v, const int* tail_len_dev, int M,
+                                        int K, float eps, int Hq, int Hkv, int D, int Cmax, spacer_stream_t stream) {
+    SP_REQUIRE(x32 && Wp_rope && cos_t && sin_t && q_out && tail_k && tail_v && tail_len_dev, SPACER_EINVAL, "decode_qkv_rows16: null operand");
+    SP_REQUIRE(M > 0 && M <= 16 && K % 32 == 0 && ldx % 4 == 0 && ((uintptr_t)x32 % 16) == 0 && D % 16 == 0 && D >= 16 && Hq > 0 && Hkv > 0, SPACER_EINVAL,
+               "decode_qkv_rows16: need 0 < M <= 16, K %% 32 == 0, head_dim %% 16 == 0 (M=%d K=%d D=%d)", M, K, D);
+    Rows16Args a = {};
+    a.A = x32; a.lda = ldx; a.Bp = (const bf16_t*)Wp_rope; a.M = M; a.N = (Hq + 2 * Hkv) * D; a.K = K;
+    a.bias = (const bf16_t*)bias; a.cos_t = cos_t; a.sin_t = sin_t; a.q_out = (bf16_t*)q_out; a.tail_k = (bf16_t*)tail_k;
+    a.tail_v = (bf16_t*)tail_v; a.tail_len = tail_len_dev; a.Hq = Hq; a.Hkv = Hkv; a.D = D; a.Cmax = Cmax; a.eps = eps;
+    hipLaunchKernelGGL((gemm_rows16_kernel<R16_QKV, true, R16_DEPTH>), dim3(a.N / 16), dim3(256), 0, (hipStream_t)stream, a);
+    SP_CHECK_LAUNCH();
+    return SPACER_OK;
+}

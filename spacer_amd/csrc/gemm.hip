@@ -51,9 +51,14 @@ struct GemmArgs {
     // workgroups; stage_bf16 = bf16 output without a residual (and the SwiGLU form): the epilogue stages bf16 through half of the
     // LDS and the next item's first K tile is requested under it (gemm_halftile.h)
     int total_blocks, stage_bf16;
+};
+
+// The pair forms' own arguments (a SECOND kernel argument of gemm_bf16_pair_256h_kernel only: the production kernels' argument block
+// is byte for byte round 3's -- growing GemmArgs changed their register allocation, see profiles/r05_gemm_ab.md).
+struct PairArgs {
     // K-concatenated pair form (precise mode, NT operands only): C = [A | A2] . [B | B]^T in ONE launch -- global K tiles
-    // kt < kt_wrap come from A, the others from A2 at tile kt - kt_wrap, and B's K tile index wraps at kt_wrap; K = 2 x the
-    // contraction length of one pass.  kt_wrap = INT_MAX (never reached) for every other launch.
+    // kt < kt_wrap come from A, the others from A2 at tile kt - kt_wrap, and B's K tile index wraps at kt_wrap; GemmArgs::K = 2 x the
+    // contraction length of one pass
     const bf16_t* A2; int kt_wrap;
     // pair forms with a fused producer epilogue (gemm_halftile.h: PAIR_SWIGLU / PAIR_ROPE / PAIR_ACT): C = hi, C2 = lo (bf16, same ld);
     // C3 = bf16 tape output (gate | up, or the pre-activation) or null; rotary tables fp32 [M, 128], heads below rope_heads are rotated
@@ -362,8 +367,8 @@ static int launch_gemm(const void* A, long lda, const void* B, long ldb, void* C
     GemmArgs g;
     g.swiglu_inter = 0; g.C2 = nullptr; g.ldc2 = 0;
     g.k_tail_tile = -1; g.A_tail = nullptr; g.B_tail = nullptr;
-    g.A2 = (const bf16_t*)A2; g.kt_wrap = A2 ? K / BK : 0x7fffffff;
-    g.pair_mode = A2 ? PAIR_PLAIN : PAIR_NONE; g.C3 = nullptr; g.ldc3 = 0; g.rope_cos = g.rope_sin = nullptr; g.rope_heads = 0;
+    PairArgs pa = {};
+    pa.A2 = (const bf16_t*)A2; pa.kt_wrap = A2 ? K / BK : 0x7fffffff; pa.pair_mode = A2 ? PAIR_PLAIN : PAIR_NONE;
     if (A2) K *= 2;                                   // one launch walks the K tiles of both passes
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
@@ -423,10 +428,10 @@ static int launch_gemm(const void* A, long lda, const void* B, long ldb, void* C
         } else {
             if (ta) hipLaunchKernelGGL((gemm_bf16_nt_256h_kernel<true, true, true, false>), grid, dim3(512), LDS, s, g);
             else if (tb) hipLaunchKernelGGL((gemm_bf16_nt_256h_kernel<true, false, true, false>), grid, dim3(512), LDS, s, g);
-            else if (A2) hipLaunchKernelGGL((gemm_bf16_pair_256h_kernel<PAIR_PLAIN>), grid, dim3(512), LDS, s, g);
+            else if (A2) hipLaunchKernelGGL((gemm_bf16_pair_256h_kernel<PAIR_PLAIN>), grid, dim3(512), LDS, s, g, pa);
             else hipLaunchKernelGGL((gemm_bf16_nt_256h_kernel<true, false, false, false>), grid, dim3(512), LDS, s, g);
         }
-        if (g.splits > 1) hipLaunchKernelGGL(gemm_tail_reduce_kernel, dim3((unsigned)(tail_tiles * 32)), dim3(512), 0, s, g);
+        if (g.splits > 1) hipLaunchKernelGGL(gemm_tail_reduce_kernel, dim3((unsigned)(tail_tiles * 32)), dim3(512), 0, s, g, pa);
     } else {
         constexpr int LDS = 2 * (128 * BK * 2 + 128 * BK * 2);
         g.tiles_m = cdiv(M, 128); g.tiles_n = cdiv(N, 128);
@@ -495,14 +500,15 @@ extern "C" int spacer_gemm_bf16_pair_epilogue(int kind, const void* A_hi, const 
                && ((uintptr_t)rope_sin % 16) == 0), SPACER_EINVAL, "gemm_pair_epilogue: rotary tables / rope_heads=%d", rope_heads);
     SP_REQUIRE(kind != SPACER_PAIR_ACT || (act >= SPACER_ACT_NONE && act <= SPACER_ACT_SILU), SPACER_EINVAL, "gemm_pair_epilogue: unknown activation %d", act);
     GemmArgs g;
-    g.A = (const bf16_t*)A_hi; g.A2 = (const bf16_t*)A_lo; g.B = (const bf16_t*)W; g.C = y_hi; g.C2 = y_lo; g.C3 = tape_bf16;
-    g.lda = lda; g.ldb = ldb; g.ldc = ld_y; g.ldc2 = ld_y; g.ldc3 = ld_tape;
-    g.M = M; g.N = N; g.K = 2 * K; g.kt_wrap = K / BK;
+    PairArgs pa = {};
+    g.A = (const bf16_t*)A_hi; pa.A2 = (const bf16_t*)A_lo; g.B = (const bf16_t*)W; g.C = y_hi; g.C2 = y_lo; pa.C3 = tape_bf16;
+    g.lda = lda; g.ldb = ldb; g.ldc = ld_y; g.ldc2 = ld_y; pa.ldc3 = ld_tape;
+    g.M = M; g.N = N; g.K = 2 * K; pa.kt_wrap = K / BK;
     g.bias = (const bf16_t*)bias; g.resid = nullptr; g.ldr = 0; g.out_f32 = 1; g.act = kind == SPACER_PAIR_ACT ? act : SPACER_ACT_NONE; g.alpha = 1.f;
     g.swiglu_inter = kind == SPACER_PAIR_SWIGLU ? N / 2 : 0;
     g.k_tail_tile = -1; g.A_tail = nullptr; g.B_tail = nullptr;
-    g.pair_mode = kind == SPACER_PAIR_SWIGLU ? PAIR_SWIGLU : kind == SPACER_PAIR_ROPE ? PAIR_ROPE : PAIR_ACT;
-    g.rope_cos = rope_cos; g.rope_sin = rope_sin; g.rope_heads = rope_heads;
+    pa.pair_mode = kind == SPACER_PAIR_SWIGLU ? PAIR_SWIGLU : kind == SPACER_PAIR_ROPE ? PAIR_ROPE : PAIR_ACT;
+    pa.rope_cos = rope_cos; pa.rope_sin = rope_sin; pa.rope_heads = rope_heads;
     g.tiles_m = cdiv(M, 256); g.tiles_n = N / 256 + (kind != SPACER_PAIR_SWIGLU && N % 256 ? 1 : 0);
     const long tiles = (long)g.tiles_m * g.tiles_n;
     tail_plan(tiles, g.K / BK, have_ws && !(plan && plan->gemm_no_split), &g.full_tiles, &g.splits);
@@ -517,10 +523,10 @@ extern "C" int spacer_gemm_bf16_pair_epilogue(int kind, const void* A_hi, const 
     (void)once;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)g.total_blocks);
-    if (kind == SPACER_PAIR_SWIGLU) hipLaunchKernelGGL((gemm_bf16_pair_256h_kernel<PAIR_SWIGLU>), grid, dim3(512), LDS, s, g);
-    else if (kind == SPACER_PAIR_ROPE) hipLaunchKernelGGL((gemm_bf16_pair_256h_kernel<PAIR_ROPE>), grid, dim3(512), LDS, s, g);
-    else hipLaunchKernelGGL((gemm_bf16_pair_256h_kernel<PAIR_ACT>), grid, dim3(512), LDS, s, g);
-    if (g.splits > 1) hipLaunchKernelGGL(gemm_tail_reduce_kernel, dim3((unsigned)(tail_tiles * 32)), dim3(512), 0, s, g);
+    if (kind == SPACER_PAIR_SWIGLU) hipLaunchKernelGGL((gemm_bf16_pair_256h_kernel<PAIR_SWIGLU>), grid, dim3(512), LDS, s, g, pa);
+    else if (kind == SPACER_PAIR_ROPE) hipLaunchKernelGGL((gemm_bf16_pair_256h_kernel<PAIR_ROPE>), grid, dim3(512), LDS, s, g, pa);
+    else hipLaunchKernelGGL((gemm_bf16_pair_256h_kernel<PAIR_ACT>), grid, dim3(512), LDS, s, g, pa);
+    if (g.splits > 1) hipLaunchKernelGGL(gemm_tail_reduce_kernel, dim3((unsigned)(tail_tiles * 32)), dim3(512), 0, s, g, pa);
     SP_CHECK_LAUNCH();
     return SPACER_OK;
 }
@@ -555,8 +561,6 @@ extern "C" int spacer_gemm_swiglu_bf16(const void* A, long lda, const void* W, l
     g.bias = (const bf16_t*)bias; g.resid = nullptr; g.ldr = 0; g.out_f32 = 0; g.act = SPACER_ACT_NONE; g.alpha = 1.f;
     g.swiglu_inter = inter; g.C2 = gu; g.ldc2 = ld_gu;
     g.k_tail_tile = -1; g.A_tail = nullptr; g.B_tail = nullptr;
-    g.A2 = nullptr; g.kt_wrap = 0x7fffffff;
-    g.pair_mode = PAIR_NONE; g.C3 = nullptr; g.ldc3 = 0; g.rope_cos = g.rope_sin = nullptr; g.rope_heads = 0;
     g.tiles_m = cdiv(M, 256); g.tiles_n = inter / 128;
     g.full_tiles = g.tiles_m * g.tiles_n; g.splits = 1; g.slabs = nullptr;      // no K-split tail: the reduce kernel has no SwiGLU form
     g.total_blocks = g.full_tiles; g.stage_bf16 = 1;

@@ -25,6 +25,9 @@ from .qwen2vl.engine import Qwen2VLEngine
 
 BF16, F32 = torch.bfloat16, torch.float32
 DECODE_NORM_FOLD = os.environ.get("SPACER_DECODE_NORM", "fold") != "separate"     # A/B switch, read once at import
+# decode batches of <= 16 rows (cfg4 = the reference script's 1 prompt group per GPU; cfg2): whole-K workgroups without split-K atomics,
+# q|k|v norm + projection + bias + rotary + cache append in one launch (csrc/decode_rows16.hip).  SPACER_DECODE_SMALL=off: the 64-row kernels
+DECODE_SMALL = os.environ.get("SPACER_DECODE_SMALL", "on") != "off"
 
 
 @dataclass
@@ -63,25 +66,35 @@ class RolloutEngine:
         # (the finishing kernel of layer i clears the row sums of layer (i + 1) % layers while it reads layer i's: a one-layer model
         # would clear what it reads, so it keeps the separate norm launch)
         self.fold_norm = DECODE_NORM_FOLD and engine.cfg.layers >= 2
+        self.small_rows = DECODE_SMALL and engine.cfg.head_dim % 16 == 0 and engine.cfg.hidden % 32 == 0 and engine.cfg.intermediate % 32 == 0
 
     # ------------------------------------------------------------------ decode-layout weights
     def invalidate(self) -> None:
         """Call after the optimizer rewrote the bf16 weights."""
         self._packed = None
 
-    def _pack(self) -> dict:
+    def _pack(self, rows: int = 64) -> dict:
         """Fragment-major (spacer_pack_weight_frag) copies of qkv/o/gate-up/down per layer + lm_head: every skinny-GEMM
-        load instruction then reads 1 KiB of contiguous HBM.  Rebuilt once per optimizer step (~14 GB at 7B, ~10 ms)."""
+        load instruction then reads 1 KiB of contiguous HBM.  Rebuilt once per optimizer step (~14 GB at 7B, ~10 ms).  The q|k|v
+        copy comes in the form the batch's row count needs (packed on first use): <= 16 rows the rotary-paired fragments with the
+        input-norm weight folded in (decode_qkv_rows16), <= 64 rows plain fragments with the norm weight folded in, else plain."""
+        W, cfg = self.e.W, self.cfg
         if self._packed is None:
-            W, cfg = self.e.W, self.cfg
-            names = [f"llm.{i}.{n}" for i in range(cfg.layers) for n in ("qkv_w", "o_w", "gu_w", "down_w")] + ["llm.lm_head"]
+            names = [f"llm.{i}.{n}" for i in range(cfg.layers) for n in ("o_w", "gu_w", "down_w")] + ["llm.lm_head"]
             self._packed = {n: (K.pack_weight_frag_swiglu(W[n]) if n.endswith("gu_w") else K.pack_weight_frag(W[n])) for n in names}
-            if self.fold_norm:           # q|k|v weights with the layer's input-norm weight folded in: W diag(w_ln1), rounded once to bf16
-                for i in range(cfg.layers):  # (the plain copy stays for batches of more than 64 rows: +33 MB per layer at 7B)
+        PW = self._packed
+        kind = "qkv_wr" if (self.small_rows and rows <= 16) else "qkv_wn" if (self.fold_norm and rows <= 64) else "qkv_w"
+        if f"llm.0.{kind}" not in PW:
+            for i in range(cfg.layers):
+                if kind == "qkv_wr":     # fragments pair the rotary halves of one head; W diag(w_ln1) folded in, rounded once to bf16
+                    PW[f"llm.{i}.qkv_wr"] = K.pack_weight_frag_rope(W[f"llm.{i}.qkv_w"], cfg.head_dim, scale=W[f"llm.{i}.ln1_w"])
+                elif kind == "qkv_wn":   # q|k|v weights with the layer's input-norm weight folded in
                     wf = (W[f"llm.{i}.qkv_w"].float() * W[f"llm.{i}.ln1_w"].float()[None, :]).to(torch.bfloat16)
-                    self._packed[f"llm.{i}.qkv_wn"] = K.pack_weight_frag(wf)
+                    PW[f"llm.{i}.qkv_wn"] = K.pack_weight_frag(wf)
                     del wf
-        return self._packed
+                else:
+                    PW[f"llm.{i}.qkv_w"] = K.pack_weight_frag(W[f"llm.{i}.qkv_w"])
+        return PW
 
     # ------------------------------------------------------------------ prefill
     def _prefill(self, prompts: List[PromptInput], era_rule: bool):
@@ -140,7 +153,12 @@ class RolloutEngine:
         scale = D ** -0.5
         for i in range(cfg.layers):
             p = f"llm.{i}."
-            if self.fold_norm and B <= 64:
+            if self.small_rows and B <= 16:
+                # <= 16 rows: input norm + q|k|v + bias + rotary + cache append in ONE launch of whole-K workgroups (no split-K atomics,
+                # no fp32 accumulator, no finishing kernel)
+                K.decode_qkv_rows16(x, PW[p + "qkv_wr"], W[p + "qkv_b"], st["cos"], st["sin"], st["q"], st["tk"][i], st["tv"][i],
+                                    st["tail_len"], cfg.rms_eps, Hq, Hkv, D)
+            elif self.fold_norm and B <= 64:
                 # norm(x) Wqkv^T = rstd * (bf16(x) (W diag(w))^T): the GEMM stages the fp32 stream and sums x^2 per row, the
                 # finishing kernel applies rstd (and clears the next layer's row sums)
                 rs = st["rowss"]
@@ -158,10 +176,17 @@ class RolloutEngine:
             else:
                 o = K.attn_decode(st["q"], st["pk"][i], st["pv"][i], st["plen"], st["prompt_of"], st["tk"][i], st["tv"][i],
                                   st["tail_len"], Hq, Hkv, D, scale, out=st["o"])
-            K.gemm_skinny_packed_acc(o, PW[p + "o_w"], x, cfg.hidden)
+            small = self.small_rows and B <= 16
+            if small:
+                K.gemm_rows16_acc(o, PW[p + "o_w"], x, cfg.hidden)
+            else:
+                K.gemm_skinny_packed_acc(o, PW[p + "o_w"], x, cfg.hidden)
             h2 = K.rmsnorm_fwd(x, W[p + "ln2_w"], cfg.rms_eps, out=st["h"])
             a = K.gemm_skinny_swiglu(h2, PW[p + "gu_w"], I, out=st["a"])      # gate|up GEMM + SwiGLU in one launch
-            K.gemm_skinny_packed_acc(a, PW[p + "down_w"], x, cfg.hidden)
+            if small:
+                K.gemm_rows16_acc(a, PW[p + "down_w"], x, cfg.hidden)
+            else:
+                K.gemm_skinny_packed_acc(a, PW[p + "down_w"], x, cfg.hidden)
         hn = K.rmsnorm_fwd(x, W["llm.norm_w"], cfg.rms_eps, out=st["h"])
         if cfg.vocab >= 448 * 64:                        # whole-K workgroups: plain stores, no zero fill of the logits
             K.gemm_skinny_packed_store(hn, PW["llm.lm_head"], st["logits"], cfg.vocab)
@@ -200,7 +225,7 @@ class RolloutEngine:
             ev[1].record()
         L, Hkv, D, H = cfg.layers, cfg.kv_heads, cfg.head_dim, cfg.hidden
         st = dict(
-            B=B, pk=pk, pv=pv, packed=self._pack(), Kn=Kn, shared_prefix=Kn * (cfg.heads // cfg.kv_heads) <= 64 and Kn > 1,
+            B=B, pk=pk, pv=pv, packed=self._pack(B), Kn=Kn, shared_prefix=Kn * (cfg.heads // cfg.kv_heads) <= 64 and Kn > 1,
             attn_ws=torch.empty(K.attn_decode_workspace_bytes(nP, cfg.kv_heads) // 4, device=dev, dtype=F32),
             plen=torch.tensor(plen, dtype=torch.int32, device=dev),
             prompt_of=torch.arange(B, dtype=torch.int32, device=dev) // Kn,

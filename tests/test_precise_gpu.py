@@ -257,8 +257,10 @@ def test_pair_gemm_with_swiglu_epilogue(dev, M, I, Kd, bias):
     gud = a.double() @ w.double().t() + (b.double() if bias else 0.0)
     want = torch.nn.functional.silu(gud[:, :I]) * gud[:, I:]
     assert rel_err(pair_f64(fused), want) <= 4 * PAIR_EPS
-    no_tape = K.gemm_pair_swiglu(ah, al, w, bias=b) if M < 1000 else fused          # the tape output is optional
-    _pair_close(no_tape, fused, "without the tape output")
+    if M < 1000:                                                                     # the tape output is optional
+        with K.plan(gemm_tile=256):
+            no_tape = K.gemm_pair_swiglu(ah, al, w, bias=b)
+        assert torch.equal(no_tape[0], fused[0]) and torch.equal(no_tape[1], fused[1])
 
 
 @pytest.mark.parametrize("M,Hq,Hkv,Kd", [(300, 2, 1, 256), (3000, 12, 2, 1536), (5498, 28, 4, 3584)])
