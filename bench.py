@@ -356,6 +356,9 @@ def main():
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="gloo: every rank on cuda:0, gradients staged through the host -- exercises the multi-rank control flow on a "
                          "one-GPU box (tests only; the number it prints is not a scaling measurement)")
+    ap.add_argument("--check-replicas", action="store_true",
+                    help="N > 1: after the timed region compare a checksum of every rank's bf16 policy weights (data-parallel replicas must "
+                         "stay bit-identical); the line carries replicas_identical")
     ap.add_argument("--force-dist", action="store_true",
                     help="create the process group (and run the reducer / barrier / max-over-ranks code) even for a world of ONE rank: "
                          "exercises the RCCL path of the multi-GPU job on a one-GPU box (tests)")
@@ -508,6 +511,16 @@ def main():
         t = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
+    replicas_identical = None
+    if dist_on and args.check_replicas:
+        import torch.distributed as dist
+        bits = ge.policy.flat.view(torch.int16).to(torch.int64)
+        idx = torch.arange(bits.numel(), device=bits.device, dtype=torch.int64) % 8191 + 1
+        sig = torch.stack([bits.sum(), (bits * idx).sum()])                   # position-weighted: a permutation would show
+        sig = sig.cpu() if args.backend == "gloo" else sig
+        sigs = [torch.empty_like(sig) for _ in range(world)]
+        dist.all_gather(sigs, sig)
+        replicas_identical = all(bool(torch.equal(sigs[0], x)) for x in sigs)
     prof = K.PROFILER.summary()
     main_stats, main_phase = dict(roll_stats), dict(phase)
     hbm_peak_gb = round(torch.cuda.max_memory_allocated() / 1e9, 1)       # of 288 GB: replicas, no ZeRO, no recompute
@@ -670,6 +683,8 @@ def main():
                 out["roofline_hbm"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
         if comm is not None:
             out["comm"] = comm
+        if replicas_identical is not None:
+            out["replicas_identical"] = replicas_identical
         if variants:
             out["variants"] = variants
         if not args.no_cpu_baseline and world == 1:

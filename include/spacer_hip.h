@@ -238,6 +238,11 @@ int spacer_attn_decode_shared(const void* q, const void* prefix_k, const void* p
  *                  row sums of x^2 from the same loads; + bias, rotary (cos/sin fp32 [M, head_dim]) on the q and k heads;
  *                  q_out bf16 [M, Hq*D]; k, v appended to the tail cache [M, Cmax, Hkv, D] at position *tail_len_dev.
  *                  Replaces spacer_gemm_skinny_packed_normed + spacer_decode_qkv_finish_normed for M <= 16. */
+/*   normed SwiGLU: y bf16 [M, inter] = silu(rstd g) * (rstd u), [g | u] = bf16(x32) . Wp^T, rstd = rsqrt(mean_k x32^2 + eps): HF
+ *                  post_attention_layernorm + gate_proj / up_proj + act_fn of one generate step for M <= 16 rows in ONE launch;
+ *                  Wp = spacer_pack_weight_frag_swiglu of W diag(w_norm); workspace / plan as spacer_gemm_skinny_swiglu_bf16_ws. */
+int spacer_gemm_skinny_swiglu_normed(const float* x32, long ldx, const void* Bpacked, void* Y, long ldy, int M, int inter, int K,
+                                     float eps, void* workspace, long workspace_bytes, const spacer_plan* plan, spacer_stream_t stream);
 int spacer_pack_weight_frag_rope(const void* W, long ld, const void* scale_bf16, void* out, int N, int K, int head_dim,
                                  spacer_stream_t stream);
 int spacer_gemm_rows16_packed_bf16(const void* A, long lda, const void* Bpacked, float* C, long ldc, int M, int N, int K, int store,

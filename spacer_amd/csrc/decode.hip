@@ -46,16 +46,24 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 // row into `rowss` (one fp32 atomic per row per K range) from which the finishing kernel forms rstd.  One ~6 us launch (the norm) less
 // per layer; the A slice costs twice the L2 -> CU bytes, which the q|k|v projection (33 MB of weights, latency-bound) does not
 // feel; on gate|up (592 column groups re-reading 64 x 3584 fp32) the same fold measured slower and is not used.
-template <bool PACKED, bool SWIGLU = false, int MT = 1, bool NORMA = false>
+// SMALL (round 5; MT = 1): the batch has <= 16 rows (cfg4's one prompt group per GPU = 8 rows): only row fragment 0 is staged,
+// read and multiplied (MF = 1: a quarter of the LDS traffic, 12 accumulator registers instead of 48).  With NORMA + SWIGLU + SMALL the
+// post-attention RMSNorm is folded into the gate|up projection: A is the fp32 residual stream (at <= 16 rows its re-staging by every
+// workgroup costs 16 x 256 x 4 B per slice beside 40 KB of weights -- at 64 rows the same fold measured slower), every
+// workgroup sums x^2 per row over its whole K (the SWIGLU forms never split K), rstd meets the epilogue through LDS, and the packed
+// weights carry W diag(w_ln2): y = silu(rstd g) * (rstd u).  One ~5 us launch (the norm) less per layer of an 8-row decode step.
+template <bool PACKED, bool SWIGLU = false, int MT = 1, bool NORMA = false, bool SMALL = false>
 __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __restrict__ A, long lda,
                                                              const bf16_t* __restrict__ B, long ldb,
                                                              float* __restrict__ C, long ldc, int M, int N, int K,
                                                              int slices_per_range, int mflush, int overwrite,
                                                              int split_groups = 0, int split_ranges = 1,
                                                              float* __restrict__ scratch = nullptr, int* __restrict__ tickets = nullptr,
-                                                             float* __restrict__ rowss = nullptr, int wide_groups = 0) {
+                                                             float* __restrict__ rowss = nullptr, int wide_groups = 0, float eps = 0.f) {
+    static_assert(!SMALL || MT == 1, "SMALL is a 64-row-block form");
     constexpr int KS = 256 / MT, ROWB = KS * 2;            // LDS row bytes (512 / 256); 16-byte chunk index ^= row & 15
-    constexpr int NU = KS / 32, MF = 4 * MT;               // MFMA k-steps per slice, 16-row A fragments
+    constexpr int NU = KS / 32, MF = SMALL ? 1 : 4 * MT;   // MFMA k-steps per slice, 16-row A fragments
+    constexpr int NJ = SMALL ? 2 : 8;                      // staging instructions per thread (8 rows each)
     constexpr int CH = KS / 8, CHS = (MT == 1) ? 5 : 4;    // 16-byte chunks per LDS row and log2
     __shared__ __attribute__((aligned(16))) char smem[2][64 * MT * ROWB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -101,17 +109,18 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __res
     // ---- staging map: instruction j of a thread covers row (tid >> CHS) + (256 / CH) j, 16-byte chunk tid & (CH - 1)
     // (a wave reads whole rows of the slice: 2 x 512 or 4 x 256 contiguous bytes per load instruction); 8 per thread
     const int ar0 = tid >> CHS, ach = tid & (CH - 1);
-    uint4 areg[8];
-    float4 areg32[NORMA ? 8 : 1][2];                   // NORMA: the same 8 elements per row as fp32
-    float ss[NORMA ? 8 : 1];                           // NORMA, column group 0: running sum of x^2 of this thread's chunk of 8 rows
-    const bool sums = NORMA && blockIdx.x == 0;
+    uint4 areg[NJ];
+    float4 areg32[NORMA ? NJ : 1][2];                  // NORMA: the same 8 elements per row as fp32
+    float ss[NORMA ? NJ : 1];                          // NORMA: running sum of x^2 of this thread's chunk of 8 rows
+    // who sums x^2: column group 0 of a K-split launch (atomics into rowss), EVERY workgroup of the SwiGLU fold (its own rstd)
+    const bool sums = NORMA && (SWIGLU || blockIdx.x == 0);
     if (NORMA) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ss[NORMA ? j : 0] = 0.f;
+        for (int j = 0; j < NJ; ++j) ss[NORMA ? j : 0] = 0.f;
     }
     auto load_a = [&](int slice) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int row = ar0 + (256 / CH) * j;
             if (NORMA) {
                 const float* p = (const float*)A + (long)row * lda + slice * KS + ach * 8;
@@ -126,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __res
     };
     auto store_a = [&](char* buf) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int row = ar0 + (256 / CH) * j;
             if (NORMA) {
                 const float4 lo = areg32[NORMA ? j : 0][0], hi = areg32[NORMA ? j : 0][1];
@@ -206,17 +215,20 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __res
         compute(wb, wb5, smem[1]);
         if (++s >= s_end) break;
     }
+    __shared__ float rstd_lds[SWIGLU && NORMA ? 64 : 1];
     if (NORMA && sums) {
         // the CH = 32 threads that share a row are one half wave: reduce, one atomic per row per K range
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             float v = ss[NORMA ? j : 0];
 #pragma unroll
             for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
             const int row = ar0 + (256 / CH) * j;
-            if (ach == 0 && row < M) atomicAdd(rowss + row, v);
+            if (SWIGLU) { if (ach == 0) rstd_lds[SWIGLU && NORMA ? row : 0] = rsqrtf(v / (float)K + eps); }   // whole K in this workgroup
+            else if (ach == 0 && row < M) atomicAdd(rowss + row, v);
         }
     }
+    if (SWIGLU && NORMA) __syncthreads();
     // lane holds C[m = mf*16 + g*4 + r][n = n0 + l15]
     const int n = n0 + l15;
     if (SWIGLU && split_block) {
@@ -255,10 +267,11 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __res
         for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float other = __shfl_xor(acc[mf][r], 8);
                 const int m = mf * 16 + g * 4 + r;
+                const float rs = (SWIGLU && NORMA) ? rstd_lds[SWIGLU && NORMA ? m : 0] : 1.f;
+                const float other = __shfl_xor(acc[mf][r], 8) * rs;
                 if (l15 < 8 && m < mflush && n < N) {
-                    const float gv = acc[mf][r];
+                    const float gv = acc[mf][r] * rs;
                     Y[(long)m * ldc + col] = f2bf(gv / (1.f + __expf(-gv)) * other);
                 }
             }
@@ -275,6 +288,7 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __res
 #pragma unroll
             for (int b = 0; b < MT; ++b) {
                 const int mf = wave + 4 * b;                                 // MF = 4 MT row blocks, MT per wave
+                if (SMALL && mf >= MF) break;                                // <= 16 rows: row block 0 only (wave 0 finishes it)
                 float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
@@ -283,10 +297,11 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __res
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float other = __shfl_xor(v[r], 8);
                     const int m = mf * 16 + g * 4 + r;
+                    const float rs = (SWIGLU && NORMA) ? rstd_lds[SWIGLU && NORMA ? m : 0] : 1.f;
+                    const float other = __shfl_xor(v[r], 8) * rs, gv = v[r] * rs;
                     if (l15 < 8 && m < mflush && n5 + l15 < N)
-                        Y[(long)m * ldc + col5] = f2bf(v[r] / (1.f + __expf(-v[r])) * other);
+                        Y[(long)m * ldc + col5] = f2bf(gv / (1.f + __expf(-gv)) * other);
                 }
             }
         }
@@ -912,13 +927,16 @@ extern "C" int spacer_pack_weight_frag_swiglu(const void* W, long ld, void* out,
 constexpr int SWIGLU_MAX_SPLIT_GROUPS = 256;
 extern "C" long spacer_gemm_skinny_swiglu_workspace_bytes(void) { return (long)SWIGLU_MAX_SPLIT_GROUPS * (64 * 64 * 4 + 4); }
 
+// normed: A is the fp32 residual stream and the RMSNorm in front of the projection is folded in (<= 16 rows; gemm_skinny_kernel SMALL)
 static int launch_skinny_swiglu(const void* A, long lda, const void* Bpacked, void* Y, long ldy, int M, int inter, int K, void* ws,
-                                long ws_bytes, const spacer_plan* plan, hipStream_t stream) {
+                                long ws_bytes, const spacer_plan* plan, hipStream_t stream, bool normed = false, float eps = 0.f) {
     SP_REQUIRE(A && Bpacked && Y, SPACER_EINVAL, "gemm_skinny_swiglu: null operand");
     SP_REQUIRE_PLAN(plan);
     SP_REQUIRE(M > 0 && M <= 128, SPACER_EINVAL, "gemm_skinny_swiglu: M=%d must be in 1..128", M);
     SP_REQUIRE(K % 256 == 0 && inter % 32 == 0 && lda % 8 == 0, SPACER_EINVAL,
                "gemm_skinny_swiglu: need K %% 256 == 0, inter %% 32 == 0, lda %% 8 == 0");
+    SP_REQUIRE(!normed || M <= 16, SPACER_EINVAL, "gemm_skinny_swiglu_normed: the norm-folded form takes <= 16 rows (M=%d)", M);
+    const bool small = M <= 16;
     const int N = 2 * inter, col_groups = cdiv(N, 64);
     // one-round form (round 4): between 4 and 5 column fragments per resident slot -> exactly `slots` workgroups, the first
     // `wide` of them five fragments wide (gemm_skinny_kernel: wide_groups); 65..128 rows: the same with two row blocks per pass
@@ -932,10 +950,17 @@ static int launch_skinny_swiglu(const void* A, long lda, const void* Bpacked, vo
         SP_CHECK_LAUNCH();
         return SPACER_OK;
     }
-    if (one_round) {
-        hipLaunchKernelGGL((gemm_skinny_kernel<true, true, 1>), dim3(slots1, 1), dim3(256), 0, stream, (const bf16_t*)A, lda,
-                           (const bf16_t*)Bpacked, 0L, (float*)Y, ldy, M, N, K, K / 256, M, 0, 0, 1, (float*)nullptr, (int*)nullptr,
-                           (float*)nullptr, wide);
+    if (one_round || small) {
+        // (<= 16 rows outside the one-round window: one whole-K workgroup per 64 columns, no tail balance -- the small models' shapes)
+        const dim3 grid(one_round ? slots1 : col_groups, 1);
+#define SKINNY_SWIGLU_LAUNCH(NRM, SML)                                                                                              \
+        hipLaunchKernelGGL((gemm_skinny_kernel<true, true, 1, NRM, SML>), grid, dim3(256), 0, stream, (const bf16_t*)A, lda,       \
+                           (const bf16_t*)Bpacked, 0L, (float*)Y, ldy, M, N, K, K / 256, M, 0, 0, 1, (float*)nullptr, (int*)nullptr, \
+                           (float*)nullptr, wide, eps)
+        if (normed) SKINNY_SWIGLU_LAUNCH(true, true);
+        else if (small) SKINNY_SWIGLU_LAUNCH(false, true);
+        else SKINNY_SWIGLU_LAUNCH(false, false);
+#undef SKINNY_SWIGLU_LAUNCH
         SP_CHECK_LAUNCH();
         return SPACER_OK;
     }
@@ -969,6 +994,16 @@ extern "C" int spacer_gemm_skinny_swiglu_bf16_ws(const void* A, long lda, const 
                                                  int K, void* workspace, long workspace_bytes, const spacer_plan* plan,
                                                  spacer_stream_t stream) {
     return launch_skinny_swiglu(A, lda, Bpacked, Y, ldy, M, inter, K, workspace, workspace_bytes, plan, (hipStream_t)stream);
+}
+
+// y[M, inter] = silu(rstd g) * (rstd u), [g | u] = bf16(x32) . Wp^T, rstd = rsqrt(mean(x32^2) + eps): the decode gate|up projection of
+// <= 16 rows with the post-attention RMSNorm folded in (Wp = spacer_pack_weight_frag_swiglu of W diag(w_norm)); one launch for HF's
+// post_attention_layernorm + gate_proj / up_proj + act_fn of one generate step (TR:463).
+extern "C" int spacer_gemm_skinny_swiglu_normed(const float* X32, long ldx, const void* Bpacked, void* Y, long ldy, int M, int inter,
+                                                int K, float eps, void* workspace, long workspace_bytes, const spacer_plan* plan,
+                                                spacer_stream_t stream) {
+    SP_REQUIRE(ldx % 4 == 0 && ((uintptr_t)X32 % 16) == 0, SPACER_EINVAL, "gemm_skinny_swiglu_normed: x32 rows must be 16-byte aligned");
+    return launch_skinny_swiglu(X32, ldx, Bpacked, Y, ldy, M, inter, K, workspace, workspace_bytes, plan, (hipStream_t)stream, true, eps);
 }
 
 extern "C" int spacer_decode_rope_table(const int* pos_base, const int* step_dev, float theta, float* cos_t, float* sin_t,

@@ -300,6 +300,22 @@ def gemm_skinny_swiglu(a: torch.Tensor, bp: torch.Tensor, inter: int, out: Optio
     return out
 
 
+def gemm_skinny_swiglu_normed(x32: torch.Tensor, bp: torch.Tensor, inter: int, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M, inter] = silu(rstd g) * (rstd u) with [g | u] = bf16(x32) @ Wp^T, rstd = rsqrt(mean(x32^2) + eps): the decode gate|up
+    projection of <= 16 rows with the RMSNorm in front of it folded in; bp = pack_weight_frag_swiglu(W * w_norm[None, :])."""
+    M, K = x32.shape
+    assert x32.dtype == torch.float32 and M <= 16 and bp.numel() == 2 * inter * K
+    if out is None:
+        out = torch.empty(M, inter, device=x32.device, dtype=BF16)
+    ws = _SWIGLU_WS.get(x32.device)
+    if ws is None:
+        ws = torch.zeros(_lib.load().spacer_gemm_skinny_swiglu_workspace_bytes() // 4, device=x32.device, dtype=torch.int32)
+        _SWIGLU_WS[x32.device] = ws
+    check(_lib.load().spacer_gemm_skinny_swiglu_normed(_ptr(x32), _rowmajor(x32), _ptr(bp), _ptr(out), _rowmajor(out), M, inter, K, eps,
+                                                       _ptr(ws), ws.numel() * 4, _plan(), _stream()), "gemm_skinny_swiglu_normed")
+    return out
+
+
 def transpose_pad(x: torch.Tensor, rpad: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x[R,C] bf16 -> out[C, Rpad] with zero fill (Rpad defaults to R rounded up to 64)."""
     R, Cc = x.shape

@@ -28,6 +28,8 @@ DECODE_NORM_FOLD = os.environ.get("SPACER_DECODE_NORM", "fold") != "separate"   
 # decode batches of <= 16 rows (cfg4 = the reference script's 1 prompt group per GPU; cfg2): whole-K workgroups without split-K atomics,
 # q|k|v norm + projection + bias + rotary + cache append in one launch (csrc/decode_rows16.hip).  SPACER_DECODE_SMALL=off: the 64-row kernels
 DECODE_SMALL = os.environ.get("SPACER_DECODE_SMALL", "on") != "off"
+# ... and the post-attention RMSNorm folded into the gate|up projection of such a batch (SPACER_DECODE_SMALL=nofold keeps the norm launch)
+DECODE_SMALL_FOLD = os.environ.get("SPACER_DECODE_SMALL", "on") not in ("off", "nofold")
 
 
 @dataclass
@@ -67,6 +69,7 @@ class RolloutEngine:
         # would clear what it reads, so it keeps the separate norm launch)
         self.fold_norm = DECODE_NORM_FOLD and engine.cfg.layers >= 2
         self.small_rows = DECODE_SMALL and engine.cfg.head_dim % 16 == 0 and engine.cfg.hidden % 32 == 0 and engine.cfg.intermediate % 32 == 0
+        self.small_fold = self.small_rows and DECODE_SMALL_FOLD and engine.cfg.hidden % 256 == 0
 
     # ------------------------------------------------------------------ decode-layout weights
     def invalidate(self) -> None:
@@ -80,9 +83,18 @@ class RolloutEngine:
         input-norm weight folded in (decode_qkv_rows16), <= 64 rows plain fragments with the norm weight folded in, else plain."""
         W, cfg = self.e.W, self.cfg
         if self._packed is None:
-            names = [f"llm.{i}.{n}" for i in range(cfg.layers) for n in ("o_w", "gu_w", "down_w")] + ["llm.lm_head"]
-            self._packed = {n: (K.pack_weight_frag_swiglu(W[n]) if n.endswith("gu_w") else K.pack_weight_frag(W[n])) for n in names}
+            names = [f"llm.{i}.{n}" for i in range(cfg.layers) for n in ("o_w", "down_w")] + ["llm.lm_head"]
+            self._packed = {n: K.pack_weight_frag(W[n]) for n in names}
         PW = self._packed
+        gu_kind = "gu_wn" if (self.small_fold and rows <= 16) else "gu_w"
+        if f"llm.0.{gu_kind}" not in PW:
+            for i in range(cfg.layers):
+                if gu_kind == "gu_wn":   # gate|up weights with the post-attention norm weight folded in: W diag(w_ln2), rounded once to bf16
+                    wf = (W[f"llm.{i}.gu_w"].float() * W[f"llm.{i}.ln2_w"].float()[None, :]).to(torch.bfloat16)
+                    PW[f"llm.{i}.gu_wn"] = K.pack_weight_frag_swiglu(wf)
+                    del wf
+                else:
+                    PW[f"llm.{i}.gu_w"] = K.pack_weight_frag_swiglu(W[f"llm.{i}.gu_w"])
         kind = "qkv_wr" if (self.small_rows and rows <= 16) else "qkv_wn" if (self.fold_norm and rows <= 64) else "qkv_w"
         if f"llm.0.{kind}" not in PW:
             for i in range(cfg.layers):
@@ -181,8 +193,11 @@ class RolloutEngine:
                 K.gemm_rows16_acc(o, PW[p + "o_w"], x, cfg.hidden)
             else:
                 K.gemm_skinny_packed_acc(o, PW[p + "o_w"], x, cfg.hidden)
-            h2 = K.rmsnorm_fwd(x, W[p + "ln2_w"], cfg.rms_eps, out=st["h"])
-            a = K.gemm_skinny_swiglu(h2, PW[p + "gu_w"], I, out=st["a"])      # gate|up GEMM + SwiGLU in one launch
+            if small and self.small_fold:      # post-attention norm folded into the gate|up launch (x itself is the A operand)
+                a = K.gemm_skinny_swiglu_normed(x, PW[p + "gu_wn"], I, cfg.rms_eps, out=st["a"])
+            else:
+                h2 = K.rmsnorm_fwd(x, W[p + "ln2_w"], cfg.rms_eps, out=st["h"])
+                a = K.gemm_skinny_swiglu(h2, PW[p + "gu_w"], I, out=st["a"])      # gate|up GEMM + SwiGLU in one launch
             if small:
                 K.gemm_rows16_acc(a, PW[p + "down_w"], x, cfg.hidden)
             else:

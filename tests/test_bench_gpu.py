@@ -70,6 +70,36 @@ def test_bench_two_ranks_control_flow_on_one_gpu(dev, algo):
     assert d["comm"]["rccl_world"] == 2 and d["comm"]["bytes_on_wire_per_gpu_per_step"] > 0 and algo.split("_")[0] in d["comm"]["algo"]
 
 
+@pytest.mark.parametrize("groups", [None, 1], ids=["2-groups-per-rank", "cfg4-style-1-group-per-rank"])
+@pytest.mark.parametrize("algo", ["allreduce", "rs_ag"])
+def test_bench_eight_ranks_on_one_gpu(dev, algo, groups):
+    """Multi-GPU readiness at the world size the driver's scaling run uses (run_SpaceR_SG_RLVR.sh:9-13 launches 8
+    ranks, zero3.json:14-33 = overlapped bf16 gradient exchange): `bench.py --gpus 8 --backend gloo` = 8 processes on the box's ONE GPU
+    (gradients staged through the host) -- shard bounds of the sharded exchange at n = 8, bucket schedule of the overlapped reducer, the
+    packed metric gather, per-rank seeds, barrier + max-over-ranks timing.  Replicas must end bit-identical and the comm object must
+    state 2 (n-1)/n x gradient bytes on the wire per GPU (all-reduce) / (n-1)/n x (gradient + weight bytes) (rs_ag), on the bf16 wire.
+    With --groups 1 every rank holds ONE prompt group per step: the reference script's own launch shape (cfg4)."""
+    from spacer_amd.qwen2vl.config import TINY
+    from spacer_amd.qwen2vl.weights import param_specs, total_numel
+    n = 8
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tiny", "--gpus", str(n), "--steps", "2", "--warmup", "1",
+           "--backend", "gloo", "--grad-algo", algo, "--check-replicas"] + (["--groups", str(groups)] if groups else [])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    g = groups or 2
+    assert d["n_gpus"] == n and d["config"]["rccl_world"] == n and d["config"]["parallelism"] == f"dp{n}" and d["config"]["grad_algo"] == algo
+    assert d["config"]["groups_per_gpu"] == g and d["config"]["global_batch"] == n * g * 4 and d["value"] > 0
+    assert d["replicas_identical"] is True
+    numel = total_numel(param_specs(TINY))
+    want = 2 * (n - 1) / n * numel * 2 if algo == "allreduce" else (n - 1) / n * (numel * 2 + numel * 2)
+    assert d["comm"]["rccl_world"] == n and d["comm"]["wire_dtype"] == "bf16"
+    assert d["comm"]["bytes_on_wire_per_gpu_per_step"] == round(want), (d["comm"], want)
+
+
 @pytest.mark.parametrize("algo", ["allreduce", "rs_ag"])
 def test_bench_rccl_branch_with_a_world_of_one(dev, algo):
     """bench.py's distributed branch over RCCL ("nccl") on the one-GPU box: --force-dist forms a process group of one rank, so the

@@ -516,6 +516,37 @@ def test_decode_qkv_projection_with_folded_rmsnorm(dev):
     assert_close(tv_b[:, 2], y[:, (Hq + Hkv) * D:].view(B, Hkv, D), 3e-2, 2e-2, "folded norm v vs fp32")
 
 
+@pytest.mark.parametrize("M,I,Kd", [(8, 18944, 3584), (16, 18944, 3584), (5, 8960, 1536), (16, 512, 256), (1, 96, 512)])
+def test_gemm_skinny_swiglu_small_rows_and_norm_fold(dev, M, I, Kd):
+    """<= 16 rows: (i) the SMALL instantiation of the decode gate|up + SwiGLU GEMM (row fragment 0 only) gives the bits of the 64-row
+    launch on the same rows; (ii) the norm-folded form -- A = the fp32 stream, rstd from the workgroup's own row sums, W diag(w) in the
+    packed weights -- equals rmsnorm + gate|up + SwiGLU to bf16 rounding and the fp32 reference."""
+    g = torch.Generator(device="cpu").manual_seed(21)
+    x = (torch.randn(M, Kd, generator=g) * 1.3).to(dev)
+    w = rnd((2 * I, Kd), dev, 22, 0.05)
+    lnw = (1.0 + 0.3 * torch.randn(Kd, generator=g)).to(dev).to(BF)
+    eps = 1e-6
+    # (i) bf16 A, SMALL vs the 64-row instantiation (rows padded to 17 take the general kernel)
+    h = K.rmsnorm_fwd(x, lnw, eps)
+    wp = K.pack_weight_frag_swiglu(w)
+    y_small = K.gemm_skinny_swiglu(h, wp, I)
+    pad = torch.zeros(17, Kd, device=dev, dtype=BF)
+    pad[:M] = h
+    y_64 = K.gemm_skinny_swiglu(pad, wp, I)[:M]
+    assert torch.equal(y_small, y_64)
+    # (ii) the fold
+    wn = K.pack_weight_frag_swiglu((w.float() * lnw.float()[None, :]).to(BF))
+    y_fold = K.gemm_skinny_swiglu_normed(x, wn, I, eps)
+    y_fold2 = K.gemm_skinny_swiglu_normed(x, wn, I, eps)
+    assert torch.equal(y_fold, y_fold2)
+    xf = x.float()
+    hn = xf * torch.rsqrt((xf ** 2).mean(1, keepdim=True) + eps) * lnw.float()
+    gu = hn @ w.float().t()
+    want = torch.nn.functional.silu(gu[:, :I]) * gu[:, I:]
+    assert_close(y_fold, want, 3e-2, 2e-2, "norm-folded gate|up + SwiGLU vs fp32")
+    assert_close(y_fold, y_small.float(), 3e-2, 3e-2, "norm-folded vs norm + gate|up + SwiGLU")
+
+
 @pytest.mark.parametrize("M", [1, 8, 13, 16])
 @pytest.mark.parametrize("N,Kd", [(3584, 3584), (3584, 18944), (1536, 8960), (64, 96), (4608, 3584)])
 def test_gemm_rows16_whole_k_workgroups(dev, M, N, Kd):
