@@ -346,6 +346,9 @@ def main():
     ap.add_argument("--precise-logps", action="store_true",
                     help="the headline step with GRPOHyper.precise_logps: policy / reference log-probs, KL and loss in the precise mode "
                          "(<= 1e-3 of fp32 at full depth); default: the fast bf16-operand path, precise step reported under variants")
+    ap.add_argument("--reuse-prefill", choices=("auto", "on", "off"), default="auto",
+                    help="the rollout's prefill keeps its tape and the policy's scoring pass takes the prompt-side forward from it "
+                         "(auto: when the tape fits beside the training state -- cfg2 / cfg4 yes, cfg3 no)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--grad-comm", choices=("fp32", "bf16"), default="bf16",
                     help="wire format of the gradient all-reduce (N > 1): bf16 as the reference's DeepSpeed bf16 mode sends them, or fp32")
@@ -426,7 +429,7 @@ def main():
     cfg = PRESETS[preset]
     hyper = GRPOHyper(num_generations=Kgen, temporal=False, len_control=True, total_steps=1000, grad_comm_bf16=args.grad_comm == "bf16",
                       overlap_comm=not args.no_overlap, recompute=args.recompute, grad_algo=args.grad_algo,
-                      precise_logps=args.precise_logps)
+                      precise_logps=args.precise_logps, reuse_prefill={"auto": None, "on": True, "off": False}[args.reuse_prefill])
     params = FlatParams.empty(cfg, dev)
     random_init_(params, seed=1234)
     ge = GRPOEngine(cfg, params, hyper, process_group=pg)
@@ -434,6 +437,7 @@ def main():
     frames = [synthetic_frames(rank * groups + g, F, Hpx, Wpx, dev) for g in range(groups)]   # resident in HBM
     phase = {}
     roll_stats = {}
+    reuse_seen = [False]
 
     def tick(name, t0):
         if args.phase_times:
@@ -461,6 +465,7 @@ def main():
         else:
             comp = ge.roll.generate(prompts, Kgen, sp, use_graph=not args.no_graph, stats=roll_stats)
         t0 = tick("rollout", t0)
+        reuse_seen[0] = reuse_seen[0] or prompts[0].prefill is not None
         advs = []
         for g in range(groups):
             cg = comp[g * Kgen:(g + 1) * Kgen]
@@ -635,6 +640,7 @@ def main():
                        "global_batch": groups * Kgen * world, "parallelism": f"dp{world}", "decode_graph": not args.no_graph,
                        "grad_comm": args.grad_comm, "grad_algo": args.grad_algo, "overlap_comm": not args.no_overlap, "backend": args.backend, "groups_per_pass": max(1, min(gpp_default, groups)),
                        "rccl_world": world, "recompute": bool(args.recompute), "precise_logps": bool(args.precise_logps),
+                       "reuse_prefill": args.reuse_prefill, "prefill_tape_kept": bool(reuse_seen[0]), "prefill_tape_gb": round(ge.roll.prefill_tape_bytes / 1e9, 1),
                        "groups_per_gpu": groups,
                        "launch_shape": ("the reference script's own: 1 prompt group (K rollouts) per GPU per step (run_SpaceR_SG_RLVR.sh:21)"
                                         if groups == 1 else f"weak scaling with {groups} prompt groups per GPU per step (decode batch {groups * Kgen} rows); "

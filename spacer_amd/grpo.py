@@ -46,6 +46,10 @@ class GRPOHyper:
     # (Qwen2VLEngine.recompute: MLP intermediates + lm_head logits; bit-identical gradients, -20 GB of saved activations per 7B
     # prompt group for one more gate|up and lm_head GEMM).  Off by default: 288 GB holds two groups per pass without it.
     recompute: bool = False
+    # the rollout's prefill keeps its tape and the policy's scoring pass takes the prompt-side forward (ViT + prompt rows) from it
+    # instead of recomputing it (the reference runs it twice: TR:463 inside generate, TR:517-541 in the scoring forward).  None = when
+    # the tape fits beside the training state (2B: yes; 7B with 8 groups per GPU: ~100 GB, no), True / False = forced
+    reuse_prefill: Optional[bool] = None
     # data-parallel gradient exchange: "allreduce" = bucketed all-reduce of the flat gradient, overlapped with the last backward, then
     # the SAME AdamW on every replica; "rs_ag" = reduce-scatter of the gradient, AdamW on the rank's 1/world shard of the
     # parameters only, all-gather of the updated bf16 weights (on the xGMI mesh every GPU talks to its 7 peers
@@ -354,6 +358,7 @@ class GRPOEngine:
         self.engine = Qwen2VLEngine(cfg, self.policy, recompute=hyper.recompute)
         self.ref_engine = Qwen2VLEngine(cfg, self.ref)
         self.roll = RolloutEngine(self.engine)
+        self.roll.keep_prefill_tape = lambda: False if (self.h.recompute or self.h.precise_logps) else self.h.reuse_prefill
         self.master = FlatParams(cfg, policy.flat.float(), policy.specs)
         self.G = policy.like(F32)
         self.m = torch.zeros_like(self.master.flat)
@@ -394,7 +399,9 @@ class GRPOEngine:
             pr = self.h.precise_logps
             ref_lp = self.ref_engine.score_group(prompt.ids, completion_ids, prompt.pix, prompt.grids, era_rule=era_rule, precise=pr)
             tape: dict = {}
-            lp = self.engine.score_group(prompt.ids, completion_ids, prompt.pix, prompt.grids, tape=tape, era_rule=era_rule, precise=pr)
+            lp = self.engine.score_groups([(prompt.ids, prompt.pix, prompt.grids)], [completion_ids], tape=tape, era_rule=era_rule, precise=pr,
+                                          prefill=[getattr(prompt, "prefill", None)])
+            prompt.prefill = None                      # (its share of the kept tape is consumed)
             if callable(advantages):           # lazy: the host shapes the rewards while the two forwards run (see _multi)
                 advantages = advantages()
                 advantages = (advantages[0] if isinstance(advantages, (list, tuple)) else advantages).to(self.dev)
@@ -426,7 +433,10 @@ class GRPOEngine:
             pr = self.h.precise_logps
             ref_lp = self.ref_engine.score_groups(entries, completions, era_rule=era_rule, precise=pr)
             tape: dict = {}
-            lp = self.engine.score_groups(entries, completions, tape=tape, era_rule=era_rule, precise=pr)
+            lp = self.engine.score_groups(entries, completions, tape=tape, era_rule=era_rule, precise=pr,
+                                          prefill=[getattr(p, "prefill", None) for p in prompts])
+            for p in prompts:
+                p.prefill = None                       # (their share of the kept tape is consumed; the last reference frees it)
             if callable(advantages):
                 advantages = advantages()
             # the loss kernel averages over its rows: G groups of K rows -> mean over G*K rows = (1/G) * sum of group means
@@ -500,6 +510,7 @@ class GRPOEngine:
                           beta2=h.adam_beta2, eps=h.adam_eps, weight_decay=h.weight_decay, step=self.step_count,
                           sumsq=self._sumsq, max_norm=h.max_grad_norm, grad_scale=gscale)
         K.zero_(self.G.flat)
+        self.engine.weights_version += 1               # a kept prefill tape belongs to the weights that produced it
         self.roll.invalidate()
         return lr
 

@@ -197,7 +197,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, trans_b: bo
     return out
 
 
-def gemm_swiglu(a: torch.Tensor, w_gu: torch.Tensor, *, bias=None, keep_gu: bool = True):
+def gemm_swiglu(a: torch.Tensor, w_gu: torch.Tensor, *, bias=None, keep_gu: bool = True, out=None, gu_out=None):
     """SwiGLU input half of an MLP: returns (act [M, I] bf16, gu [M, 2I] bf16 or None) with
     act = silu(a @ Wgate^T + b) * (a @ Wup^T + b), w_gu = [gate rows | up rows] ([2I, K]).  One launch (gate|up GEMM with the
     SwiGLU in its epilogue) when the shape runs on the 256 tile, else GEMM + swiglu_fwd; the bits are the same either way.
@@ -206,10 +206,10 @@ def gemm_swiglu(a: torch.Tensor, w_gu: torch.Tensor, *, bias=None, keep_gu: bool
     two_i = w_gu.shape[0]
     inter = two_i // 2
     if not _lib.load().spacer_gemm_swiglu_fused(M, inter, K, _plan()) or SWIGLU_UNFUSED:
-        gu = gemm_nt(a, w_gu, bias=bias)
-        return swiglu_fwd(gu), (gu if keep_gu else None)
-    act = torch.empty(M, inter, device=a.device, dtype=BF16)
-    gu = torch.empty(M, two_i, device=a.device, dtype=BF16) if keep_gu else None
+        gu = gemm_nt(a, w_gu, bias=bias, out=gu_out if keep_gu else None)
+        return swiglu_fwd(gu, out=out), (gu if keep_gu else None)
+    act = out if out is not None else torch.empty(M, inter, device=a.device, dtype=BF16)
+    gu = (gu_out if gu_out is not None else torch.empty(M, two_i, device=a.device, dtype=BF16)) if keep_gu else None
     t0 = PROFILER.begin()
     check(_lib.load().spacer_gemm_swiglu_bf16(_ptr(a), _rowmajor(a), _ptr(w_gu), _rowmajor(w_gu), _ptr(bias), _ptr(act), _rowmajor(act),
                                               _ptr(gu), _rowmajor(gu) if gu is not None else 0, M, inter, K, _stream()),

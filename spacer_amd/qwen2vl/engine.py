@@ -36,6 +36,9 @@ class Qwen2VLEngine:
         # by the SAME kernel launch as in the forward -- bit-identical gradients (tests/test_recompute_gpu.py), one more
         # gate|up GEMM per layer and one more lm_head GEMM.  17.5 + 2.5 of the 27 + 2.5 GB per 5.5k-token 7B group.
         self.recompute = recompute
+        # bumped by whoever rewrites the weights (GRPOEngine.optimizer_step): a prefill tape kept by the rollout engine is only
+        # reused by a scoring pass of the same weights
+        self.weights_version = 0
 
     # ------------------------------------------------------------------ helpers
     def _dx(self, dy: torch.Tensor, name: str) -> torch.Tensor:
@@ -478,58 +481,188 @@ class Qwen2VLEngine:
 
     def score_groups(self, prompts: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor], Optional[Sequence]]],
                      completions: Sequence[torch.Tensor], *, tape: Optional[dict] = None, era_rule: bool = False,
-                     precise: bool = False) -> torch.Tensor:
+                     precise: bool = False, prefill: Optional[Sequence] = None) -> torch.Tensor:
         """``score_group`` for SEVERAL prompt groups in ONE token-packed pass: prompts[g] = (prompt_ids, pix, grids),
         completions[g] int64 [K, C] (same K, C for all g); returns [G*K, C] in group order.  Groups are independent (their
         segments never see each other), so the numbers are the single-group ones; what changes is the launch shape: every GEMM
         sees G x the rows (fewer, fuller launches: the dW GEMMs' fp32 read-modify-write of the gradient is paid once per pass,
-        the ViT's small-K GEMMs fill the chip) at G x the activation memory (27 GB per 7B group)."""
+        the ViT's small-K GEMMs fill the chip) at G x the activation memory (27 GB per 7B group).
+        Row layout of the pass (round 5): [prompt_0 | .. | prompt_{G-1} | completions of group 0 | .. | of group G-1] -- all prompt
+        rows first, so the completion rows are ONE contiguous block.  ``prefill`` (one ``PrefillSlice`` per group, from
+        ``RolloutEngine.generate`` with ``keep_prefill_tape``): the rollout's prefill already ran the ViT and the prompt rows of THIS
+        policy with a tape -- the pass then computes the completion rows only and takes the prompt rows of every taped tensor from
+        that tape (SG_RLVR_trainer.py:463 then :517-541 run the same prompt-side forward twice; here it runs once)."""
         cfg = self.cfg
         Kn, C = completions[0].shape
-        assert all(tuple(c.shape) == (Kn, C) for c in completions) and len(prompts) == len(completions)
+        G = len(prompts)
+        assert all(tuple(c.shape) == (Kn, C) for c in completions) and G == len(completions)
         with_video = [g for g, (_, pix, _) in enumerate(prompts) if pix is not None]
-        assert len(with_video) in (0, len(prompts)), "groups of one pass either all carry vision inputs or none does"
+        assert len(with_video) in (0, G), "groups of one pass either all carry vision inputs or none does"
+        reuse = (prefill is not None and tape is not None and not precise and all(pf is not None for pf in prefill)
+                 and self._prefill_usable(prefill, prompts, era_rule))
         vit_tape = {} if tape is not None else None
         video, all_grids, unit_rev = None, [], None
         if with_video:
             all_grids = [g for _, _, gr in prompts for g in gr]
-            pix_all = prompts[0][1] if len(prompts) == 1 else torch.cat([p[1] for p in prompts], 0)
-            if precise:
-                video, unit_rev = self._vit_forward_precise(pix_all, all_grids, vit_tape)
+            if reuse:
+                video = None                              # the prompt rows' embeddings come from the prefill tape
+                vit_tape = self._vit_tape_slice(prefill)
             else:
-                video = self.vit_forward(pix_all, all_grids, vit_tape)
-        ids_parts, pos_parts, seg_list, sel_parts, scope = [], [], [], [], []
-        off = 0
-        for (prompt_ids, _, grids), comp in zip(prompts, completions):
-            P = prompt_ids.numel()
-            ids_parts += [prompt_ids.reshape(-1), comp.reshape(-1)]
+                pix_all = prompts[0][1] if G == 1 else torch.cat([p[1] for p in prompts], 0)
+                if precise:
+                    video, unit_rev = self._vit_forward_precise(pix_all, all_grids, vit_tape)
+                else:
+                    video = self.vit_forward(pix_all, all_grids, vit_tape)
+        plen = [p[0].numel() for p in prompts]
+        poff = [0]
+        for P in plen[:-1]:
+            poff.append(poff[-1] + P)
+        Pt = sum(plen)                                                     # prompt rows of the pass; completions start here
+        ids_parts = [p[0].reshape(-1) for p in prompts] + [c.reshape(-1) for c in completions]
+        pos_prompt, pos_comp, seg_list, sel_parts, scope = [], [], [], [], []
+        t = torch.arange(C)
+        for g, ((prompt_ids, _, grids), comp) in enumerate(zip(prompts, completions)):
+            P = plen[g]
             pos3, delta = POS.mrope_positions(prompt_ids.tolist(), list(grids or []), cfg, era_rule)
-            comp_pos = (P + delta) + torch.arange(C)                       # same for every rollout of the group
-            pos_parts += [pos3] + [comp_pos.view(1, C).expand(3, C)] * Kn
-            segs_g, sel_g = self.group_layout(P, Kn, C)
-            seg_list += [(off + qs, ql, off + ps if pl else 0, pl) for qs, ql, ps, pl in segs_g]
-            sel_parts.append(sel_g + off)
-            scope.append((off, off + P))
-            off += P + Kn * C
-        T = off
+            comp_pos = (P + delta) + t                                     # same for every rollout of the group
+            pos_prompt.append(pos3)
+            pos_comp += [comp_pos.view(1, C).expand(3, C)] * Kn
+            c0 = Pt + g * Kn * C                                           # first completion row of the group
+            seg_list.append((poff[g], P, 0, 0))
+            seg_list += [(c0 + k * C, C, poff[g], P) for k in range(Kn)]
+            # rows whose logits predict the completions: the prompt's last row for token 0, then the completion rows
+            sel_parts.append(torch.stack([torch.where(t == 0, torch.full_like(t, poff[g] + P - 1), c0 + k * C + t - 1) for k in range(Kn)]).reshape(-1))
+            scope.append((poff[g], poff[g] + P))
+        T = Pt + G * Kn * C
         ids = torch.cat(ids_parts)
-        cos, sin = POS.mrope_tables(torch.cat(pos_parts, dim=1), cfg, self.dev)
-        segs = K.make_segments(seg_list, self.dev)
-        sel = torch.cat(sel_parts).to(self.dev)
+        cos, sin = POS.mrope_tables(torch.cat(pos_prompt + pos_comp, dim=1), cfg, self.dev)
+        sel = torch.cat(sel_parts).int().to(self.dev)
         max_q = max(s[1] for s in seg_list)
         targets = torch.cat([c.reshape(-1) for c in completions]).contiguous()
         llm_tape = [] if tape is not None else None
-        if precise:
-            x0, vrow = self.embed(ids, video, placeholder_scopes=scope, unit_rev=unit_rev)
-            x = self._llm_forward_precise(x0, cos, sin, segs, max_q, tape=llm_tape)
+        if reuse:
+            # placeholders sit in the prompt rows only: the vision-row map for embed_bwd is computed from the ids, no embedding of them
+            _, vrow = self._vision_rows(ids, scope) if with_video else (None, None)
+            xc = K.embed_fwd(ids[Pt:], self.W["llm.embed"], None, None)      # completion rows are ordinary tokens
+            comp_segs = [s for s in seg_list if s[3] > 0]
+            x = self._llm_forward_reuse(xc, cos, sin, K.make_segments(comp_segs, self.dev), C, Pt, prefill, llm_tape)
+            segs = K.make_segments(seg_list, self.dev)
         else:
-            x0, vrow = self.embed(ids, video, placeholder_scopes=scope)
-            x = self.llm_forward(x0, cos, sin, segs, max_q, tape=llm_tape)
+            segs = K.make_segments(seg_list, self.dev)
+            if precise:
+                x0, vrow = self.embed(ids, video, placeholder_scopes=scope, unit_rev=unit_rev)
+                x = self._llm_forward_precise(x0, cos, sin, segs, max_q, tape=llm_tape)
+            else:
+                x0, vrow = self.embed(ids, video, placeholder_scopes=scope)
+                x = self.llm_forward(x0, cos, sin, segs, max_q, tape=llm_tape)
         logp = self.head_forward(x, sel, targets, tape, precise=precise)
         if tape is not None:
             tape.update(vit=vit_tape, llm=llm_tape, ids=ids, vrow=vrow, cos=cos, sin=sin, segs=segs, max_q=max_q, T=T,
-                        has_video=video is not None)
-        return logp.view(len(prompts) * Kn, C)
+                        has_video=bool(with_video), reused_prefill=reuse)
+        return logp.view(G * Kn, C)
+
+    # ------------------------------------------------------------------ prompt-side forward taken from the rollout's prefill
+    def _vision_rows(self, ids: torch.Tensor, scopes):
+        """(None, vrow): the token -> vision-row map of ``embed`` without embedding anything."""
+        cfg = self.cfg
+        is_vis = (ids == cfg.video_token_id) | (ids == cfg.image_token_id)
+        inside = torch.zeros_like(is_vis)
+        for a, b in scopes:
+            inside[a:b] = True
+        is_vis &= inside
+        vrow = torch.where(is_vis, torch.cumsum(is_vis.int(), 0, dtype=torch.int32) - 1, torch.full_like(ids, -1, dtype=torch.int32)).int().contiguous()
+        return None, vrow
+
+    def _prefill_usable(self, prefill, prompts, era_rule) -> bool:
+        """The slices must come from ONE prefill pass of this engine's current weights, cover consecutive prompts of that pass in
+        order, be taped with the stored policy, and describe the same prompts."""
+        first = prefill[0]
+        sh = first.shared
+        if self.recompute or self.cfg.vit_kind != "qwen2" or sh.get("engine") is not self or sh.get("era_rule") != era_rule:
+            return False
+        if sh.get("weights_version") != self.weights_version:
+            return False
+        for j, (pf, pr) in enumerate(zip(prefill, prompts)):
+            if pf.shared is not sh or pf.index != first.index + j or pf.P != pr[0].numel():
+                return False
+            if (pr[1] is None) != (pf.n_patch == 0):
+                return False
+        return True
+
+    @staticmethod
+    def _rows(arr: Optional[torch.Tensor], a: int, b: int):
+        return None if arr is None else arr[a:b]
+
+    def _vit_tape_slice(self, prefill) -> dict:
+        """The vision tower's tape of the pass = row slices (views) of the prefill's tape: patches [a, b) of the packed pass."""
+        sh = prefill[0].shared
+        vt = sh["vit"]
+        a, b = prefill[0].patch0, prefill[-1].patch0 + prefill[-1].n_patch
+        m4 = self.cfg.merge ** 2
+        R = self._rows
+        blocks = []
+        for t in vt["blocks"]:
+            # (lse is [heads, patches]: attn_bwd reads it with a row stride of the pass's patch count, so its column slice is copied)
+            blocks.append({k: (v[:, a:b].contiguous() if k == "lse" else R(v, a, b)) for k, v in t.items()})
+        seg_list = [(qs - a, ql, 0, 0) for (qs, ql, _, _) in sh["vit_segments"] if a <= qs < b]
+        out = dict(pix=R(vt["pix"], a, b), blocks=blocks, x_last=R(vt["x_last"], a, b), mean=R(vt["mean"], a, b), rstd=R(vt["rstd"], a, b),
+                   hm4=R(vt["hm4"], a // m4, b // m4), m1=R(vt["m1"], a // m4, b // m4), g=R(vt["g"], a // m4, b // m4),
+                   cos=R(vt["cos"], a, b), sin=R(vt["sin"], a, b), segs=K.make_segments(seg_list, self.dev), max_q=vt["max_q"])
+        return out
+
+    def _llm_forward_reuse(self, xc: torch.Tensor, cos, sin, comp_segs, max_q: int, Pt: int, prefill, tape: list) -> torch.Tensor:
+        """``llm_forward`` (taped) of a pass whose prompt rows [0, Pt) were already computed and taped by the rollout's prefill: only
+        the completion rows [Pt, T) run through the layer's kernels; they attend the prompts' keys / values, which are copied from
+        the prefill tape together with the prompt rows of every other taped tensor (the backward reads whole [T, features] arrays;
+        GEMM outputs land directly in the completion rows of those arrays).  Row-wise kernels and GEMM rows do not depend on the
+        other rows of a launch, so every number equals the full pass's bit for bit when the GEMM's K-split tail is off.  Returns
+        the pre-final-norm stream [T, hidden]."""
+        cfg, W = self.cfg, self.W
+        Hq, Hkv, D = cfg.heads, cfg.kv_heads, cfg.head_dim
+        qd, kd = Hq * D, Hkv * D
+        Tc = xc.shape[0]
+        T = Pt + Tc
+        scale = D ** -0.5
+        sh = prefill[0].shared
+        r0, r1 = prefill[0].row0, prefill[-1].row0 + prefill[-1].P
+        assert r1 - r0 == Pt
+        cos_c, sin_c = cos[Pt:], sin[Pt:]
+
+        def full(cached: torch.Tensor):
+            """[T, F] buffer whose prompt rows are the prefill's; returns (buffer, the view of its completion rows)."""
+            buf = torch.empty(T, *cached.shape[1:], device=self.dev, dtype=cached.dtype)
+            buf[:Pt].copy_(cached[r0:r1])
+            return buf, buf[Pt:]
+
+        x_in, x = full(sh["llm"][0]["x_in"])
+        x.copy_(xc)
+        for i in range(cfg.layers):
+            p = f"llm.{i}."
+            c = sh["llm"][i]
+            rstd1, rstd1_c = full(c["rstd1"])
+            h, h_c = full(c["h"])
+            K.rmsnorm_fwd(x, W[p + "ln1_w"], cfg.rms_eps, rstd=rstd1_c, out=h_c)
+            qkv, qkv_c = full(c["qkv"])                                     # the prompts' post-rotary keys / values
+            K.gemm_nt(h_c, W[p + "qkv_w"], bias=W[p + "qkv_b"], out=qkv_c)
+            K.rope_(qkv_c, cos_c, sin_c, Hq + Hkv, D)
+            o, o_c = full(c["o"])
+            lse = self._empty(Hq, T)
+            lse[:, :Pt].copy_(c["lse"][:, r0:r1])
+            K.attn_fwd(qkv[:, :qd], qkv[:, qd:qd + kd], qkv[:, qd + kd:], comp_segs, max_q, Hq, Hkv, D, True, scale, out=o, lse=lse)
+            x_mid, x_mid_c = full(c["x_mid"])
+            rstd2, rstd2_c = full(c["rstd2"])
+            h2, h2_c = full(c["h2"])
+            K.gemm_nt(o_c, W[p + "o_w"], residual=x, out=x_mid_c, out_dtype=F32)
+            K.rmsnorm_fwd(x_mid_c, W[p + "ln2_w"], cfg.rms_eps, rstd=rstd2_c, out=h2_c)
+            gu, gu_c = full(c["gu"])
+            a, a_c = full(c["a"])
+            K.gemm_swiglu(h2_c, W[p + "gu_w"], keep_gu=True, out=a_c, gu_out=gu_c)
+            # the layer's output goes straight into the completion rows of the NEXT layer's x_in (or of the final stream)
+            nxt, nxt_c = full(sh["llm"][i + 1]["x_in"] if i + 1 < cfg.layers else sh["x_final"])
+            K.gemm_nt(a_c, W[p + "down_w"], residual=x_mid_c, out=nxt_c, out_dtype=F32)
+            tape.append(dict(x_in=x_in, rstd1=rstd1, h=h, qkv=qkv, o=o, lse=lse, x_mid=x_mid, rstd2=rstd2, h2=h2, gu=gu, a=a))
+            x_in, x = nxt, nxt_c
+        return x_in
 
     # ================================================================== head: final norm -> lm_head -> log-prob of the targets
     def head_forward(self, x: torch.Tensor, sel: torch.Tensor, targets: torch.Tensor, tape: Optional[dict] = None, *,

@@ -41,6 +41,22 @@ class PromptInput:
     # ROLLOUT positions only -- the reference deletes it before its scoring forwards (SG_RLVR_trainer.py:519-520), so
     # scoring spaces the temporal positions by the default 1 s.
     second_per_grid_ts: Optional[Sequence[float]] = None
+    # set by RolloutEngine.generate when it keeps the prefill's tape: the policy's scoring pass of this prompt takes its prompt-side
+    # forward (ViT + prompt rows) from it instead of recomputing (Qwen2VLEngine.score_groups(prefill=...))
+    prefill: Optional["PrefillSlice"] = None
+
+
+@dataclass
+class PrefillSlice:
+    """One prompt's share of a kept prefill tape (``RolloutEngine.keep_prefill_tape``): ``shared`` = the packed pass's tapes
+    ({"vit": ..., "llm": [...], "x_final", "vit_segments", "engine", "weights_version", "era_rule"}), this prompt = rows
+    [row0, row0 + P) of the LLM arrays and patches [patch0, patch0 + n_patch) of the vision arrays; ``index`` = its position in the pass."""
+    shared: dict
+    index: int
+    row0: int
+    P: int
+    patch0: int
+    n_patch: int
 
 
 @dataclass
@@ -70,6 +86,12 @@ class RolloutEngine:
         self.fold_norm = DECODE_NORM_FOLD and engine.cfg.layers >= 2
         self.small_rows = DECODE_SMALL and engine.cfg.head_dim % 16 == 0 and engine.cfg.hidden % 32 == 0 and engine.cfg.intermediate % 32 == 0
         self.small_fold = self.small_rows and DECODE_SMALL_FOLD and engine.cfg.hidden % 256 == 0
+        # keep the prefill's tape (ViT + prompt rows of every layer) for the policy's scoring pass: None = when it fits (the tape must
+        # live through the decode loop beside the training state: ~100 GB for 8 cfg3 groups at 7B -- no; 12 GB for cfg2 at 2B -- yes),
+        # True / False = forced.  Only the stored (non-recompute) policy of the Qwen2-VL tower is eligible.
+        # (may also be a callable returning one of those, evaluated per generate call: GRPOEngine ties it to its live hyper-parameters)
+        self.keep_prefill_tape = False
+        self.prefill_tape_bytes = 0
 
     # ------------------------------------------------------------------ decode-layout weights
     def invalidate(self) -> None:
@@ -109,9 +131,25 @@ class RolloutEngine:
         return PW
 
     # ------------------------------------------------------------------ prefill
-    def _prefill(self, prompts: List[PromptInput], era_rule: bool):
+    def _tape_fits(self, prompts: List[PromptInput]) -> bool:
+        """Would the prefill tape of these prompts fit beside what is allocated now, with room for the scoring passes' own tapes?
+        Estimate: bytes per token and decoder layer of llm_forward's tape + bytes per patch and vision block of vit_forward's."""
+        cfg = self.cfg
+        per_tok = cfg.layers * (2 * 4 * cfg.hidden + 2 * (2 * cfg.hidden + cfg.qkv_dim + cfg.heads * cfg.head_dim + 3 * cfg.intermediate) + 8 + 4 * cfg.heads)
+        per_patch = cfg.vit_depth * (2 * 4 * cfg.vit_dim + 2 * (6 * cfg.vit_dim + 2 * cfg.vit_mlp) + 16 + 4 * cfg.vit_heads)
+        toks = sum(p.ids.numel() for p in prompts)
+        patches = sum(p.pix.shape[0] for p in prompts if p.pix is not None)
+        need = toks * per_tok + patches * per_patch
+        self.prefill_tape_bytes = need
+        free, total = torch.cuda.mem_get_info(self.dev)
+        free += torch.cuda.memory_reserved(self.dev) - torch.cuda.memory_allocated(self.dev)      # the caching allocator's own pool
+        # the scoring passes that follow need ~ (K C / P + 1) x the tape of their groups on top of it; keep a third of the part free
+        return need * 4 < free and need < 0.15 * total
+
+    def _prefill(self, prompts: List[PromptInput], era_rule: bool, keep_tape: bool = False):
         """ViT + LLM prefill of ALL prompts as one token-packed pass (one attention segment per prompt, one set of GEMMs
-        with M = total prompt tokens): the reference runs this per rollout inside HF generate (TR:463)."""
+        with M = total prompt tokens): the reference runs this per rollout inside HF generate (TR:463).  ``keep_tape``: the pass
+        is taped like a scoring pass and every prompt receives its ``PrefillSlice``."""
         cfg, e = self.cfg, self.e
         L, Hkv, D = cfg.layers, cfg.kv_heads, cfg.head_dim
         nP = len(prompts)
@@ -130,9 +168,10 @@ class RolloutEngine:
         gidx = gidx.reshape(-1).to(self.dev)
         with_video = [p for p in prompts if p.pix is not None]
         video = None
+        vit_tape, llm_tape = ({} if keep_tape else None), ([] if keep_tape else None)
         if with_video:
             pix = with_video[0].pix if len(with_video) == 1 else torch.cat([p.pix for p in with_video], 0)
-            video = e.vit_forward(pix, [g for p in with_video for g in p.grids])
+            video = e.vit_forward(pix, [g for p in with_video for g in p.grids], vit_tape)
         ids = prompts[0].ids if nP == 1 else torch.cat([p.ids for p in prompts], 0)
         x0, _ = e.embed(ids, video)               # video rows fill the placeholder tokens in prompt order
         pos_list, pos_base = [], []
@@ -147,7 +186,15 @@ class RolloutEngine:
             K.gather_rows(k, gidx, out=pk[layer].view(nP * Pmax, Hkv * D))
             K.gather_rows(v, gidx, out=pv[layer].view(nP * Pmax, Hkv * D))
 
-        x = e.llm_forward(x0, cos, sin, segs, Pmax, kv_sink=sink)
+        x = e.llm_forward(x0, cos, sin, segs, Pmax, kv_sink=sink, tape=llm_tape)
+        if keep_tape:
+            shared = dict(vit=vit_tape, llm=llm_tape, x_final=x, engine=e, weights_version=e.weights_version, era_rule=era_rule,
+                          vit_segments=POS.vit_segments([g for p in with_video for g in p.grids]) if with_video else [])
+            patch0 = 0
+            for pi, (pr, s0, P) in enumerate(zip(prompts, starts, plen)):
+                npatch = pr.pix.shape[0] if pr.pix is not None else 0
+                pr.prefill = PrefillSlice(shared, pi, s0, P, patch0, npatch)
+                patch0 += npatch
         last = torch.tensor([s0 + P - 1 for s0, P in zip(starts, plen)], dtype=torch.int64, device=self.dev)
         hn = K.rmsnorm_fwd(x.index_select(0, last), e.W["llm.norm_w"], cfg.rms_eps)
         first_logits = K.gemm_nt(hn, e.W["llm.lm_head"], out_dtype=F32)
@@ -235,7 +282,17 @@ class RolloutEngine:
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if stats is not None else None
         if ev:
             ev[0].record()
-        pk, pv, first_logits, plen, pos_base = self._prefill(prompts, sp.era_rule)
+        for pr in prompts:
+            pr.prefill = None
+        keep = self.keep_prefill_tape() if callable(self.keep_prefill_tape) else self.keep_prefill_tape
+        eligible = (not self.e.recompute and cfg.vit_kind == "qwen2" and all((p.pix is None) == (prompts[0].pix is None) for p in prompts))
+        if keep is not False and eligible:
+            fits = self._tape_fits(prompts)               # (also records the tape's estimated size)
+            keep = fits if keep is None else keep
+        keep = bool(keep) and eligible
+        if not keep:
+            self.prefill_tape_bytes = 0
+        pk, pv, first_logits, plen, pos_base = self._prefill(prompts, sp.era_rule, keep_tape=keep)
         if ev:
             ev[1].record()
         L, Hkv, D, H = cfg.layers, cfg.kv_heads, cfg.head_dim, cfg.hidden
