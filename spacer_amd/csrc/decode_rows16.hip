@@ -38,59 +38,80 @@ struct Rows16Args {
     float eps;
 };
 
-template <int EPI, bool NORMA, int DEPTH>
-__global__ __launch_bounds__(256, 2) void gemm_rows16_kernel(Rows16Args a) {
-    __shared__ float4 part[4][64];
-    __shared__ float rowss[4][16];
+template <int EPI, bool NORMA, int DEPTH, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void gemm_rows16_kernel(Rows16Args a) {
+    __shared__ float4 part[NW][64];
+    __shared__ float rowss[NW][16];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
     const int nb = blockIdx.x;                                  // fragment column
     const int nsteps = a.K >> 5;
-    const bool row_ok = l15 < a.M;
-    const bf16_t* wbase = a.Bp + ((long)nb * nsteps) * 512 + lane * 8;
-    const char* abase = (const char*)a.A + (long)l15 * a.lda * (NORMA ? 4 : 2) + g * 8 * (NORMA ? 4 : 2);
-
+    const int S = (nsteps - wave + NW - 1) / NW;                // k-steps of this wave: u = wave + NW j, j < S (wave-uniform)
+    // rows >= M of the MFMA tile compute garbage that is never stored (an output row depends on its own A row only): the row index is
+    // clamped for address validity, nothing is zeroed
+    const int arow = l15 < a.M ? l15 : a.M - 1;
+    // addresses = wave-uniform 64-bit base (SGPR pair, advanced per k-step by scalar adds) + a fixed 32-bit lane offset (one VGPR each
+    // for the weights and for A): the ring's loads cost no address registers
+    const bf16_t* wbase = a.Bp + ((long)nb * nsteps) * 512;                         // + u * 512 elements per k-step
+    const unsigned woff = lane * 16;
+    const char* abase = (const char*)a.A;                                            // + u * 32 elements per k-step
+    const unsigned aoff = (unsigned)(((long)arow * a.lda + g * 8) * (NORMA ? 4 : 2));
+    // The K loop is BRANCH-FREE: a ring of DEPTH (weight fragment, A fragment) loads per wave stays in flight from the first
+    // instruction on; past the wave's last k-step the ring slots are refilled from the first KiB of the weights / the first k-step of A
+    // (always the same cached lines) and their products are masked out, so the compiler's vmcnt bookkeeping never meets a control-flow merge
+    // (with `if (u < nsteps)` around the loads it drained the queue -- vmcnt(0) -- every ring round: 40 us for the 7B down projection
+    // against 25 us for the K-split kernel it was meant to beat).
+    // Loads and waits are inline asm with COUNTED vmcnt: through the builtins hipcc's waitcnt pass gives up at the loop back-edge and
+    // puts one vmcnt(0) at the top of every ring round (the queue drains DEPTH steps at a time).  VMEM returns are in order, so after
+    // vmcnt(LPS (DEPTH - 1)) the oldest slot's LPS loads have landed; the wait takes the slot's registers as in/out operands so
+    // that the MFMA cannot be scheduled above it.
+    constexpr int LPS = NORMA ? 3 : 2;                          // loads per k-step
     r16_u32x4 w[DEPTH];
-    uint4 ab[NORMA ? 1 : DEPTH];
-    float4 af[NORMA ? DEPTH : 1][2];
-    auto issue = [&](int i, int u) {                            // k-step u into ring slot i
-        w[i] = __builtin_nontemporal_load((const r16_u32x4*)(wbase + (long)u * 512));
+    r16_u32x4 ab[NORMA ? 1 : DEPTH];
+    r16_u32x4 af[NORMA ? DEPTH : 1][2];
+    auto issue = [&](int i, int j) {                            // k-step j of this wave into ring slot i
+        const bool ok = j < S;
+        const long u = wave + NW * (long)j;
+        const bf16_t* wp = ok ? wbase + u * 512 : a.Bp;           // scalar selects
+        asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(w[i]) : "v"(woff), "s"(wp) : "memory");
         if (NORMA) {
-            const float* p = (const float*)(abase + (long)u * 32 * 4);
-            af[NORMA ? i : 0][0] = row_ok ? *(const float4*)p : make_float4(0.f, 0.f, 0.f, 0.f);
-            af[NORMA ? i : 0][1] = row_ok ? *(const float4*)(p + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const char* p = ok ? abase + u * 32 * 4 : abase;
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(af[NORMA ? i : 0][0]) : "v"(aoff), "s"(p) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(af[NORMA ? i : 0][1]) : "v"(aoff), "s"(p) : "memory");
         } else {
-            ab[NORMA ? 0 : i] = row_ok ? *(const uint4*)(abase + (long)u * 32 * 2) : make_uint4(0, 0, 0, 0);
+            const char* p = ok ? abase + u * 32 * 2 : abase;
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ab[NORMA ? 0 : i]) : "v"(aoff), "s"(p) : "memory");
         }
     };
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
     float ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < DEPTH; ++i) {
-        const int u = wave + 4 * i;
-        if (u < nsteps) issue(i, u);
-    }
-    for (int j0 = 0; wave + 4 * j0 < nsteps; j0 += DEPTH) {
+    for (int i = 0; i < DEPTH; ++i) issue(i, i);
+    for (int j0 = 0; j0 < S; j0 += DEPTH) {
 #pragma unroll
         for (int i = 0; i < DEPTH; ++i) {
-            const int u = wave + 4 * (j0 + i);
-            if (u < nsteps) {
-                bf16x8 av;
-                if (NORMA) {
-                    const float4 lo = af[NORMA ? i : 0][0], hi = af[NORMA ? i : 0][1];
-                    ss += lo.x * lo.x + lo.y * lo.y + lo.z * lo.z + lo.w * lo.w + hi.x * hi.x + hi.y * hi.y + hi.z * hi.z + hi.w * hi.w;
-                    av = __builtin_bit_cast(bf16x8, make_uint4(pack_bf2(lo.x, lo.y), pack_bf2(lo.z, lo.w), pack_bf2(hi.x, hi.y), pack_bf2(hi.z, hi.w)));
-                } else {
-                    av = __builtin_bit_cast(bf16x8, ab[NORMA ? 0 : i]);
-                }
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, w[i]), acc, 0, 0, 0);   // D[m = g*4 + r][n = l15]
-                const int un = u + 4 * DEPTH;
-                if (un < nsteps) issue(i, un);
+            const bool ok = j0 + i < S;                          // wave-uniform: a scalar select, not a branch
+            if (NORMA) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(w[i]), "+v"(af[NORMA ? i : 0][0]), "+v"(af[NORMA ? i : 0][1]) : "n"(LPS * (DEPTH - 1)));
+            else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[i]), "+v"(ab[NORMA ? 0 : i]) : "n"(LPS * (DEPTH - 1)));
+            bf16x8 av;
+            if (NORMA) {
+                const float4 lo = __builtin_bit_cast(float4, af[NORMA ? i : 0][0]), hi = __builtin_bit_cast(float4, af[NORMA ? i : 0][1]);
+                const float q = lo.x * lo.x + lo.y * lo.y + lo.z * lo.z + lo.w * lo.w + hi.x * hi.x + hi.y * hi.y + hi.z * hi.z + hi.w * hi.w;
+                ss += ok ? q : 0.f;
+                av = __builtin_bit_cast(bf16x8, make_uint4(pack_bf2(lo.x, lo.y), pack_bf2(lo.z, lo.w), pack_bf2(hi.x, hi.y), pack_bf2(hi.z, hi.w)));
+            } else {
+                av = __builtin_bit_cast(bf16x8, ab[NORMA ? 0 : i]);
             }
+            const r16_u32x4 wz = ok ? w[i] : (r16_u32x4){0u, 0u, 0u, 0u};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, wz), acc, 0, 0, 0);   // D[m = g*4 + r][n = l15]
+            __builtin_amdgcn_sched_barrier(0);                   // the slot's registers are read before its refill is issued
+            issue(i, j0 + i + DEPTH);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
-    // ---- the four K-interleaved partial sums (and row sums of x^2) meet in LDS; wave 0 finishes
+    // ---- the NW K-interleaved partial sums (and row sums of x^2) meet in LDS; wave 0 finishes
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (the ring's trailing dummy loads)
     part[wave][lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
     if (NORMA) {
         ss += __shfl_xor(ss, 16, 64);
@@ -99,11 +120,11 @@ __global__ __launch_bounds__(256, 2) void gemm_rows16_kernel(Rows16Args a) {
     }
     __syncthreads();
     if (wave != 0) return;
-    float v[4];
-    {
-        const float4 p0 = part[0][lane], p1 = part[1][lane], p2 = part[2][lane], p3 = part[3][lane];
-        v[0] = (p0.x + p1.x) + (p2.x + p3.x); v[1] = (p0.y + p1.y) + (p2.y + p3.y);
-        v[2] = (p0.z + p1.z) + (p2.z + p3.z); v[3] = (p0.w + p1.w) + (p2.w + p3.w);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w_ = 0; w_ < NW; ++w_) {
+        const float4 p = part[w_][lane];
+        v[0] += p.x; v[1] += p.y; v[2] += p.z; v[3] += p.w;
     }
     const int n = nb * 16 + l15;
     if (EPI == R16_ACC || EPI == R16_STORE) {
@@ -128,7 +149,9 @@ __global__ __launch_bounds__(256, 2) void gemm_rows16_kernel(Rows16Args a) {
         const int m = g * 4 + r;
         float x = v[r];
         if (NORMA) {
-            const float s2 = (rowss[0][m] + rowss[1][m]) + (rowss[2][m] + rowss[3][m]);
+            float s2 = 0.f;
+#pragma unroll
+            for (int w_ = 0; w_ < NW; ++w_) s2 += rowss[w_][m];
             x *= rsqrtf(s2 / (float)a.K + a.eps);
         }
         x += bv;
@@ -173,7 +196,8 @@ __global__ __launch_bounds__(256) void pack_frag_rope_kernel(const bf16_t* __res
     }
 }
 
-constexpr int R16_DEPTH = 14;
+constexpr int R16_DEPTH = 12, R16_NW = 8;        // bf16 A: 8 waves x 12 KiB of weights in flight per workgroup (120 VGPRs)
+constexpr int R16_DEPTH_N = 8, R16_NW_N = 4;    // fp32 A (norm fold): 12 registers per ring slot -> 4 waves x 14
 
 }  // namespace
 
@@ -197,8 +221,8 @@ extern "C" int spacer_gemm_rows16_packed_bf16(const void* A, long lda, const voi
                "gemm_rows16: need 0 < M <= 16, N %% 16 == 0, K %% 32 == 0, lda %% 8 == 0 (M=%d N=%d K=%d)", M, N, K);
     Rows16Args a = {};
     a.A = A; a.lda = lda; a.Bp = (const bf16_t*)Bpacked; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
-    if (store) hipLaunchKernelGGL((gemm_rows16_kernel<R16_STORE, false, R16_DEPTH>), dim3(N / 16), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((gemm_rows16_kernel<R16_ACC, false, R16_DEPTH>), dim3(N / 16), dim3(256), 0, (hipStream_t)stream, a);
+    if (store) hipLaunchKernelGGL((gemm_rows16_kernel<R16_STORE, false, R16_DEPTH, R16_NW>), dim3(N / 16), dim3(R16_NW * 64), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((gemm_rows16_kernel<R16_ACC, false, R16_DEPTH, R16_NW>), dim3(N / 16), dim3(R16_NW * 64), 0, (hipStream_t)stream, a);
     SP_CHECK_LAUNCH();
     return SPACER_OK;
 }
@@ -215,7 +239,7 @@ extern "C" int spacer_decode_qkv_rows16(const float* x32, long ldx, const void* 
     a.A = x32; a.lda = ldx; a.Bp = (const bf16_t*)Wp_rope; a.M = M; a.N = (Hq + 2 * Hkv) * D; a.K = K;
     a.bias = (const bf16_t*)bias; a.cos_t = cos_t; a.sin_t = sin_t; a.q_out = (bf16_t*)q_out; a.tail_k = (bf16_t*)tail_k;
     a.tail_v = (bf16_t*)tail_v; a.tail_len = tail_len_dev; a.Hq = Hq; a.Hkv = Hkv; a.D = D; a.Cmax = Cmax; a.eps = eps;
-    hipLaunchKernelGGL((gemm_rows16_kernel<R16_QKV, true, R16_DEPTH>), dim3(a.N / 16), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((gemm_rows16_kernel<R16_QKV, true, R16_DEPTH_N, R16_NW_N>), dim3(a.N / 16), dim3(R16_NW_N * 64), 0, (hipStream_t)stream, a);
     SP_CHECK_LAUNCH();
     return SPACER_OK;
 }

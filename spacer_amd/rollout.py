@@ -25,12 +25,12 @@ from .qwen2vl.engine import Qwen2VLEngine
 
 BF16, F32 = torch.bfloat16, torch.float32
 DECODE_NORM_FOLD = os.environ.get("SPACER_DECODE_NORM", "fold") != "separate"     # A/B switch, read once at import
-# decode batches of <= 16 rows (cfg4 = the reference script's 1 prompt group per GPU; cfg2): whole-K workgroups without split-K atomics,
-# q|k|v norm + projection + bias + rotary + cache append in one launch (csrc/decode_rows16.hip).  SPACER_DECODE_SMALL=off: the 64-row kernels
-DECODE_SMALL = os.environ.get("SPACER_DECODE_SMALL", "on") != "off"
-# ... and the post-attention RMSNorm folded into the gate|up projection of such a batch (SPACER_DECODE_SMALL=nofold keeps the norm launch)
-DECODE_SMALL_FOLD = os.environ.get("SPACER_DECODE_SMALL", "on") not in ("off", "nofold")
-
+# decode batches of <= 16 rows (cfg4 = the reference script's 1 prompt group per GPU; cfg2): which of the small-row forms run
+# (comma list, read once): "fold" = post-attention RMSNorm folded into the gate|up + SwiGLU launch (gemm_skinny_kernel SMALL + NORMA);
+# "qkv" / "o" / "down" = that projection as whole-K workgroups without split-K atomics (csrc/decode_rows16.hip; qkv = norm + projection
+# + bias + rotary + cache append in one launch); "off" = the 64-row kernels throughout.  Default = what measured faster.
+_SMALL = set(filter(None, os.environ.get("SPACER_DECODE_SMALL", "fold").replace("on", "fold,qkv,o,down").split(",")))
+DECODE_SMALL_FOLD, DECODE_SMALL_QKV, DECODE_SMALL_O, DECODE_SMALL_DOWN = ("fold" in _SMALL, "qkv" in _SMALL, "o" in _SMALL, "down" in _SMALL)
 
 @dataclass
 class PromptInput:
@@ -84,8 +84,10 @@ class RolloutEngine:
         # (the finishing kernel of layer i clears the row sums of layer (i + 1) % layers while it reads layer i's: a one-layer model
         # would clear what it reads, so it keeps the separate norm launch)
         self.fold_norm = DECODE_NORM_FOLD and engine.cfg.layers >= 2
-        self.small_rows = DECODE_SMALL and engine.cfg.head_dim % 16 == 0 and engine.cfg.hidden % 32 == 0 and engine.cfg.intermediate % 32 == 0
-        self.small_fold = self.small_rows and DECODE_SMALL_FOLD and engine.cfg.hidden % 256 == 0
+        c = engine.cfg
+        ok16 = c.head_dim % 16 == 0 and c.hidden % 32 == 0 and c.intermediate % 32 == 0
+        self.small_qkv, self.small_o, self.small_down = (DECODE_SMALL_QKV and ok16, DECODE_SMALL_O and ok16, DECODE_SMALL_DOWN and ok16)
+        self.small_fold = DECODE_SMALL_FOLD and c.hidden % 256 == 0
         # keep the prefill's tape (ViT + prompt rows of every layer) for the policy's scoring pass: None = when it fits (the tape must
         # live through the decode loop beside the training state: ~100 GB for 8 cfg3 groups at 7B -- no; 12 GB for cfg2 at 2B -- yes),
         # True / False = forced.  Only the stored (non-recompute) policy of the Qwen2-VL tower is eligible.
@@ -117,7 +119,7 @@ class RolloutEngine:
                     del wf
                 else:
                     PW[f"llm.{i}.gu_w"] = K.pack_weight_frag_swiglu(W[f"llm.{i}.gu_w"])
-        kind = "qkv_wr" if (self.small_rows and rows <= 16) else "qkv_wn" if (self.fold_norm and rows <= 64) else "qkv_w"
+        kind = "qkv_wr" if (self.small_qkv and rows <= 16) else "qkv_wn" if (self.fold_norm and rows <= 64) else "qkv_w"
         if f"llm.0.{kind}" not in PW:
             for i in range(cfg.layers):
                 if kind == "qkv_wr":     # fragments pair the rotary halves of one head; W diag(w_ln1) folded in, rounded once to bf16
@@ -212,7 +214,7 @@ class RolloutEngine:
         scale = D ** -0.5
         for i in range(cfg.layers):
             p = f"llm.{i}."
-            if self.small_rows and B <= 16:
+            if self.small_qkv and B <= 16:
                 # <= 16 rows: input norm + q|k|v + bias + rotary + cache append in ONE launch of whole-K workgroups (no split-K atomics,
                 # no fp32 accumulator, no finishing kernel)
                 K.decode_qkv_rows16(x, PW[p + "qkv_wr"], W[p + "qkv_b"], st["cos"], st["sin"], st["q"], st["tk"][i], st["tv"][i],
@@ -235,17 +237,16 @@ class RolloutEngine:
             else:
                 o = K.attn_decode(st["q"], st["pk"][i], st["pv"][i], st["plen"], st["prompt_of"], st["tk"][i], st["tv"][i],
                                   st["tail_len"], Hq, Hkv, D, scale, out=st["o"])
-            small = self.small_rows and B <= 16
-            if small:
+            if self.small_o and B <= 16:
                 K.gemm_rows16_acc(o, PW[p + "o_w"], x, cfg.hidden)
             else:
                 K.gemm_skinny_packed_acc(o, PW[p + "o_w"], x, cfg.hidden)
-            if small and self.small_fold:      # post-attention norm folded into the gate|up launch (x itself is the A operand)
+            if self.small_fold and B <= 16:    # post-attention norm folded into the gate|up launch (x itself is the A operand)
                 a = K.gemm_skinny_swiglu_normed(x, PW[p + "gu_wn"], I, cfg.rms_eps, out=st["a"])
             else:
                 h2 = K.rmsnorm_fwd(x, W[p + "ln2_w"], cfg.rms_eps, out=st["h"])
                 a = K.gemm_skinny_swiglu(h2, PW[p + "gu_w"], I, out=st["a"])      # gate|up GEMM + SwiGLU in one launch
-            if small:
+            if self.small_down and B <= 16:
                 K.gemm_rows16_acc(a, PW[p + "down_w"], x, cfg.hidden)
             else:
                 K.gemm_skinny_packed_acc(a, PW[p + "down_w"], x, cfg.hidden)

@@ -539,12 +539,21 @@ def test_gemm_skinny_swiglu_small_rows_and_norm_fold(dev, M, I, Kd):
     y_fold = K.gemm_skinny_swiglu_normed(x, wn, I, eps)
     y_fold2 = K.gemm_skinny_swiglu_normed(x, wn, I, eps)
     assert torch.equal(y_fold, y_fold2)
+    # exact algebra of the fold on the operands the kernel multiplies: rstd * (bf16(x) . bf16(W diag(w))^T), one bf16 rounding at the end
     xf = x.float()
-    hn = xf * torch.rsqrt((xf ** 2).mean(1, keepdim=True) + eps) * lnw.float()
-    gu = hn @ w.float().t()
+    rstd = torch.rsqrt((xf ** 2).mean(1, keepdim=True) + eps)
+    wnf = (w.float() * lnw.float()[None, :]).to(BF).float()
+    gu = (x.to(BF).float() @ wnf.t()) * rstd
     want = torch.nn.functional.silu(gu[:, :I]) * gu[:, I:]
-    assert_close(y_fold, want, 3e-2, 2e-2, "norm-folded gate|up + SwiGLU vs fp32")
-    assert_close(y_fold, y_small.float(), 3e-2, 3e-2, "norm-folded vs norm + gate|up + SwiGLU")
+    assert_close(y_fold, want, 2e-3, 1e-2, "norm-folded gate|up + SwiGLU vs its own algebra in fp32")
+    # against the unfolded operator (norm -> bf16 h -> GEMM): the two roundings sit at different places, so only statistically close
+    hn = xf * rstd * lnw.float()
+    gu2 = hn @ w.float().t()
+    want2 = torch.nn.functional.silu(gu2[:, :I]) * gu2[:, I:]
+    for other, nm in ((want2, "fp32 operator"), (y_small.float(), "norm + gate|up + SwiGLU launches")):
+        d = (y_fold.float() - other).abs()
+        assert float(d.mean()) <= 6e-3 * float(other.abs().mean()) + 1e-4, (nm, float(d.mean()), float(other.abs().mean()))
+        assert float(d.max()) <= 0.05 * float(other.abs().max()), (nm, float(d.max()), float(other.abs().max()))
 
 
 @pytest.mark.parametrize("M", [1, 8, 13, 16])
