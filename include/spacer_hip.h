@@ -227,29 +227,15 @@ int spacer_attn_decode_shared(const void* q, const void* prefix_k, const void* p
  *   qkv finish: acc32 [B,(Hq+2Hkv)*D] (+bias, rotary on q,k) -> q_out bf16 [B,Hq*D]; k,v appended to the tail
  *               cache [B,Cmax,Hkv,D] at position *tail_len_dev; acc32 is re-zeroed for the next layer
  *   swiglu_f32: y bf16 [B,inter] = silu(gate)*up from acc32 [B, 2*inter] (re-zeroed) */
-/* Round 5 -- the decode GEMMs for SMALL batches (M <= 16 rows: one prompt group of K = 8 rollouts per GPU is the reference script's
- * own launch shape, run_SpaceR_SG_RLVR.sh:21,39).  One whole-K workgroup per 16-column weight fragment, A fragments straight from
- * global memory, the four K-interleaved partial sums of a workgroup reduced in LDS: no split-K atomics, no zero-filled accumulator,
- * bit-reproducible.
- *   rows16 GEMM:   C32[M,N] += A[M,K] . Wp^T (store != 0: C32 = ...), Wp = spacer_pack_weight_frag(W); N % 16 == 0, K % 32 == 0
- *   qkv rows16:    HF input_layernorm + q/k/v_proj + rotary + cache update of one generate step (TR:463) in ONE launch:
- *                  x32 [M,K] = the fp32 residual stream, Wp_rope = spacer_pack_weight_frag_rope(W_qkv, scale = w_norm, head_dim)
- *                  (fragments pair dims d and d + head_dim/2 of one head; W diag(w_norm) folded in: norm(x) W^T = rstd (x (W diag w)^T)),
- *                  row sums of x^2 from the same loads; + bias, rotary (cos/sin fp32 [M, head_dim]) on the q and k heads;
- *                  q_out bf16 [M, Hq*D]; k, v appended to the tail cache [M, Cmax, Hkv, D] at position *tail_len_dev.
- *                  Replaces spacer_gemm_skinny_packed_normed + spacer_decode_qkv_finish_normed for M <= 16. */
-/*   normed SwiGLU: y bf16 [M, inter] = silu(rstd g) * (rstd u), [g | u] = bf16(x32) . Wp^T, rstd = rsqrt(mean_k x32^2 + eps): HF
+/* Round 5 -- decode batches of <= 16 rows (one prompt group of K = 8 rollouts per GPU is the reference script's own launch shape,
+ * run_SpaceR_SG_RLVR.sh:21,39): the gate|up + SwiGLU GEMM with the post-attention RMSNorm folded in.  (Whole-K workgroups for the
+ * q|k|v / o / down projections of such a batch were built and measured slower than the K-split kernels: scripts/probes/
+ * decode_rows16_probe.hip, profiles/r05_decode_small_rows.md.)
+ *   normed SwiGLU: y bf16 [M, inter] = silu(rstd g) * (rstd u), [g | u] = bf16(x32) . Wp^T, rstd = rsqrt(mean_k x32^2 + eps): HF
  *                  post_attention_layernorm + gate_proj / up_proj + act_fn of one generate step for M <= 16 rows in ONE launch;
  *                  Wp = spacer_pack_weight_frag_swiglu of W diag(w_norm); workspace / plan as spacer_gemm_skinny_swiglu_bf16_ws. */
 int spacer_gemm_skinny_swiglu_normed(const float* x32, long ldx, const void* Bpacked, void* Y, long ldy, int M, int inter, int K,
                                      float eps, void* workspace, long workspace_bytes, const spacer_plan* plan, spacer_stream_t stream);
-int spacer_pack_weight_frag_rope(const void* W, long ld, const void* scale_bf16, void* out, int N, int K, int head_dim,
-                                 spacer_stream_t stream);
-int spacer_gemm_rows16_packed_bf16(const void* A, long lda, const void* Bpacked, float* C, long ldc, int M, int N, int K, int store,
-                                   spacer_stream_t stream);
-int spacer_decode_qkv_rows16(const float* x32, long ldx, const void* Wp_rope, const void* bias, const float* cos_t, const float* sin_t,
-                             void* q_out, void* tail_k, void* tail_v, const int* tail_len_dev, int M, int K, float eps, int Hq, int Hkv,
-                             int D, int Cmax, spacer_stream_t stream);
 int spacer_decode_rope_table(const int* pos_base, const int* step_dev, float theta, float* cos_t, float* sin_t, int B,
                              int D, spacer_stream_t stream);
 int spacer_decode_qkv_finish(float* acc32, const void* bias, const float* cos_t, const float* sin_t, void* q_out,

@@ -868,32 +868,6 @@ def decode_qkv_finish_normed(acc32, bias, cos, sin, q_out, tail_k, tail_v, tail_
                                                       B, Hq, Hkv, D, tail_k.shape[1], _stream()), "decode_qkv_finish_normed")
 
 
-def pack_weight_frag_rope(w: torch.Tensor, head_dim: int, scale: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Fragment-major copy of the q|k|v weights whose 16-column fragments pair the rotary halves of one head (decode_qkv_rows16);
-    ``scale`` (bf16 [K]): W diag(scale) folded in (the layer's input RMSNorm weight)."""
-    N, Kd = w.shape
-    out = torch.empty(N * Kd, device=w.device, dtype=BF16)
-    check(_lib.load().spacer_pack_weight_frag_rope(_ptr(w), _rowmajor(w), _ptr(scale), _ptr(out), N, Kd, head_dim, _stream()), "pack_weight_frag_rope")
-    return out
-
-
-def gemm_rows16_acc(a: torch.Tensor, bp: torch.Tensor, c32: torch.Tensor, N: int, *, store: bool = False) -> torch.Tensor:
-    """c32[M,N] += a[M,K] @ W^T for M <= 16 rows (bp = pack_weight_frag(W)): whole-K workgroups, no atomics (csrc/decode_rows16.hip)."""
-    M, Kd = a.shape
-    assert c32.dtype == torch.float32 and a.dtype == BF16 and tuple(c32.shape) == (M, N)
-    check(_lib.load().spacer_gemm_rows16_packed_bf16(_ptr(a), _rowmajor(a), _ptr(bp), _ptr(c32), _rowmajor(c32), M, N, Kd, int(store), _stream()),
-          "gemm_rows16_packed_bf16")
-    return c32
-
-
-def decode_qkv_rows16(x32, wp_rope, bias, cos, sin, q_out, tail_k, tail_v, tail_len_dev, eps, Hq, Hkv, D):
-    """Input RMSNorm + q|k|v projection + bias + rotary + KV-cache append of one decode step for <= 16 rows, one launch."""
-    M, Kd = x32.shape
-    assert x32.dtype == torch.float32 and M <= 16
-    check(_lib.load().spacer_decode_qkv_rows16(_ptr(x32), _rowmajor(x32), _ptr(wp_rope), _ptr(bias), _ptr(cos), _ptr(sin), _ptr(q_out), _ptr(tail_k),
-                                               _ptr(tail_v), _ptr(tail_len_dev), M, Kd, eps, Hq, Hkv, D, tail_k.shape[1], _stream()), "decode_qkv_rows16")
-
-
 def swiglu_f32_fwd(acc32, out):
     B, two_i = acc32.shape
     check(_lib.load().spacer_swiglu_f32_fwd(_ptr(acc32), _ptr(out), B, two_i // 2, _stream()), "swiglu_f32_fwd")

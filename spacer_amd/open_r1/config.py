@@ -75,6 +75,7 @@ class GRPOConfig:                              # the trl.GRPOConfig / TrainingAr
     # (within 1e-3 of an fp32 evaluation at full 7B depth; GRPOHyper.precise_logps); the gradient runs on the production backward
     precise_logps: bool = False
     grad_algo: str = "allreduce"               # data-parallel exchange: "allreduce" (overlapped, replicated AdamW) or "rs_ag" (GRPOHyper.grad_algo)
+    reuse_prefill: str = "auto"                # the rollout's prefill keeps its tape for the policy's scoring pass: auto (when it fits) | true | false (GRPOHyper.reuse_prefill)
     # vLLM-trainer topology (trl.GRPOConfig fields read by vllm_grpo_trainer_modified.py:300,325,362): generation on a dedicated GPU
     use_vllm: bool = False
     vllm_device: str = "auto"                  # "auto" = the first GPU index after the training ranks (:325-327)

@@ -207,7 +207,8 @@ class SGRLVRTrainer:
                           adam_eps=args.adam_epsilon, max_grad_norm=args.max_grad_norm, temporal=self.temporal,
                           len_control=self.len_control, lr_scheduler_type=args.lr_scheduler_type, total_steps=total_steps,
                           warmup_steps=args.warmup_steps, recompute=bool(getattr(args, "gradient_checkpointing", False)),
-                          grad_algo=getattr(args, "grad_algo", "allreduce"), precise_logps=bool(getattr(args, "precise_logps", False)))
+                          grad_algo=getattr(args, "grad_algo", "allreduce"), precise_logps=bool(getattr(args, "precise_logps", False)),
+                          reuse_prefill={"auto": None, "true": True, "false": False}.get(str(getattr(args, "reuse_prefill", "auto")).lower()))
         if hyper.precise_logps:
             self._note("--precise_logps true: policy / reference log-probs in the precise mode (hi+lo bf16 operand pairs; <= 1e-3 of fp32 "
                        "at full depth), gradient on the production backward of the same tape")

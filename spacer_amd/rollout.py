@@ -25,12 +25,11 @@ from .qwen2vl.engine import Qwen2VLEngine
 
 BF16, F32 = torch.bfloat16, torch.float32
 DECODE_NORM_FOLD = os.environ.get("SPACER_DECODE_NORM", "fold") != "separate"     # A/B switch, read once at import
-# decode batches of <= 16 rows (cfg4 = the reference script's 1 prompt group per GPU; cfg2): which of the small-row forms run
-# (comma list, read once): "fold" = post-attention RMSNorm folded into the gate|up + SwiGLU launch (gemm_skinny_kernel SMALL + NORMA);
-# "qkv" / "o" / "down" = that projection as whole-K workgroups without split-K atomics (csrc/decode_rows16.hip; qkv = norm + projection
-# + bias + rotary + cache append in one launch); "off" = the 64-row kernels throughout.  Default = what measured faster.
-_SMALL = set(filter(None, os.environ.get("SPACER_DECODE_SMALL", "fold").replace("on", "fold,qkv,o,down").split(",")))
-DECODE_SMALL_FOLD, DECODE_SMALL_QKV, DECODE_SMALL_O, DECODE_SMALL_DOWN = ("fold" in _SMALL, "qkv" in _SMALL, "o" in _SMALL, "down" in _SMALL)
+# decode batches of <= 16 rows (cfg4 = the reference script's 1 prompt group per GPU; cfg2): the post-attention RMSNorm is folded into the
+# gate|up + SwiGLU launch (gemm_skinny_kernel SMALL + NORMA: -3 % per token-step at 8 rows of 7B, -10 % at 16 rows of 2B).
+# SPACER_DECODE_SMALL=off keeps the norm launch; "attn1" (A/B) = one attention launch per layer instead of prompt split + merge.
+_SMALL = set(filter(None, os.environ.get("SPACER_DECODE_SMALL", "fold").split(",")))
+DECODE_SMALL_FOLD, DECODE_SMALL_ATTN1 = "fold" in _SMALL, "attn1" in _SMALL
 
 @dataclass
 class PromptInput:
@@ -84,10 +83,7 @@ class RolloutEngine:
         # (the finishing kernel of layer i clears the row sums of layer (i + 1) % layers while it reads layer i's: a one-layer model
         # would clear what it reads, so it keeps the separate norm launch)
         self.fold_norm = DECODE_NORM_FOLD and engine.cfg.layers >= 2
-        c = engine.cfg
-        ok16 = c.head_dim % 16 == 0 and c.hidden % 32 == 0 and c.intermediate % 32 == 0
-        self.small_qkv, self.small_o, self.small_down = (DECODE_SMALL_QKV and ok16, DECODE_SMALL_O and ok16, DECODE_SMALL_DOWN and ok16)
-        self.small_fold = DECODE_SMALL_FOLD and c.hidden % 256 == 0
+        self.small_fold = DECODE_SMALL_FOLD and engine.cfg.hidden % 256 == 0
         # keep the prefill's tape (ViT + prompt rows of every layer) for the policy's scoring pass: None = when it fits (the tape must
         # live through the decode loop beside the training state: ~100 GB for 8 cfg3 groups at 7B -- no; 12 GB for cfg2 at 2B -- yes),
         # True / False = forced.  Only the stored (non-recompute) policy of the Qwen2-VL tower is eligible.
@@ -102,34 +98,25 @@ class RolloutEngine:
 
     def _pack(self, rows: int = 64) -> dict:
         """Fragment-major (spacer_pack_weight_frag) copies of qkv/o/gate-up/down per layer + lm_head: every skinny-GEMM
-        load instruction then reads 1 KiB of contiguous HBM.  Rebuilt once per optimizer step (~14 GB at 7B, ~10 ms).  The q|k|v
-        copy comes in the form the batch's row count needs (packed on first use): <= 16 rows the rotary-paired fragments with the
-        input-norm weight folded in (decode_qkv_rows16), <= 64 rows plain fragments with the norm weight folded in, else plain."""
+        load instruction then reads 1 KiB of contiguous HBM.  Rebuilt once per optimizer step (~14 GB at 7B, ~10 ms).  The q|k|v and
+        gate|up copies come in the form the batch's row count needs (packed on first use): q|k|v with the input-norm weight folded
+        in for <= 64 rows, gate|up with the post-attention norm weight folded in for <= 16 rows."""
         W, cfg = self.e.W, self.cfg
         if self._packed is None:
             names = [f"llm.{i}.{n}" for i in range(cfg.layers) for n in ("o_w", "down_w")] + ["llm.lm_head"]
             self._packed = {n: K.pack_weight_frag(W[n]) for n in names}
         PW = self._packed
-        gu_kind = "gu_wn" if (self.small_fold and rows <= 16) else "gu_w"
-        if f"llm.0.{gu_kind}" not in PW:
+        for kind, norm, swiglu in (("gu_wn" if (self.small_fold and rows <= 16) else "gu_w", "ln2_w", True),
+                                   ("qkv_wn" if (self.fold_norm and rows <= 64) else "qkv_w", "ln1_w", False)):
+            if f"llm.0.{kind}" in PW:
+                continue
+            pack = K.pack_weight_frag_swiglu if swiglu else K.pack_weight_frag
             for i in range(cfg.layers):
-                if gu_kind == "gu_wn":   # gate|up weights with the post-attention norm weight folded in: W diag(w_ln2), rounded once to bf16
-                    wf = (W[f"llm.{i}.gu_w"].float() * W[f"llm.{i}.ln2_w"].float()[None, :]).to(torch.bfloat16)
-                    PW[f"llm.{i}.gu_wn"] = K.pack_weight_frag_swiglu(wf)
-                    del wf
-                else:
-                    PW[f"llm.{i}.gu_w"] = K.pack_weight_frag_swiglu(W[f"llm.{i}.gu_w"])
-        kind = "qkv_wr" if (self.small_qkv and rows <= 16) else "qkv_wn" if (self.fold_norm and rows <= 64) else "qkv_w"
-        if f"llm.0.{kind}" not in PW:
-            for i in range(cfg.layers):
-                if kind == "qkv_wr":     # fragments pair the rotary halves of one head; W diag(w_ln1) folded in, rounded once to bf16
-                    PW[f"llm.{i}.qkv_wr"] = K.pack_weight_frag_rope(W[f"llm.{i}.qkv_w"], cfg.head_dim, scale=W[f"llm.{i}.ln1_w"])
-                elif kind == "qkv_wn":   # q|k|v weights with the layer's input-norm weight folded in
-                    wf = (W[f"llm.{i}.qkv_w"].float() * W[f"llm.{i}.ln1_w"].float()[None, :]).to(torch.bfloat16)
-                    PW[f"llm.{i}.qkv_wn"] = K.pack_weight_frag(wf)
-                    del wf
-                else:
-                    PW[f"llm.{i}.qkv_w"] = K.pack_weight_frag(W[f"llm.{i}.qkv_w"])
+                w = W[f"llm.{i}.{kind[:-1] if kind.endswith('wn') else kind}"]       # "gu_wn" -> "gu_w", "qkv_wn" -> "qkv_w"
+                if kind.endswith("wn"):      # W diag(w_norm), rounded once to bf16: norm(x) W^T = rstd * (x (W diag w)^T)
+                    w = (w.float() * W[f"llm.{i}.{norm}"].float()[None, :]).to(torch.bfloat16)
+                PW[f"llm.{i}.{kind}"] = pack(w)
+                del w
         return PW
 
     # ------------------------------------------------------------------ prefill
@@ -214,12 +201,7 @@ class RolloutEngine:
         scale = D ** -0.5
         for i in range(cfg.layers):
             p = f"llm.{i}."
-            if self.small_qkv and B <= 16:
-                # <= 16 rows: input norm + q|k|v + bias + rotary + cache append in ONE launch of whole-K workgroups (no split-K atomics,
-                # no fp32 accumulator, no finishing kernel)
-                K.decode_qkv_rows16(x, PW[p + "qkv_wr"], W[p + "qkv_b"], st["cos"], st["sin"], st["q"], st["tk"][i], st["tv"][i],
-                                    st["tail_len"], cfg.rms_eps, Hq, Hkv, D)
-            elif self.fold_norm and B <= 64:
+            if self.fold_norm and B <= 64:
                 # norm(x) Wqkv^T = rstd * (bf16(x) (W diag(w))^T): the GEMM stages the fp32 stream and sums x^2 per row, the
                 # finishing kernel applies rstd (and clears the next layer's row sums)
                 rs = st["rowss"]
@@ -237,19 +219,13 @@ class RolloutEngine:
             else:
                 o = K.attn_decode(st["q"], st["pk"][i], st["pv"][i], st["plen"], st["prompt_of"], st["tk"][i], st["tv"][i],
                                   st["tail_len"], Hq, Hkv, D, scale, out=st["o"])
-            if self.small_o and B <= 16:
-                K.gemm_rows16_acc(o, PW[p + "o_w"], x, cfg.hidden)
-            else:
-                K.gemm_skinny_packed_acc(o, PW[p + "o_w"], x, cfg.hidden)
+            K.gemm_skinny_packed_acc(o, PW[p + "o_w"], x, cfg.hidden)
             if self.small_fold and B <= 16:    # post-attention norm folded into the gate|up launch (x itself is the A operand)
                 a = K.gemm_skinny_swiglu_normed(x, PW[p + "gu_wn"], I, cfg.rms_eps, out=st["a"])
             else:
                 h2 = K.rmsnorm_fwd(x, W[p + "ln2_w"], cfg.rms_eps, out=st["h"])
                 a = K.gemm_skinny_swiglu(h2, PW[p + "gu_w"], I, out=st["a"])      # gate|up GEMM + SwiGLU in one launch
-            if self.small_down and B <= 16:
-                K.gemm_rows16_acc(a, PW[p + "down_w"], x, cfg.hidden)
-            else:
-                K.gemm_skinny_packed_acc(a, PW[p + "down_w"], x, cfg.hidden)
+            K.gemm_skinny_packed_acc(a, PW[p + "down_w"], x, cfg.hidden)
         hn = K.rmsnorm_fwd(x, W["llm.norm_w"], cfg.rms_eps, out=st["h"])
         if cfg.vocab >= 448 * 64:                        # whole-K workgroups: plain stores, no zero fill of the logits
             K.gemm_skinny_packed_store(hn, PW["llm.lm_head"], st["logits"], cfg.vocab)
@@ -298,7 +274,7 @@ class RolloutEngine:
             ev[1].record()
         L, Hkv, D, H = cfg.layers, cfg.kv_heads, cfg.head_dim, cfg.hidden
         st = dict(
-            B=B, pk=pk, pv=pv, packed=self._pack(B), Kn=Kn, shared_prefix=Kn * (cfg.heads // cfg.kv_heads) <= 64 and Kn > 1,
+            B=B, pk=pk, pv=pv, packed=self._pack(B), Kn=Kn, shared_prefix=Kn * (cfg.heads // cfg.kv_heads) <= 64 and Kn > 1 and not (DECODE_SMALL_ATTN1 and B <= 16),
             attn_ws=torch.empty(K.attn_decode_workspace_bytes(nP, cfg.kv_heads) // 4, device=dev, dtype=F32),
             plen=torch.tensor(plen, dtype=torch.int32, device=dev),
             prompt_of=torch.arange(B, dtype=torch.int32, device=dev) // Kn,

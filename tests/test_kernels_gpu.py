@@ -556,75 +556,6 @@ def test_gemm_skinny_swiglu_small_rows_and_norm_fold(dev, M, I, Kd):
         assert float(d.max()) <= 0.05 * float(other.abs().max()), (nm, float(d.max()), float(other.abs().max()))
 
 
-@pytest.mark.parametrize("M", [1, 8, 13, 16])
-@pytest.mark.parametrize("N,Kd", [(3584, 3584), (3584, 18944), (1536, 8960), (64, 96), (4608, 3584)])
-def test_gemm_rows16_whole_k_workgroups(dev, M, N, Kd):
-    """csrc/decode_rows16.hip: C32 += A . W^T for <= 16 rows with one whole-K workgroup per 16-column fragment (the o / down
-    projections of an 8-row decode batch): fp32 reference, the store form, the 64-row kernel's result, and -- no atomics -- two runs
-    bit-identical."""
-    a, b = rnd((M, Kd), dev, 1, 0.5), rnd((N, Kd), dev, 2, 0.05)
-    bp = K.pack_weight_frag(b)
-    c0 = rnd((M, N), dev, 3, dtype=torch.float32)
-    want = c0 + a.float() @ b.float().t()
-    c1, c2 = c0.clone(), c0.clone()
-    K.gemm_rows16_acc(a, bp, c1, N)
-    K.gemm_rows16_acc(a, bp, c2, N)
-    assert_close(c1, want, 5e-3, 2e-3, "rows16 acc")
-    assert torch.equal(c1, c2)
-    cs = torch.full((M, N), 7.0, device=dev)
-    K.gemm_rows16_acc(a, bp, cs, N, store=True)
-    assert_close(cs, a.float() @ b.float().t(), 5e-3, 2e-3, "rows16 store")
-    if Kd % 256 == 0:
-        c64 = c0.clone()
-        K.gemm_skinny_packed_acc(a, bp, c64, N)
-        assert_close(c1, c64, 1e-3, 1e-4, "rows16 vs the 64-row K-split kernel (fp32 summation order only)")
-
-
-@pytest.mark.parametrize("B,Hq,Hkv,Hd", [(8, 28, 4, 3584), (16, 12, 2, 1536), (5, 6, 2, 768), (1, 2, 1, 256)])
-def test_decode_qkv_rows16_one_launch(dev, B, Hq, Hkv, Hd):
-    """decode_qkv_rows16 (input RMSNorm + q|k|v projection + bias + rotary + KV-cache append for <= 16 rows in ONE launch, rotary-paired
-    weight fragments with W diag(w_ln) folded in) against fp32 torch and against the 64-row path it replaces
-    (gemm_skinny_packed_normed + decode_qkv_finish_normed) to bf16 rounding; the cache is written at *tail_len only."""
-    D, Cmax, eps = 128, 6, 1e-6
-    heads = Hq + 2 * Hkv
-    x = torch.randn(B, Hd, device=dev, generator=torch.Generator(dev).manual_seed(1)) * 1.7
-    w = rnd((heads * D, Hd), dev, 2, 0.04)
-    lnw = (1.0 + 0.3 * torch.randn(Hd, device=dev, generator=torch.Generator(dev).manual_seed(3))).to(torch.bfloat16)
-    bias = rnd((heads * D,), dev, 4, 0.3)
-    pos_base = torch.arange(B, dtype=torch.int32, device=dev) * 3 + 5
-    tld = torch.tensor([2], dtype=torch.int32, device=dev)
-    cos, sin = torch.empty(B, D, device=dev), torch.empty(B, D, device=dev)
-    K.decode_rope_table(pos_base, tld, 1e6, cos, sin)
-    q = torch.empty(B, Hq * D, device=dev, dtype=torch.bfloat16)
-    tk, tv = torch.zeros(B, Cmax, Hkv, D, device=dev, dtype=torch.bfloat16), torch.zeros(B, Cmax, Hkv, D, device=dev, dtype=torch.bfloat16)
-    wr = K.pack_weight_frag_rope(w, D, scale=lnw)
-    K.decode_qkv_rows16(x, wr, bias, cos, sin, q, tk, tv, tld, eps, Hq, Hkv, D)
-    q2, tk2, tv2 = torch.empty_like(q), torch.zeros_like(tk), torch.zeros_like(tv)
-    K.decode_qkv_rows16(x, wr, bias, cos, sin, q2, tk2, tv2, tld, eps, Hq, Hkv, D)
-    assert torch.equal(q, q2) and torch.equal(tk, tk2) and torch.equal(tv, tv2)               # no atomics: reproducible
-    assert float(tk[:, [0, 1, 3, 4, 5]].float().abs().max()) == 0.0 and float(tv[:, [0, 1, 3, 4, 5]].float().abs().max()) == 0.0
-    # fp32 reference
-    xf = x.float()
-    y = (xf * torch.rsqrt((xf ** 2).mean(1, keepdim=True) + eps) * lnw.float()) @ w.float().t() + bias.float()
-    c, s_ = cos[:, None, :], sin[:, None, :]
-
-    def rot(t):
-        return t * c + torch.cat([-t[..., D // 2:], t[..., :D // 2]], -1) * s_
-    assert_close(q.view(B, Hq, D), rot(y[:, :Hq * D].view(B, Hq, D)), 3e-2, 2e-2, "rows16 q vs fp32")
-    assert_close(tk[:, 2], rot(y[:, Hq * D:(Hq + Hkv) * D].view(B, Hkv, D)), 3e-2, 2e-2, "rows16 k vs fp32")
-    assert_close(tv[:, 2], y[:, (Hq + Hkv) * D:].view(B, Hkv, D), 3e-2, 2e-2, "rows16 v vs fp32")
-    if Hd % 256 == 0:
-        # the two-launch 64-row path on the same operands (same bf16(x) (W diag w)^T products, other fp32 summation order)
-        wn = K.pack_weight_frag((w.float() * lnw.float()[None, :]).to(torch.bfloat16))
-        acc, rowss, rz = torch.zeros(B, heads * D, device=dev), torch.zeros(B, device=dev), torch.zeros(B, device=dev)
-        qb, tkb, tvb = torch.empty_like(q), torch.zeros_like(tk), torch.zeros_like(tv)
-        K.gemm_skinny_packed_normed(x, wn, acc, rowss, heads * D)
-        K.decode_qkv_finish_normed(acc, bias, cos, sin, qb, tkb, tvb, tld, rowss, rz, Hd, eps, Hq, Hkv, D)
-        for a_, b_, nm in ((q, qb, "q"), (tk, tkb, "k"), (tv, tvb, "v")):
-            assert_close(a_, b_.float(), 2e-2, 1e-2, f"rows16 {nm} vs the two-launch path")
-            assert float((a_ == b_).float().mean()) > 0.98, nm                              # same products: almost always the same bf16
-
-
 def test_gemm_swiglu_epilogue_is_the_two_step_path(dev):
     """gate|up GEMM with the SwiGLU in its epilogue == GEMM into gu + swiglu_fwd, bit for bit (ragged M, bias, no gu)."""
     for M, I, Kd, with_bias in ((3000, 2048, 512, False), (4160, 3456, 1280, True), (5498, 1024, 256, False), (1402, 18944, 3584, False)):
