@@ -27,7 +27,8 @@ BF16, F32 = torch.bfloat16, torch.float32
 DECODE_NORM_FOLD = os.environ.get("SPACER_DECODE_NORM", "fold") != "separate"     # A/B switch, read once at import
 # decode batches of <= 16 rows (cfg4 = the reference script's 1 prompt group per GPU; cfg2): the post-attention RMSNorm is folded into the
 # gate|up + SwiGLU launch (gemm_skinny_kernel SMALL + NORMA: -3 % per token-step at 8 rows of 7B, -10 % at 16 rows of 2B).
-# SPACER_DECODE_SMALL=off keeps the norm launch; "attn1" (A/B) = one attention launch per layer instead of prompt split + merge.
+# SPACER_DECODE_SMALL=off keeps the norm launch; "attn1" (A/B) = one attention launch per layer instead of prompt split + merge
+# (measured slower at 8 rows: 3.69 vs 3.28 ms per token-step -- each rollout's workgroup re-reads the prompt's keys).
 _SMALL = set(filter(None, os.environ.get("SPACER_DECODE_SMALL", "fold").split(",")))
 DECODE_SMALL_FOLD, DECODE_SMALL_ATTN1 = "fold" in _SMALL, "attn1" in _SMALL
 
