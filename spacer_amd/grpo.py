@@ -358,7 +358,9 @@ class GRPOEngine:
         self.engine = Qwen2VLEngine(cfg, self.policy, recompute=hyper.recompute)
         self.ref_engine = Qwen2VLEngine(cfg, self.ref)
         self.roll = RolloutEngine(self.engine)
-        self.roll.keep_prefill_tape = lambda: False if (self.h.recompute or self.h.precise_logps) else self.h.reuse_prefill
+        # (the closure holds the hyper-parameter object, not this engine: a GRPOEngine <-> RolloutEngine reference cycle would keep
+        # 165 GB of training state alive until the cyclic collector runs)
+        self.roll.keep_prefill_tape = lambda h=hyper: False if (h.recompute or h.precise_logps) else h.reuse_prefill
         self.master = FlatParams(cfg, policy.flat.float(), policy.specs)
         self.G = policy.like(F32)
         self.m = torch.zeros_like(self.master.flat)

@@ -578,7 +578,7 @@ class Qwen2VLEngine:
         order, be taped with the stored policy, and describe the same prompts."""
         first = prefill[0]
         sh = first.shared
-        if self.recompute or self.cfg.vit_kind != "qwen2" or sh.get("engine") is not self or sh.get("era_rule") != era_rule:
+        if self.recompute or self.cfg.vit_kind != "qwen2" or (sh.get("engine") or (lambda: None))() is not self or sh.get("era_rule") != era_rule:
             return False
         if sh.get("weights_version") != self.weights_version:
             return False

@@ -13,6 +13,7 @@ Sampling semantics: temperature -> top_k -> top_p -> multinomial (HF warper orde
 from __future__ import annotations
 
 import os
+import weakref
 
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
@@ -178,7 +179,7 @@ class RolloutEngine:
 
         x = e.llm_forward(x0, cos, sin, segs, Pmax, kv_sink=sink, tape=llm_tape)
         if keep_tape:
-            shared = dict(vit=vit_tape, llm=llm_tape, x_final=x, engine=e, weights_version=e.weights_version, era_rule=era_rule,
+            shared = dict(vit=vit_tape, llm=llm_tape, x_final=x, engine=weakref.ref(e), weights_version=e.weights_version, era_rule=era_rule,
                           vit_segments=POS.vit_segments([g for p in with_video for g in p.grids]) if with_video else [])
             patch0 = 0
             for pi, (pr, s0, P) in enumerate(zip(prompts, starts, plen)):
