@@ -461,6 +461,33 @@ def test_taped_precise_forward_feeds_the_production_backward(dev, which, recompu
     assert float((lp2.cpu() - O.completion_logps(wb, g["cfg"], g["prompt"][-9:], comps, None, None)).abs().max()) <= 1e-4
 
 
+@pytest.mark.parametrize("which", ["tiny", "tiny25"])
+def test_precise_recompute_equals_stored(dev, which):
+    """under --precise_logps + --gradient_checkpointing the backward used to recompute gate|up / fc1 with the FAST bf16
+    GEMM on the hi half only, so 'recompute == stored' no longer held.  Round 5: the recompute re-runs the forward's own PAIR launch
+    (the tape keeps the lo half of the MLP input), so log-probs are bit-identical and the gradients agree up to the backward's
+    atomics (two runs of the stored policy differ by as much)."""
+    g, wb, eng, pix, rows, grid = _tiny_setup(dev, which)
+    comps = g["completions"].to(dev)
+    prompt = g["prompt"].to(dev)
+    dlogp = (torch.randn(*comps.shape, generator=torch.Generator().manual_seed(7)) * 0.5).to(dev)
+    grads, lps = {}, {}
+    for name, rc in (("stored", False), ("stored2", False), ("recompute", True)):
+        eng.recompute = rc
+        tape = {}
+        lps[name] = eng.score_group(prompt, comps, pix, [grid], precise=True, tape=tape)
+        G = eng.W.like(torch.float32)
+        eng.backward_group(tape, dlogp, G)
+        grads[name] = G.flat.clone()
+    eng.recompute = False
+    assert torch.equal(lps["stored"], lps["recompute"])
+    scale = float(grads["stored"].abs().max())
+    noise = float((grads["stored"] - grads["stored2"]).abs().max())
+    diff = float((grads["stored"] - grads["recompute"]).abs().max())
+    print(f"{which}: stored vs recompute on a precise tape: max |dG| {diff:.2e} (two stored runs: {noise:.2e}) at scale {scale:.2e}")
+    assert diff <= max(4 * noise, 1e-6 * scale)
+
+
 @pytest.mark.parametrize("depth", ["2b", "7b"])
 def test_precise_grpo_step_matches_the_cpu_oracle_at_full_depth(dev, depth):
     """ONE FULL GRPO step (reference + policy scoring, k3 KL, loss, backward) with ``GRPOHyper.precise_logps`` at
