@@ -436,7 +436,9 @@ int spacer_embed_fwd_f32video(const int64_t* ids, const void* table, const float
 int spacer_attn_fwd_pair(const void* q_hi, const void* q_lo, const void* k_hi, const void* k_lo, const void* v_hi, const void* v_lo,
                          void* o_hi, void* o_lo, float* lse, long q_stride, long kv_stride, long o_stride,
                          const spacer_attn_segment* segs_dev, int num_segs, int max_q_len, int T, int Hq, int Hkv, int D, int causal,
-                         float scale, spacer_stream_t stream);
+                         float scale, int variant, spacer_stream_t stream);
+/* variant: 0 = DMA-staged tiles, 256 query rows per workgroup (round 5); 1 = the register-staged round-3 kernel (A/B runs, tests).
+ * Same MFMA order per wave: the two give the same bits. */
 
 #ifdef __cplusplus
 }

@@ -108,7 +108,7 @@ SIGNATURES = {
     "spacer_norm_f32_pair": [_p, _p, _p, _p, _p, _i, _i, _f, _i, _p, _p, _p],
     "spacer_rope_f32_pair": [_p, _l, _p, _p, _p, _p, _l, _i, _i, _i, _i, _p],
     "spacer_embed_fwd_f32video": [_p, _p, _p, _p, _p, _i, _i, _p],
-    "spacer_attn_fwd_pair": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _l, _l, _l, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p],
+    "spacer_attn_fwd_pair": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _l, _l, _l, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p],
 }
 OTHER_SYMBOLS = ["spacer_last_error", "spacer_version", "spacer_sample_workspace_bytes", "spacer_attn_decode_workspace_bytes", "spacer_gemm_tile", "spacer_gemm_workspace_bytes", "spacer_gemm_swiglu_fused", "spacer_gemm_pair_fused", "spacer_gemm_pair_epilogue_fused", "spacer_resize_workspace_bytes", "spacer_gemm_skinny_swiglu_workspace_bytes"]
 

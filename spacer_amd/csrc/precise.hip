@@ -366,6 +366,232 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pair_kernel(AttnPairArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------ attention forward on (hi, lo) operands, DMA-staged (round 5)
+// The same arithmetic as attn_fwd_pair_kernel (same MFMA order per wave, so the same bits), restructured around what the profile of
+// the precise step showed: 899 us per launch on the two-group cfg3 layout against ~315 us of pure MFMA time -- the register-staged
+// kernel issues a tile's global loads at the top of that tile (no prefetch: every tile pays its latency), and its two 128-row
+// workgroups per CU each pull their own 64 KiB K_hi | K_lo | V_hi | V_lo tile.  Here a workgroup is 8 waves = 256 query rows sharing
+// one tile (half the L2 -> CU bytes per query row), the four images reach LDS by global_load_lds DMA (no registers, no ds_write
+// pass) into TWO buffer sets (128 KiB, one workgroup per CU, still 2 waves per SIMD), tile t+1 is requested right after the barrier
+// that publishes tile t, one barrier per tile.
+struct PairKeyTile { int start_abs, len, rel0; bool own; };
+__device__ __forceinline__ PairKeyTile pair_key_tile(const spacer_attn_segment& seg, int n_pre, int own_len, int t) {
+    PairKeyTile kt;
+    if (t < n_pre) { kt.own = false; kt.rel0 = t * PBKV; kt.start_abs = seg.pre_start; kt.len = seg.pre_len; }
+    else { kt.own = true; kt.rel0 = (t - n_pre) * PBKV; kt.start_abs = seg.q_start; kt.len = own_len; }
+    return kt;
+}
+
+template <int D>
+__global__ __launch_bounds__(512, 2) void attn_fwd_pair_dma_kernel(AttnPairArgs a) {
+    constexpr int F = 2;
+    constexpr int DC = (D + 31) / 32;
+    constexpr int DF = D / 16;
+    constexpr int BQP = 8 * 16 * F;                                 // 256 query rows per workgroup
+    constexpr int BUF = 4 * AT_RM_BYTES;                            // K_hi | K_lo | V_hi | V_lo
+    extern __shared__ __attribute__((aligned(16))) char smem[];    // [2][BUF]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int seg_id = a.num_segs - 1 - blockIdx.x / a.nqb;        // longest first
+    const int qb = a.nqb - 1 - blockIdx.x % a.nqb;
+    const int h = blockIdx.y, hk = h / (a.Hq / a.Hkv);
+    const spacer_attn_segment seg = a.segs[seg_id];
+    const int qb0 = qb * BQP;
+    if (qb0 >= seg.q_len) return;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int wq0 = qb0 + wave * 16 * F;
+
+    bf16x8 qh[F][DC], ql[F][DC];
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        int qi = wq0 + f * 16 + l15;
+        qi = qi < seg.q_len ? qi : seg.q_len - 1;
+        const long off = (long)(seg.q_start + qi) * a.q_stride + (long)h * D;
+#pragma unroll
+        for (int dc = 0; dc < DC; ++dc) {
+            qh[f][dc] = frag_global<D>(a.q_hi + off, dc, lane);
+            ql[f][dc] = frag_global<D>(a.q_lo + off, dc, lane);
+        }
+    }
+    f32x4 oacc[F][DF];
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+#pragma unroll
+        for (int d = 0; d < DF; ++d) oacc[f][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run[F], l_run[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) { m_run[f] = -INFINITY; l_run[f] = 0.f; }
+    const float c2 = a.scale * 1.4426950408889634f;
+
+    const int own_len = a.causal ? min(seg.q_len, qb0 + BQP) : seg.q_len;
+    const int n_pre = (seg.pre_len + PBKV - 1) / PBKV, n_tiles = n_pre + (own_len + PBKV - 1) / PBKV;
+
+    // ---- DMA map: waves 2 i, 2 i + 1 fill image i (0 K_hi, 1 K_lo, 2 V_hi, 3 V_lo); a wave's piece j = rows (wave & 1) * 32 + 4 j + g,
+    // j = 0..7; lane (g, l15) sits at physical chunk l15 of its row and fetches the logical chunk l15 ^ (row & 15) (frag_rm / frag_tr)
+    const int img = wave >> 1;
+    const bf16_t* gsrc = (img == 0 ? a.k_hi : img == 1 ? a.k_lo : img == 2 ? a.v_hi : a.v_lo) + (long)hk * D;
+    const int img_off = img * AT_RM_BYTES + (wave & 1) * 8 * 1024;
+    const int prow = (wave & 1) * 32 + g;
+    const unsigned stride_b = (unsigned)a.kv_stride * 2u;
+    unsigned doff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = prow + 4 * j;
+        int c = l15 ^ (row & 15);
+        if (c >= D / 8) c = 0;                                       // D = 80: padding chunks take finite filler (they meet Q's zeros / are never read)
+        doff[j] = (unsigned)row * stride_b + (unsigned)c * 16u;
+    }
+    auto issue_tile = [&](int t, int buf) {
+        const PairKeyTile kt = pair_key_tile(seg, n_pre, own_len, t);
+        const int valid = kt.len - kt.rel0;                          // >= 1
+        const char* base = (const char*)(gsrc + (long)(kt.start_abs + kt.rel0) * a.kv_stride);
+        char* dst = smem + buf * BUF + img_off;
+        if (valid >= PBKV) {
+            const char* base16 = base + 16l * stride_b;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((i < 4 ? base : base16) + doff[i & 3]),
+                                                 (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                int row = prow + 4 * i;
+                row = row < valid ? row : valid - 1;                 // finite filler; those scores are masked, P is 0 there
+                const unsigned dch = doff[i & 3] - (unsigned)(prow + 4 * (i & 3)) * stride_b;          // (ragged tiles only: recomputed, not kept)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (unsigned)row * stride_b + dch),
+                                                 (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    issue_tile(0, 0);
+    for (int t = 0; t < n_tiles; ++t) {
+        const PairKeyTile kt = pair_key_tile(seg, n_pre, own_len, t);
+        const int rel0 = kt.rel0, len = kt.len;
+        const bool own = kt.own;
+        const int buf = t & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                // everyone's pieces of tile t landed; everyone is done with tile t - 1
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < n_tiles) issue_tile(t + 1, buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (own && a.causal && rel0 > wq0 + 16 * F - 1) continue;    // wave-uniform: tile entirely above this wave's last row
+        const char* kh_lds = smem + buf * BUF;
+        const char* kl_lds = kh_lds + AT_RM_BYTES;
+        const char* vh_lds = kh_lds + 2 * AT_RM_BYTES;
+        const char* vl_lds = kh_lds + 3 * AT_RM_BYTES;
+
+        // ---- S^T = K . Q^T with (hi, lo) operands; the small products first
+        f32x4 st[4][F];
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf) {
+#pragma unroll
+            for (int f = 0; f < F; ++f) st[kf][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dc = 0; dc < DC; ++dc) {
+                const bf16x8 kh = frag_rm(kh_lds, kf, dc, lane), kl = frag_rm(kl_lds, kf, dc, lane);
+#pragma unroll
+                for (int f = 0; f < F; ++f) {
+                    st[kf][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qh[f][dc], st[kf][f], 0, 0, 0);
+                    st[kf][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, ql[f][dc], st[kf][f], 0, 0, 0);
+                    st[kf][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qh[f][dc], st[kf][f], 0, 0, 0);
+                }
+            }
+        }
+
+        // ---- online softmax (exp2 domain), P as a pair
+        const bool need_mask = (rel0 + PBKV > len) || (own && a.causal && rel0 + PBKV - 1 > wq0);
+        bf16x8 ph[F][2], pl[F][2];
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const int qi = wq0 + f * 16 + l15;
+            float mx = -INFINITY;
+            if (need_mask) {
+#pragma unroll
+                for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int kr = rel0 + kf * 16 + g * 4 + r;
+                        const bool ok = kr < len && !(own && a.causal && kr > qi);
+                        st[kf][f][r] = ok ? st[kf][f][r] : -INFINITY;
+                    }
+            }
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kf][f][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[f], mx * c2);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = exp2f(m_run[f] - m_use);
+            float psum = 0.f;
+            float p[4][4], q[4][4];
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    p[kf][r] = exp2f(__builtin_fmaf(st[kf][f][r], c2, -m_use));
+                    psum += p[kf][r];
+                }
+            l_run[f] = l_run[f] * alpha + psum;
+            m_run[f] = m_new;
+#pragma unroll
+            for (int d = 0; d < DF; ++d) oacc[f][d] *= alpha;
+            ph[f][0] = pack_slots(p[0], p[1]);
+            ph[f][1] = pack_slots(p[2], p[3]);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const uint4 w = __builtin_bit_cast(uint4, ph[f][c]);
+                const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int kf = 2 * c + (j >> 1), r = 2 * (j & 1);
+                    q[kf][r] = p[kf][r] - bf_lo(ww[j]);
+                    q[kf][r + 1] = p[kf][r + 1] - bf_hi(ww[j]);
+                }
+            }
+            pl[f][0] = pack_slots(q[0], q[1]);
+            pl[f][1] = pack_slots(q[2], q[3]);
+        }
+
+        // ---- O^T += V^T . P^T
+#pragma unroll
+        for (int df = 0; df < DF; ++df)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const bf16x8 vh = frag_tr(vh_lds, df, c, lane), vl = frag_tr(vl_lds, df, c, lane);
+#pragma unroll
+                for (int f = 0; f < F; ++f) {
+                    oacc[f][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, ph[f][c], oacc[f][df], 0, 0, 0);
+                    oacc[f][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pl[f][c], oacc[f][df], 0, 0, 0);
+                    oacc[f][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, ph[f][c], oacc[f][df], 0, 0, 0);
+                }
+            }
+    }
+
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        float l = l_run[f];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const int qi = wq0 + f * 16 + l15;
+        if (qi >= seg.q_len) continue;
+        const float inv = 1.f / l;
+        const long tok = seg.q_start + qi;
+        const long o = tok * a.o_stride + (long)h * D;
+#pragma unroll
+        for (int df = 0; df < DF; ++df) {
+            const f32x4 v = oacc[f][df];
+            const float ov[4] = {v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv};
+            store_pair4(a.o_hi, a.o_lo, o + df * 16 + g * 4, ov);
+        }
+        if (a.lse && g == 0) a.lse[(long)h * a.T + tok] = m_run[f] * 0.6931471805599453f + logf(l);
+    }
+}
+
 }  // namespace
 
 // ================================================================================================ C-ABI
@@ -441,17 +667,30 @@ extern "C" int spacer_embed_fwd_f32video(const int64_t* ids, const void* table, 
 extern "C" int spacer_attn_fwd_pair(const void* q_hi, const void* q_lo, const void* k_hi, const void* k_lo, const void* v_hi,
                                     const void* v_lo, void* o_hi, void* o_lo, float* lse, long q_stride, long kv_stride, long o_stride,
                                     const spacer_attn_segment* segs_dev, int num_segs, int max_q_len, int T, int Hq, int Hkv, int D,
-                                    int causal, float scale, spacer_stream_t stream) {
+                                    int causal, float scale, int variant, spacer_stream_t stream) {
     SP_REQUIRE(D == 80 || D == 128, SPACER_EINVAL, "attn_fwd_pair: head_dim=%d (80 or 128)", D);
+    SP_REQUIRE(variant == 0 || variant == 1, SPACER_EINVAL, "attn_fwd_pair: variant %d (0 = DMA-staged, 1 = register-staged)", variant);
     SP_REQUIRE(Hkv > 0 && Hq % Hkv == 0, SPACER_EINVAL, "attn_fwd_pair: Hq=%d must be a multiple of Hkv=%d", Hq, Hkv);
     SP_REQUIRE(q_stride % 8 == 0 && kv_stride % 8 == 0 && o_stride % 4 == 0, SPACER_EINVAL, "attn_fwd_pair: strides must keep 16-byte rows");
     if (num_segs <= 0 || max_q_len <= 0) return SPACER_OK;
     constexpr int F = 2;
+    const bool dma = variant == 0;                                  // 0 = DMA-staged 256-row workgroups (round 5), 1 = the register-staged round-3 kernel
     AttnPairArgs a = {};
     a.q_hi = (const bf16_t*)q_hi; a.q_lo = (const bf16_t*)q_lo; a.k_hi = (const bf16_t*)k_hi; a.k_lo = (const bf16_t*)k_lo;
     a.v_hi = (const bf16_t*)v_hi; a.v_lo = (const bf16_t*)v_lo; a.o_hi = (bf16_t*)o_hi; a.o_lo = (bf16_t*)o_lo; a.lse = lse;
     a.q_stride = q_stride; a.kv_stride = kv_stride; a.o_stride = o_stride; a.segs = segs_dev; a.num_segs = num_segs;
-    a.nqb = cdiv(max_q_len, 64 * F); a.T = T; a.Hq = Hq; a.Hkv = Hkv; a.causal = causal; a.scale = scale;
+    a.nqb = cdiv(max_q_len, dma ? 256 : 64 * F); a.T = T; a.Hq = Hq; a.Hkv = Hkv; a.causal = causal; a.scale = scale;
+    if (dma) {
+        constexpr int LDS2 = 8 * AT_RM_BYTES;
+        static const int once2 = hipFuncSetAttribute((const void*)attn_fwd_pair_dma_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2)
+                               + hipFuncSetAttribute((const void*)attn_fwd_pair_dma_kernel<80>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
+        SP_REQUIRE(once2 == 0, SPACER_ELAUNCH, "attn_fwd_pair: cannot raise the dynamic LDS limit to %d bytes", LDS2);
+        const dim3 grid2(num_segs * a.nqb, Hq);
+        if (D == 128) hipLaunchKernelGGL(attn_fwd_pair_dma_kernel<128>, grid2, dim3(512), LDS2, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(attn_fwd_pair_dma_kernel<80>, grid2, dim3(512), LDS2, (hipStream_t)stream, a);
+        SP_CHECK_LAUNCH();
+        return SPACER_OK;
+    }
     constexpr int LDS = 4 * AT_RM_BYTES;
     static const int once = hipFuncSetAttribute((const void*)attn_fwd_pair_kernel<128, F>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)
                           + hipFuncSetAttribute((const void*)attn_fwd_pair_kernel<80, F>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);

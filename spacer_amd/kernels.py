@@ -738,7 +738,10 @@ def embed_fwd_f32video(ids, table, video32, video_row_of_token):
     return out
 
 
-def attn_fwd_pair(q, k, v, segs, max_q_len, Hq, Hkv, D, causal, scale, *, lse=None):
+ATTN_PAIR_VARIANT = 1 if os.environ.get("SPACER_ATTN_PAIR") == "reg" else 0     # A/B: the register-staged round-3 kernel
+
+
+def attn_fwd_pair(q, k, v, segs, max_q_len, Hq, Hkv, D, causal, scale, *, lse=None, variant=None):
     """attn_fwd on pair operands: q, k, v are (hi, lo) tuples of views with equal strides; returns the (hi, lo) pair of O.
     ``lse`` fp32 [Hq, T] receives the log-sum-exp rows attn_bwd reads (taped precise forward)."""
     (qh, ql), (kh, kl), (vh, vl) = q, k, v
@@ -748,7 +751,7 @@ def attn_fwd_pair(q, k, v, segs, max_q_len, Hq, Hkv, D, causal, scale, *, lse=No
     assert lse is None or (lse.dtype == torch.float32 and lse.is_contiguous() and tuple(lse.shape) == (Hq, T))
     check(_lib.load().spacer_attn_fwd_pair(_ptr(qh), _ptr(ql), _ptr(kh), _ptr(kl), _ptr(vh), _ptr(vl), _ptr(oh), _ptr(ol), _ptr(lse),
                                            qh.stride(0), kh.stride(0), oh.stride(0), _ptr(segs), segs.shape[0], max_q_len, T, Hq, Hkv,
-                                           D, int(causal), scale, _stream()), "attn_fwd_pair")
+                                           D, int(causal), scale, ATTN_PAIR_VARIANT if variant is None else int(variant), _stream()), "attn_fwd_pair")
     return oh, ol
 
 

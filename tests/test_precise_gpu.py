@@ -161,6 +161,13 @@ def test_attention_pair_matches_fp64(dev, case):
     assert float((lse.double()[:, owned.to(dev)] - want_lse).abs().max()) <= 2e-4, name
     o16, _ = K.attn_fwd(qh, kh, vh, K.make_segments(segs, dev), max(s[1] for s in segs), Hq, Hkv, D, causal, scale)
     assert rel_err(o16.double(), want) > 10 * err                                # and far below the bf16 kernel's
+    # round 5: the DMA-staged kernel (256 query rows per workgroup, two tile buffers) is the default; the register-staged round-3
+    # kernel walks the same tiles with the same MFMA order per wave -> the same bits
+    lse_r = torch.full((Hq, T), float("nan"), device=dev)
+    o_r = K.attn_fwd_pair((qh, ql), (kh, kl), (vh, vl), K.make_segments(segs, dev), max(s[1] for s in segs), Hq, Hkv, D, causal, scale, lse=lse_r,
+                          variant=1)
+    assert torch.equal(o[0], o_r[0]) and torch.equal(o[1], o_r[1]), name
+    assert torch.equal(lse[:, owned.to(dev)], lse_r[:, owned.to(dev)]), name
 
 
 def test_pair_producers_emit_the_tape_entries_of_the_fast_backward(dev):
