@@ -203,6 +203,8 @@ def pmc_traffic(workload: str, kernel: str, live: bool):
         try:
             sys.path.insert(0, os.path.join(ROOT, "scripts"))
             import pmc_gemm_table
+            if not kernel.startswith("gemm_bf16_nt_256h_kernel"):
+                return None, "not collected for this kernel (the PMC shape replay covers the production forms of the 256 tile)"
             kinds = {"gemm_bf16_nt_256h_kernel<true, false, false, true>": {"nt", "swiglu"},
                      "gemm_bf16_nt_256h_kernel<true, false, false, false>": {"nt"},
                      "gemm_bf16_nt_256h_kernel<true, false, true, true>": {"dx"},
