@@ -738,7 +738,10 @@ def embed_fwd_f32video(ids, table, video32, video_row_of_token):
     return out
 
 
-ATTN_PAIR_VARIANT = 1 if os.environ.get("SPACER_ATTN_PAIR") == "reg" else 0     # A/B: the register-staged round-3 kernel
+# pair attention kernel: "reg" = register-staged (round 3), "dma" = DMA-staged 256-row workgroups (round 5); default = per shape, as
+# measured (scripts/probes/attn_pair_time.py): the DMA form wins on the vision tower's long frames (head_dim 80: 302 vs 378 us at
+# 16 x 1024), the register-staged form on the decoder's layouts (head_dim 128: 785 vs 826 us on two cfg3 groups); same bits
+ATTN_PAIR_VARIANT = {"reg": 1, "dma": 0}.get(os.environ.get("SPACER_ATTN_PAIR", ""), None)
 
 
 def attn_fwd_pair(q, k, v, segs, max_q_len, Hq, Hkv, D, causal, scale, *, lse=None, variant=None):
@@ -751,7 +754,9 @@ def attn_fwd_pair(q, k, v, segs, max_q_len, Hq, Hkv, D, causal, scale, *, lse=No
     assert lse is None or (lse.dtype == torch.float32 and lse.is_contiguous() and tuple(lse.shape) == (Hq, T))
     check(_lib.load().spacer_attn_fwd_pair(_ptr(qh), _ptr(ql), _ptr(kh), _ptr(kl), _ptr(vh), _ptr(vl), _ptr(oh), _ptr(ol), _ptr(lse),
                                            qh.stride(0), kh.stride(0), oh.stride(0), _ptr(segs), segs.shape[0], max_q_len, T, Hq, Hkv,
-                                           D, int(causal), scale, ATTN_PAIR_VARIANT if variant is None else int(variant), _stream()), "attn_fwd_pair")
+                                           D, int(causal), scale,
+                                           int(variant) if variant is not None else ATTN_PAIR_VARIANT if ATTN_PAIR_VARIANT is not None else int(D != 80),
+                                           _stream()), "attn_fwd_pair")
     return oh, ol
 
 

@@ -140,7 +140,8 @@ def test_attention_pair_matches_fp64(dev, case):
     (qh, kh, vh), (ql, kl, vl) = cut(hi), cut(lo)
     scale = D ** -0.5
     lse = torch.full((Hq, T), float("nan"), device=dev)
-    o = K.attn_fwd_pair((qh, ql), (kh, kl), (vh, vl), K.make_segments(segs, dev), max(s[1] for s in segs), Hq, Hkv, D, causal, scale, lse=lse)
+    o = K.attn_fwd_pair((qh, ql), (kh, kl), (vh, vl), K.make_segments(segs, dev), max(s[1] for s in segs), Hq, Hkv, D, causal, scale, lse=lse,
+                        variant=0)
     q64, k64, v64 = cut(pair_f64((hi, lo)))
     mask = dense_mask(segs, T, causal)
     # fp64 reference (attn_ref of test_kernels_gpu.py computes in fp32): two orders below the pair error
@@ -161,8 +162,8 @@ def test_attention_pair_matches_fp64(dev, case):
     assert float((lse.double()[:, owned.to(dev)] - want_lse).abs().max()) <= 2e-4, name
     o16, _ = K.attn_fwd(qh, kh, vh, K.make_segments(segs, dev), max(s[1] for s in segs), Hq, Hkv, D, causal, scale)
     assert rel_err(o16.double(), want) > 10 * err                                # and far below the bf16 kernel's
-    # round 5: the DMA-staged kernel (256 query rows per workgroup, two tile buffers) is the default; the register-staged round-3
-    # kernel walks the same tiles with the same MFMA order per wave -> the same bits
+    # round 5: the DMA-staged kernel (variant 0: 256 query rows per workgroup, two tile buffers; the default at head_dim 80) and the
+    # register-staged round-3 kernel (variant 1; the default at head_dim 128) walk the same tiles with the same MFMA order per wave -> the same bits
     lse_r = torch.full((Hq, T), float("nan"), device=dev)
     o_r = K.attn_fwd_pair((qh, ql), (kh, kl), (vh, vl), K.make_segments(segs, dev), max(s[1] for s in segs), Hq, Hkv, D, causal, scale, lse=lse_r,
                           variant=1)
