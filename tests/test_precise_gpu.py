@@ -496,6 +496,51 @@ def test_precise_recompute_equals_stored(dev, which):
     assert diff <= max(4 * noise, 1e-6 * scale)
 
 
+def test_precise_step_on_the_cfg3_two_group_pass_equals_group_by_group_at_2b_depth(dev):
+    """VERDICT r4 item 1(d), the STEP: ``GRPOEngine.score_and_backward_multi`` with ``precise_logps`` on the layout the benchmark runs --
+    two cfg3 prompt groups in one token-packed pass (10 996 rows, K = 8 x C = 512 per group), Qwen2-VL-2B depth, reference model
+    different from the policy -- against the same two groups taken through ``score_and_backward`` one at a time.  With the GEMM's
+    K-split tail off and the tile fixed the policy / reference log-probs are bit-identical, loss and KL equal the mean of the two
+    single-group values, and the accumulated gradient agrees to fp32 summation order (the dW GEMMs contract over 10 996 rows in
+    one case and over 2 x 5 498 in the other)."""
+    from spacer_amd.grpo import GRPOEngine, GRPOHyper
+    cfg = QWEN2_VL_2B
+    torch.cuda.empty_cache()
+    params = FlatParams.empty(cfg, dev)
+    random_init_(params, seed=1234)
+    ref = FlatParams(cfg, params.flat.clone(), params.specs)
+    gen7 = torch.Generator(device=dev).manual_seed(7)
+    ref.flat.copy_((ref.flat.float() * (1.0 + 0.03 * torch.randn(ref.flat.numel(), device=dev, generator=gen7))).to(BF))
+    ge = GRPOEngine(cfg, params, GRPOHyper(num_generations=8, beta=0.04, precise_logps=True), ref=ref)
+    prompts, comps, advs = [], [], []
+    for gi in range(2):
+        prompt, _ = make_prompt(cfg, 40 + gi, 16, 280, 364, 360, dev)
+        c = torch.randint(1000, 150000, (8, 512), generator=torch.Generator().manual_seed(50 + gi))
+        c[3, 100 + gi] = cfg.eos_token_id                             # a finished rollout in each group
+        prompts.append(prompt); comps.append(c.to(dev))
+        advs.append(torch.randn(8, generator=torch.Generator().manual_seed(60 + gi)).to(dev))
+    with K.plan(gemm_no_split=1, gemm_tile=256):
+        both = ge.score_and_backward_multi(prompts, comps, advs, grad_scale=0.5)
+        g_both = ge.G.flat.clone()
+        K.zero_(ge.G.flat)
+        singles = [ge.score_and_backward(prompts[gi], comps[gi], advs[gi], grad_scale=0.5) for gi in range(2)]
+        g_single = ge.G.flat.clone()
+    for gi in range(2):
+        assert torch.equal(both["logps"][8 * gi:8 * gi + 8], singles[gi]["logps"])
+        assert torch.equal(both["ref_logps"][8 * gi:8 * gi + 8], singles[gi]["ref_logps"])
+        assert torch.equal(both["mask"][8 * gi:8 * gi + 8], singles[gi]["mask"])
+    loss_m = 0.5 * (float(singles[0]["loss"]) + float(singles[1]["loss"]))
+    kl_m = 0.5 * (float(singles[0]["kl"]) + float(singles[1]["kl"]))
+    assert abs(float(both["loss"]) - loss_m) <= 1e-6 * max(1.0, abs(loss_m)) and abs(float(both["kl"]) - kl_m) <= 1e-6 * max(1.0, kl_m)
+    assert kl_m > 1e-3
+    rel = float((g_both - g_single).norm() / g_single.norm())
+    print(f"two-group precise step vs group by group at 2B depth: loss {float(both['loss']):+.6f} / {loss_m:+.6f}, kl {float(both['kl']):.6f} / {kl_m:.6f}, "
+          f"gradient rel. Frobenius diff {rel:.2e}")
+    assert rel <= 2e-3, rel
+    del ge, params, ref
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("depth", ["2b", "7b"])
 def test_precise_grpo_step_matches_the_cpu_oracle_at_full_depth(dev, depth):
     """ONE FULL GRPO step (reference + policy scoring, k3 KL, loss, backward) with ``GRPOHyper.precise_logps`` at
