@@ -1,3 +1,10 @@
+// ARCHIVED PROBE (round 5) -- not part of libspacer_hip.so.  This file was spacer_amd/csrc/decode_rows16.hip in commits 1760bd4 .. f5c47b4^
+// (C-ABI entries spacer_gemm_rows16_packed_bf16 / spacer_decode_qkv_rows16 / spacer_pack_weight_frag_rope, wired into
+// RolloutEngine._decode_step behind SPACER_DECODE_SMALL=qkv,o,down) and was measured there: slower than the K-split kernels in every
+// position (profiles/r05_decode_small_rows.md).  To rebuild it, copy it back into spacer_amd/csrc/ (it includes "common.h").  Known
+// hazard left unfixed: the ring's trailing inline-asm loads land in registers the compiler considers dead (the q|k|v form was not
+// bit-reproducible between runs).
+//
 // Decode GEMMs for SMALL row counts (M <= 16: one prompt group of K = 8 rollouts per GPU is the reference script's own launch shape,
 // run_SpaceR_SG_RLVR.sh:21,39 = BASELINE configs[3]; cfg2's 4 groups x K = 4 are 16 rows).  Round 5.
 //
