@@ -249,6 +249,86 @@ def fuzz_pair(r):
             raise AssertionError(f"MISMATCH gemm pair {M}x{N}x{Kd}: rel err {err:.3g}")
 
 
+def fuzz_pair_epilogue(r):
+    """Round 5: the pair GEMM with its producer in the epilogue (SwiGLU / rotary / activation + hi/lo split, gemm_halftile.h) on ragged
+    M, with and without the K-split tail, against the two-kernel sequence it replaces (pair GEMM -> fp32 -> producer kernel): tapes
+    bit-identical, pairs within half the pair precision; and the pair attention's two kernels against each other bit for bit."""
+    kind = r.randint(0, 3)
+    if kind == 3:
+        D, Hq, Hkv = r.choice([(128, 4, 2), (128, 7, 1), (80, 3, 3)])
+        causal = D == 128
+        segs, at = [], 0
+        P = r.randint(1, 400) if causal else 0
+        if P:
+            segs.append((0, P, 0, 0)); at = P
+        for _ in range(r.randint(1, 4)):
+            L = r.randint(1, 600)
+            segs.append((at, L, 0, P) if P else (at, L, 0, 0)); at += L
+        qkv = rnd((at, (Hq + 2 * Hkv) * D), 0.9, torch.float32)
+        hi, lo = K.split_pair(qkv)
+        qd, kd = Hq * D, Hkv * D
+        cut = lambda t: (t[:, :qd], t[:, qd:qd + kd], t[:, qd + kd:])            # noqa: E731
+        (qh, kh, vh), (ql, kl, vl) = cut(hi), cut(lo)
+        sg = K.make_segments(segs, dev)
+        outs = [K.attn_fwd_pair((qh, ql), (kh, kl), (vh, vl), sg, max(x[1] for x in segs), Hq, Hkv, D, causal, D ** -0.5, variant=v) for v in (0, 1)]
+        if not (torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])):
+            raise AssertionError(f"MISMATCH attn pair variants differ on {segs}")
+        return
+    M = r.choice([r.randint(1, 600), r.randint(600, 5000)])
+    Kd = r.randint(1, 24) * 64
+    a = rnd((M, Kd), 1.0, torch.float32)
+    ah, al = K.split_pair(a)
+    with K.plan(gemm_tile=256, gemm_no_split=r.randint(0, 1)):
+        if kind == 0:
+            I = r.randint(1, 16) * 128
+            w, b = rnd((2 * I, Kd), 0.05), (rnd((2 * I,), 0.3) if r.randint(0, 1) else None)
+            tf, tu = torch.empty(M, 2 * I, device=dev, dtype=BF), torch.empty(M, 2 * I, device=dev, dtype=BF)
+            f = K.gemm_pair_swiglu(ah, al, w, bias=b, gu_out=tf)
+            u = K.swiglu_pair(K.gemm_pair(ah, al, w, bias=b), gu_out=tu)
+        elif kind == 1:
+            Hq, Hkv = r.randint(1, 12), r.randint(1, 3)
+            heads = Hq + 2 * Hkv
+            w, b = rnd((heads * 128, Kd), 0.05), rnd((heads * 128,), 0.3)
+            ang = torch.rand(M, 64, device=dev) * 6.28
+            cos, sin = torch.cat([ang.cos(), ang.cos()], -1).contiguous(), torch.cat([ang.sin(), ang.sin()], -1).contiguous()
+            f = K.gemm_pair_rope(ah, al, w, cos, sin, Hq + Hkv, heads, 128, bias=b)
+            u = K.rope_pair(K.gemm_pair(ah, al, w, bias=b), cos, sin, Hq + Hkv, heads, 128)
+            tf = tu = None
+        else:
+            N = r.randint(1, 80) * 64
+            act = r.choice([K.SPACER_ACT_QUICK_GELU, K.SPACER_ACT_GELU_ERF, K.SPACER_ACT_SILU])
+            w, b = rnd((N, Kd), 0.05), rnd((N,), 0.3)
+            tf, tu = torch.empty(M, N, device=dev, dtype=BF), torch.empty(M, N, device=dev, dtype=BF)
+            f = K.gemm_pair_act(ah, al, w, act, bias=b, pre_out=tf)
+            u = K.act_pair(K.gemm_pair(ah, al, w, bias=b), act, pre_out=tu)
+    if tf is not None and not torch.equal(tf, tu):
+        raise AssertionError(f"MISMATCH pair epilogue kind {kind} {M}x{Kd}: tape differs")
+    fd, ud = f[0].double() + f[1].double(), u[0].double() + u[1].double()
+    if not float((fd - ud).abs().max()) <= 2.0 ** -17 * float(ud.abs().max()) + 1e-30:
+        raise AssertionError(f"MISMATCH pair epilogue kind {kind} {M}x{Kd}: {float((fd - ud).abs().max()):.3g} at scale {float(ud.abs().max()):.3g}")
+
+
+def fuzz_small_rows(r):
+    """Round 5: decode gate|up + SwiGLU for <= 16 rows -- the SMALL instantiation equals the 64-row launch on the same rows bit for bit,
+    the norm-folded form equals its own algebra rstd (bf16(x) (W diag w)^T) to bf16 rounding."""
+    M, I, Kd = r.randint(1, 16), r.randint(1, 80) * 32, r.randint(1, 16) * 256
+    x = rnd((M, Kd), 1.3, torch.float32)
+    w = rnd((2 * I, Kd), 0.05)
+    lnw = (1.0 + 0.3 * torch.randn(Kd, device=dev)).to(BF)
+    h = K.rmsnorm_fwd(x, lnw, 1e-6)
+    wp = K.pack_weight_frag_swiglu(w)
+    y16 = K.gemm_skinny_swiglu(h, wp, I)
+    pad = torch.zeros(17, Kd, device=dev, dtype=BF)
+    pad[:M] = h
+    if not torch.equal(y16, K.gemm_skinny_swiglu(pad, wp, I)[:M]):
+        raise AssertionError(f"MISMATCH small-row swiglu {M}x{I}x{Kd} vs the 64-row launch")
+    wnf = (w.float() * lnw.float()[None, :]).to(BF)
+    y = K.gemm_skinny_swiglu_normed(x, K.pack_weight_frag_swiglu(wnf), I, 1e-6)
+    rstd = torch.rsqrt((x ** 2).mean(1, keepdim=True) + 1e-6)
+    gu = (x.to(BF).float() @ wnf.float().t()) * rstd
+    close(y, torch.nn.functional.silu(gu[:, :I]) * gu[:, I:], 2e-3, 1e-2, f"norm-folded swiglu {M}x{I}x{Kd}")
+
+
 def fuzz_chunk_head(r):
     """Vocabulary-chunked log-sum-exp / dlogits (loss.hip) against the one-shot kernels for ragged chunk sizes and strided views."""
     rows, V = r.randint(1, 300), r.randint(3, 500) * 4
@@ -275,7 +355,7 @@ def run(budget: float, seed: int) -> dict:
     r = random.Random(seed)
     torch.manual_seed(seed)
     fns = [fuzz_gemm, fuzz_gemm_trans, fuzz_swiglu, fuzz_attention, fuzz_decode_attention, fuzz_skinny, fuzz_skinny_normed, fuzz_norm, fuzz_resize, fuzz_pair,
-           fuzz_chunk_head]
+           fuzz_chunk_head, fuzz_pair_epilogue, fuzz_small_rows]
     counts = {f.__name__: 0 for f in fns}
     t0 = time.time()
     while time.time() - t0 < budget:
