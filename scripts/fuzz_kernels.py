@@ -303,9 +303,17 @@ def fuzz_pair_epilogue(r):
             u = K.act_pair(K.gemm_pair(ah, al, w, bias=b), act, pre_out=tu)
     if tf is not None and not torch.equal(tf, tu):
         raise AssertionError(f"MISMATCH pair epilogue kind {kind} {M}x{Kd}: tape differs")
+    # the two kernels evaluate the same fp32 expression; where the compiler contracted a * b + c differently, a last-bit difference can
+    # move a value across a rounding boundary of hi and the pair re-encodes it within its own precision (|lo| <= 2^-8 |x|, lo rounded
+    # to 2^-8 of itself: 2^-16 |x| per encoding).  So: element-wise within 2 x 2^-16 |x| (+ a floor for values near zero), and
+    # bit-identical almost everywhere -- a wrong partner / bias / table index would miss both by orders of magnitude
     fd, ud = f[0].double() + f[1].double(), u[0].double() + u[1].double()
-    if not float((fd - ud).abs().max()) <= 2.0 ** -17 * float(ud.abs().max()) + 1e-30:
-        raise AssertionError(f"MISMATCH pair epilogue kind {kind} {M}x{Kd}: {float((fd - ud).abs().max()):.3g} at scale {float(ud.abs().max()):.3g}")
+    scale = float(ud.abs().max())
+    bad = (fd - ud).abs() > 2.0 ** -15 * ud.abs() + 2.0 ** -20 * scale
+    same = float(((f[0] == u[0]) & (f[1] == u[1])).float().mean())
+    if bool(bad.any()) or same < 0.98:
+        raise AssertionError(f"MISMATCH pair epilogue kind {kind} {M}x{Kd}: {int(bad.sum())} elements off, max |diff| {float((fd - ud).abs().max()):.3g} at "
+                             f"scale {scale:.3g}, {100 * same:.2f} % of the pairs bit-identical")
 
 
 def fuzz_small_rows(r):

@@ -235,12 +235,12 @@ def test_precise_logps_on_the_golden_miniatures(dev, which):
 def _pair_close(got, want, what):
     """Two evaluations of the same fp32 arithmetic as (hi, lo) pairs.  The compiler may contract a * b + c differently in the two
     kernels; a last-bit fp32 difference can move a value across a bf16 rounding boundary of hi, and the pair then re-encodes it within
-    its own precision (2^-17 of the value).  So: equal to half the pair precision of the output scale, and bit-identical almost
-    everywhere (printed)."""
+    its own precision (up to 2^-16 of the value per encoding).  So: equal to twice the pair precision of the output scale, and
+    bit-identical almost everywhere (>= 99 %, printed) -- a wrong partner lane / bias / table index would miss both by orders of magnitude."""
     g, w = pair_f64(got), pair_f64(want)
     same = float(((got[0] == want[0]) & (got[1] == want[1])).float().mean())
     print(f"{what}: {100 * same:.3f} % of the pairs bit-identical, max |diff| {float((g - w).abs().max()):.2e} at scale {float(w.abs().max()):.2e}")
-    assert float((g - w).abs().max()) <= 0.5 * PAIR_EPS * float(w.abs().max()), (what, float((g - w).abs().max()), float(w.abs().max()))
+    assert float((g - w).abs().max()) <= 2 * PAIR_EPS * float(w.abs().max()), (what, float((g - w).abs().max()), float(w.abs().max()))
     assert same >= 0.99, (what, same)
 
 
