@@ -278,7 +278,8 @@ def fuzz_pair_epilogue(r):
     Kd = r.randint(1, 24) * 64
     a = rnd((M, Kd), 1.0, torch.float32)
     ah, al = K.split_pair(a)
-    with K.plan(gemm_tile=256, gemm_no_split=r.randint(0, 1)):
+    no_split = r.randint(0, 1)
+    with K.plan(gemm_tile=256, gemm_no_split=no_split):
         if kind == 0:
             I = r.randint(1, 16) * 128
             w, b = rnd((2 * I, Kd), 0.05), (rnd((2 * I,), 0.3) if r.randint(0, 1) else None)
@@ -301,8 +302,15 @@ def fuzz_pair_epilogue(r):
             tf, tu = torch.empty(M, N, device=dev, dtype=BF), torch.empty(M, N, device=dev, dtype=BF)
             f = K.gemm_pair_act(ah, al, w, act, bias=b, pre_out=tf)
             u = K.act_pair(K.gemm_pair(ah, al, w, bias=b), act, pre_out=tu)
-    if tf is not None and not torch.equal(tf, tu):
-        raise AssertionError(f"MISMATCH pair epilogue kind {kind} {M}x{Kd}: tape differs")
+    if tf is not None:
+        # one fp32 summation order (tail off): the same sums, rounded once -> identical tapes.  With the K-split tail on, the SwiGLU
+        # form's tiles cover other output columns than the plain form's, so an element may sit in a split tile in one launch and in a
+        # whole tile in the other: fp32 association differs, a bf16 rounding may flip (rarely)
+        if no_split and not torch.equal(tf, tu):
+            raise AssertionError(f"MISMATCH pair epilogue kind {kind} {M}x{Kd}: tape differs with the K-split tail off")
+        d = (tf.float() - tu.float()).abs()
+        if bool((d > 2.0 ** -7 * tu.float().abs() + 1e-6).any()) or float((tf == tu).float().mean()) < 0.999:
+            raise AssertionError(f"MISMATCH pair epilogue kind {kind} {M}x{Kd}: tape off by more than a bf16 ulp ({float(d.max()):.3g})")
     # the two kernels evaluate the same fp32 expression; where the compiler contracted a * b + c differently, a last-bit difference can
     # move a value across a rounding boundary of hi and the pair re-encodes it within its own precision (|lo| <= 2^-8 |x|, lo rounded
     # to 2^-8 of itself: 2^-16 |x| per encoding).  So: element-wise within 2 x 2^-16 |x| (+ a floor for values near zero), and
