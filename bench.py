@@ -46,7 +46,8 @@ WORKLOADS = {
 }
 MFMA_PEAK_TFLOPS = 2500.0     # dense bf16, MI355X_MICROARCH.md
 ROLLOUT_FWD_TF = {"cfg3": 5.69 + 18.7, "cfg4": 5.69 + 18.7}     # ViT fwd + prefill per prompt (TFLOP)
-DECODE_WEIGHT_GB = {"Qwen2-VL-7B": 14.14, "Qwen2.5-VL-7B": 14.14}                      # 2 (W_L + W_H) bytes streamed per decode step
+DECODE_WEIGHT_GB = {"Qwen2-VL-7B": 14.14, "Qwen2.5-VL-7B": 14.14,
+                    "Qwen2-VL-2B": 3.09}      # 2B: 28 x (1536 x 2048 + 1536^2 + 3 x 1536 x 8960) + 151936 x 1536 (tied head) = 1.54 G params x 2 B                      # 2 (W_L + W_H) bytes streamed per decode step
 ALGO_TF_PER_SAMPLE = {"cfg3": 53.1, "cfg4": 53.1}   # SURVEY 8(d), temporal branch off
 
 
