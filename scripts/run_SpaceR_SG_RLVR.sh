@@ -1,6 +1,6 @@
 #!/bin/bash
 # Drop-in for SpaceR-SG-RLVR/src/scripts/run_SpaceR_SG_RLVR.sh: same flags, one process per MI355X over RCCL/xGMI.
-export DEBUG_MODE="true"
+export DEBUG_MODE="${DEBUG_MODE:-false}"   # "true": append every rollout + reward to LOG_PATH (reference default: false, SC:3)
 export LOG_PATH="./debug_log_SpaceR.txt"
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 # For resume training:  --resume_from_checkpoint Model_Path \
@@ -10,7 +10,7 @@ torchrun --nproc_per_node="${NPROC:-8}" --nnodes="1" --node_rank="0" \
     --master_addr="127.0.0.1" --master_port="12365" \
     -m spacer_amd.open_r1.SG_RLVR \
     --output_dir "./log/SpaceR" \
-    --model_name_or_path "${MODEL:-Qwen/Qwen2-VL-7B-Instruct}" \
+    --model_name_or_path "${MODEL:-Qwen/Qwen2.5-VL-7B-Instruct}" \
     --dataset_name "${DATASET:-SpaceR-151k.jsonl}" \
     --deepspeed local_scripts/zero3.json \
     --temporal true \

@@ -46,7 +46,7 @@ def test_launch_script_flags_parse():
     sh = open(os.path.join(ROOT, "scripts", "run_SpaceR_SG_RLVR.sh")).read()
     body = sh[sh.index("-m spacer_amd.open_r1.SG_RLVR") + len("-m spacer_amd.open_r1.SG_RLVR"):]
     argv = [t for t in re.sub(r"\\\n", " ", body).replace('"', "").split() if t]
-    argv = [a.replace("${MODEL:-Qwen/Qwen2-VL-7B-Instruct}", "Qwen/Qwen2-VL-7B-Instruct").replace("${DATASET:-SpaceR-151k.jsonl}", "d.jsonl") for a in argv]
+    argv = [a.replace("${MODEL:-Qwen/Qwen2.5-VL-7B-Instruct}", "Qwen/Qwen2.5-VL-7B-Instruct").replace("${DATASET:-SpaceR-151k.jsonl}", "d.jsonl") for a in argv]
     script, train, model = parse_args(argv)
     assert script.temporal is True and script.len_control is True and script.max_pixels == 401408
     assert train.num_generations == 8 and train.beta == 0.04 and train.max_grad_norm == 5 and train.learning_rate == 1e-6
