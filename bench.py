@@ -19,6 +19,7 @@ Prints ONE JSON line on rank 0 (see the driver contract in the task statement) w
   roofline_hbm  HBM roofline of the step's largest kernel BY TIME, the decode loop's gate|up + SwiGLU weight-streaming GEMM
                 (gemm_skinny_kernel<true, true, 1, false>): algorithmic weight bytes / live HIP-event launch time
   variants      (N = 1) the same workload with the shipped script's --temporal true, free-running (EOS allowed, 1024 new tokens),
+                ragged (C = 1024, seeded rollout lengths U[320, 1024]: EOS-trimmed scoring vs the full [K, C] rectangle),
                 through SGRLVRTrainer.train(), and precise_step = the full step with --precise-logps (log-probs <= 1e-3 of fp32)
   comm          (N > 1 or --force-dist) the gradient exchange: algorithm, bytes on the wire, ms not hidden under the backward
 """
@@ -451,8 +452,13 @@ def main():
 
     gpp_default = args.groups_per_pass or (2 if args.workload in ("cfg3", "cfg3_qwen25", "cfg2", "tiny") else 1)
 
+    tok_stats = {"scored": 0, "rectangle": 0}
+
     def step(step_idx, temporal=args.temporal, sp=sp, groups_per_pass=None):
         t0 = time.perf_counter()
+        if sp.synthetic_lengths is not None:          # other lengths every step (seeded: identical on every run)
+            from dataclasses import replace as _replace
+            sp = _replace(sp, seed=sp.seed + 7919 * step_idx)
         prompts = [make_prompt(cfg, rank * groups + g, F, Hpx, Wpx, n_text, dev, frames_u8=frames[g])[0] for g in range(groups)]
         scomp = None
         if temporal:                              # the shuffled twin: same text, temporally permuted frames
@@ -483,10 +489,12 @@ def main():
             # the rank's last backward of the step hands finished layer ranges to the data-parallel reducer (overlap_comm)
             last = gs[-1] == groups - 1
             if len(gs) == 1:
-                ge.score_and_backward(prompts[g0], comp[g0 * Kgen:(g0 + 1) * Kgen], advs[g0].to(dev), grad_scale=1.0 / groups, last_group=last)
+                res = ge.score_and_backward(prompts[g0], comp[g0 * Kgen:(g0 + 1) * Kgen], advs[g0].to(dev), grad_scale=1.0 / groups, last_group=last)
             else:
-                ge.score_and_backward_multi([prompts[g] for g in gs], [comp[g * Kgen:(g + 1) * Kgen] for g in gs], [advs[g] for g in gs],
-                                            grad_scale=1.0 / groups, last_group=last)      # per-group weight
+                res = ge.score_and_backward_multi([prompts[g] for g in gs], [comp[g * Kgen:(g + 1) * Kgen] for g in gs], [advs[g] for g in gs],
+                                                  grad_scale=1.0 / groups, last_group=last)      # per-group weight
+            tok_stats["scored"] += res["scored_tokens"]             # completion tokens in the scoring passes / the backward
+            tok_stats["rectangle"] += res["mask"].numel()           # ... of the [K, C] rectangle the reference scores (TR:527-541)
         t0 = tick("score+backward", t0)
         ge.reduce_gradients()
         ge.optimizer_step(world)
@@ -555,6 +563,39 @@ def main():
             except Exception as exc:                                   # e.g. out of memory on a smaller part: report, do not die
                 variants[name] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
                 torch.cuda.empty_cache()
+        # ---- EOS-trimmed scoring on a batch shaped like a real run's: --max_completion_length 1024 (SC:33), rollouts
+        # that END -- seeded synthetic lengths ~U[320, 1024] (the length bonus pays for 320-512, TR:620-629) -- with the scoring passes
+        # and the backward packing only the tokens up to each rollout's EOS ("trimmed") against the reference's full [K, C] rectangle
+        # ("rectangular": same rollouts, same results -- tests/test_ragged_gpu.py -- pad rows scored and back-propagated)
+        if args.workload in ("cfg3", "cfg2", "tiny"):
+            Cr = 2 * C if args.workload == "tiny" else 1024
+            sp_r = replace(sp, max_new_tokens=Cr, suppress_eos=False, synthetic_lengths=(max(1, Cr * 5 // 16), Cr))
+            rag = {"max_new_tokens": Cr, "lengths": f"seeded U[{Cr * 5 // 16}, {Cr}] per rollout, EOS forced there (SamplingParams.synthetic_lengths)"}
+            for name, trim, gpp_v in (("trimmed", True, 1), ("rectangular", False, 1), ("trimmed_2_groups_per_pass", True, 2)):
+                try:
+                    ge.h.trim_completions = trim
+                    roll_stats.clear()
+                    step(30_000, sp=sp_r, groups_per_pass=gpp_v)
+                    torch.cuda.synchronize()
+                    tok_stats.update(scored=0, rectangle=0)
+                    t_v = time.perf_counter()
+                    n_v = 2
+                    for i in range(n_v):
+                        step(30_001 + i, sp=sp_r, groups_per_pass=gpp_v)
+                    torch.cuda.synchronize()
+                    dt_v = (time.perf_counter() - t_v) / n_v
+                    rag[name] = {"samples_per_s": round(groups * Kgen / dt_v, 3), "ms_per_step": round(1e3 * dt_v, 1), "steps": n_v,
+                                 "groups_per_pass": gpp_v, "completion_tokens_scored_per_step": tok_stats["scored"] // n_v,
+                                 "rectangle_tokens_per_step": tok_stats["rectangle"] // n_v,
+                                 "decode_steps_per_step": roll_stats.get("decode_steps", 0) // (n_v + 1)}
+                except Exception as exc:
+                    rag[name] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+                    torch.cuda.empty_cache()
+                finally:
+                    ge.h.trim_completions = True
+            if "ms_per_step" in rag.get("trimmed", {}) and "ms_per_step" in rag.get("rectangular", {}):
+                rag["speedup_trimmed_vs_rectangular"] = round(rag["rectangular"]["ms_per_step"] / rag["trimmed"]["ms_per_step"], 3)
+            variants["ragged"] = rag
         # ---- the same workload THROUGH the drop-in surface: SGRLVRTrainer.train() on the engine above, gradient_accumulation_steps =
         # groups, dataset rows around host-resident frames (uploaded per step: PCIe included), the GPU front end, the real
         # accuracy_reward / format_reward on decoded text, metrics + logging; step time = wall time between the trainer's own log lines

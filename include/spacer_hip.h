@@ -347,6 +347,13 @@ int spacer_grpo_loss(const float* logp, const float* ref_logp, const float* adv,
 /* First-EOS completion mask (TR:493-498). ids int64 [G, C] -> mask int32 [G, C], lengths int32 [G]. */
 int spacer_completion_mask(const int64_t* ids, int eos_id, int* mask, int* lengths, int G, int C,
                            spacer_stream_t stream);
+/* EOS-trimmed scoring (round 6; TR:493-498 builds the mask, TR:640-643 multiplies it into the loss: positions behind a rollout's
+ * first EOS contribute exactly zero, so the scoring passes and the backward pack only the first lengths[i] tokens of rollout i).
+ * idx int64 [n] = flat positions (i * C + t, t < lengths[i]) of the packed tokens inside the [G, C] rectangle:
+ *   gather : dst[j] = src[idx[j]]   (d loss / d logp of the rectangle -> packed rows)
+ *   scatter: dst[idx[j]] = src[j]   (packed log-probs -> the rectangle; the caller zeroes dst first) */
+int spacer_gather_f32(const float* src, const int64_t* idx, float* dst, long n, spacer_stream_t stream);
+int spacer_scatter_f32(const float* src, const int64_t* idx, float* dst, long n, spacer_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Sampling (HF generate with do_sample, temperature 1, top_k, top_p; TR:277-284).  logits fp32 [B, vocab].
@@ -366,6 +373,12 @@ int spacer_sample_top_p_step(const float* logits, long ld, int B, int vocab, int
                              const int* step_dev, int step_bias, int eos_id, int pad_id, int suppress_eos, int* finished,
                              int64_t* out_ids, int64_t* out_matrix, long out_ld, spacer_stream_t stream);
 int spacer_decode_embed(const int64_t* ids, const void* table, float* out, int B, int H, int* counter0, int* counter1,
+                        spacer_stream_t stream);
+/* Synthetic completion lengths (the seeded variable-length mode of the benchmark / tests; SURVEY 8(d) "free-running mode"): on the
+ * step's logits, right before spacer_sample_top_p_step with suppress_eos = 0 -- row b's EOS logit becomes -inf, except at token index
+ * *step_dev + step_bias == eos_at[b] where it dominates the row, so rollout b ends with EOS as its eos_at[b]-th token (length
+ * eos_at[b] + 1; eos_at[b] >= C: never).  Graph-capturable like the sampler (the step lives in device memory). */
+int spacer_eos_schedule(float* logits, long ld, int B, int vocab, const int* step_dev, int step_bias, const int* eos_at, int eos_id,
                         spacer_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------

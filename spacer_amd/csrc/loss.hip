@@ -128,6 +128,16 @@ __global__ __launch_bounds__(NT) void logprob_bwd_chunk_kernel(const float* __re
     }
 }
 
+// ------------------------------------------------------------------ packed (EOS-trimmed) positions <-> the [G, C] rectangle
+__global__ __launch_bounds__(NT) void gather_f32_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx,
+                                                        float* __restrict__ dst, long n) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) dst[i] = src[idx[i]];
+}
+__global__ __launch_bounds__(NT) void scatter_f32_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx,
+                                                         float* __restrict__ dst, long n) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) dst[idx[i]] = src[i];
+}
+
 // ------------------------------------------------------------------ first-EOS mask
 __global__ __launch_bounds__(NT) void completion_mask_kernel(const int64_t* __restrict__ ids, int eos, int* __restrict__ mask,
                                                              int* __restrict__ lengths, int G, int C) {
@@ -270,6 +280,22 @@ extern "C" int spacer_completion_mask(const int64_t* ids, int eos_id, int* mask,
                                       spacer_stream_t stream) {
     if (G <= 0 || C <= 0) return SPACER_OK;
     hipLaunchKernelGGL(completion_mask_kernel, dim3(G), dim3(NT), 0, (hipStream_t)stream, ids, eos_id, mask, lengths, G, C);
+    SP_CHECK_LAUNCH();
+    return SPACER_OK;
+}
+extern "C" int spacer_gather_f32(const float* src, const int64_t* idx, float* dst, long n, spacer_stream_t stream) {
+    if (n <= 0) return SPACER_OK;
+    SP_REQUIRE(src && idx && dst, SPACER_EINVAL, "gather_f32: null operand");
+    const int grid = (int)((n + NT - 1) / NT < 1024 ? (n + NT - 1) / NT : 1024);
+    hipLaunchKernelGGL(gather_f32_kernel, dim3(grid), dim3(NT), 0, (hipStream_t)stream, src, idx, dst, n);
+    SP_CHECK_LAUNCH();
+    return SPACER_OK;
+}
+extern "C" int spacer_scatter_f32(const float* src, const int64_t* idx, float* dst, long n, spacer_stream_t stream) {
+    if (n <= 0) return SPACER_OK;
+    SP_REQUIRE(src && idx && dst, SPACER_EINVAL, "scatter_f32: null operand");
+    const int grid = (int)((n + NT - 1) / NT < 1024 ? (n + NT - 1) / NT : 1024);
+    hipLaunchKernelGGL(scatter_f32_kernel, dim3(grid), dim3(NT), 0, (hipStream_t)stream, src, idx, dst, n);
     SP_CHECK_LAUNCH();
     return SPACER_OK;
 }

@@ -245,6 +245,16 @@ __global__ __launch_bounds__(SNT) void sample_kernel(const float* __restrict__ l
     }
 }
 
+// Synthetic completion lengths (bench / tests): row b may emit EOS at token index eos_at[b] and nowhere else.  Runs on the step's
+// logits right before the sampler: the EOS logit becomes -inf (never drawn) or, at the scheduled index, so large that every other
+// candidate's probability underflows to 0 (the nucleus keeps the top candidate unconditionally).
+__global__ void eos_schedule_kernel(float* __restrict__ logits, long ld, int B, const int* __restrict__ step_dev, int step_bias,
+                                    const int* __restrict__ eos_at, int eos) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    logits[(long)b * ld + eos] = (*step_dev + step_bias == eos_at[b]) ? 1e30f : -INFINITY;
+}
+
 }  // namespace
 
 extern "C" long spacer_sample_workspace_bytes(int B, int vocab) { (void)B; (void)vocab; return 0; }
@@ -278,4 +288,15 @@ extern "C" int spacer_sample_top_p_step(const float* logits, long ld, int B, int
                                         int* finished, int64_t* out_ids, int64_t* out_matrix, long out_ld, spacer_stream_t stream) {
     return sample_launch(logits, ld, B, vocab, top_k, top_p, temperature, seed, step_dev, step_bias, eos_id, pad_id, suppress_eos,
                          finished, out_ids, nullptr, out_matrix, out_ld, stream);
+}
+
+extern "C" int spacer_eos_schedule(float* logits, long ld, int B, int vocab, const int* step_dev, int step_bias, const int* eos_at,
+                                   int eos_id, spacer_stream_t stream) {
+    if (B <= 0) return SPACER_OK;
+    SP_REQUIRE(logits && step_dev && eos_at, SPACER_EINVAL, "eos_schedule: null operand");
+    SP_REQUIRE(eos_id >= 0 && eos_id < vocab, SPACER_EINVAL, "eos_schedule: eos_id %d outside the vocabulary (%d)", eos_id, vocab);
+    hipLaunchKernelGGL(eos_schedule_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, logits, ld, B, step_dev, step_bias,
+                       eos_at, eos_id);
+    SP_CHECK_LAUNCH();
+    return SPACER_OK;
 }

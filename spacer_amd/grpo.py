@@ -62,6 +62,12 @@ class GRPOHyper:
     # sits at the bf16-operand floor (~1e-1 max).  The precise forward of the policy also emits the tape of the production
     # backward (Qwen2VLEngine._llm_forward_precise), so the gradient costs nothing extra; the forward costs ~2x the fast one.
     precise_logps: bool = False
+    # EOS-trimmed scoring (round 6): the reference + policy scoring passes and the backward pack only the tokens up to each rollout's
+    # first EOS.  TR:493-498 builds the completion mask and TR:640-643 multiplies it into the loss, so everything behind the first
+    # EOS contributes exactly zero; with --max_completion_length 1024 and a length bonus that pays for 320-512 tokens (TR:620-629)
+    # about half of the [K, C] rectangle of a real run is pad.  Same log-probs on the unmasked positions, same loss / KL / gradient
+    # (tests/test_ragged_gpu.py); costs one host read of K lengths per pass.  False = the rectangular pass (A/B, tests).
+    trim_completions: bool = True
 
 
 # ------------------------------------------------------------------------------------- reward shaping (host)
@@ -397,12 +403,13 @@ class GRPOEngine:
         backward before the optimizer step: finished layer ranges go to the data-parallel reducer while it runs."""
         cfg = self.cfg
         mask, lengths = K.completion_mask(completion_ids, cfg.eos_token_id)
+        lens = lengths.tolist() if self.h.trim_completions else None      # (host read: the rollouts are finished by now)
         with torch.no_grad():
             pr = self.h.precise_logps
-            ref_lp = self.ref_engine.score_group(prompt.ids, completion_ids, prompt.pix, prompt.grids, era_rule=era_rule, precise=pr)
+            ref_lp = self.ref_engine.score_group(prompt.ids, completion_ids, prompt.pix, prompt.grids, era_rule=era_rule, precise=pr, lengths=lens)
             tape: dict = {}
             lp = self.engine.score_groups([(prompt.ids, prompt.pix, prompt.grids)], [completion_ids], tape=tape, era_rule=era_rule, precise=pr,
-                                          prefill=[getattr(prompt, "prefill", None)])
+                                          prefill=[getattr(prompt, "prefill", None)], lengths=lens)
             prompt.prefill = None                      # (its share of the kept tape is consumed)
             if callable(advantages):           # lazy: the host shapes the rewards while the two forwards run (see _multi)
                 advantages = advantages()
@@ -412,7 +419,7 @@ class GRPOEngine:
                 dlogp.mul_(grad_scale)
             hook = self.reducer.ready if (last_group and self.reducer is not None and self.h.overlap_comm) else None
             self.engine.backward_group(tape, dlogp, self.G, on_ready=hook)
-        return dict(loss=loss, kl=kl, logps=lp, ref_logps=ref_lp, mask=mask, lengths=lengths)
+        return dict(loss=loss, kl=kl, logps=lp, ref_logps=ref_lp, mask=mask, lengths=lengths, scored_tokens=int(sum(lens)) if lens is not None else mask.numel())
 
     def score_and_backward_multi(self, prompts: List[PromptInput], completions: List[torch.Tensor], advantages: List[torch.Tensor],
                                  grad_scale: float = 1.0, *, era_rule: bool = False, last_group: bool = False) -> Dict[str, torch.Tensor]:
@@ -430,13 +437,14 @@ class GRPOEngine:
         self.roll.invalidate()
         comp_all = torch.cat(completions, 0)
         mask, lengths = K.completion_mask(comp_all, cfg.eos_token_id)
+        lens = lengths.tolist() if self.h.trim_completions else None      # (host read: the rollouts are finished by now)
         entries = [(p.ids, p.pix, p.grids) for p in prompts]
         with torch.no_grad():
             pr = self.h.precise_logps
-            ref_lp = self.ref_engine.score_groups(entries, completions, era_rule=era_rule, precise=pr)
+            ref_lp = self.ref_engine.score_groups(entries, completions, era_rule=era_rule, precise=pr, lengths=lens)
             tape: dict = {}
             lp = self.engine.score_groups(entries, completions, tape=tape, era_rule=era_rule, precise=pr,
-                                          prefill=[getattr(p, "prefill", None) for p in prompts])
+                                          prefill=[getattr(p, "prefill", None) for p in prompts], lengths=lens)
             for p in prompts:
                 p.prefill = None                       # (their share of the kept tape is consumed; the last reference frees it)
             if callable(advantages):
@@ -447,7 +455,7 @@ class GRPOEngine:
                 dlogp.mul_(grad_scale * Gn)
             hook = self.reducer.ready if (last_group and self.reducer is not None and self.h.overlap_comm) else None
             self.engine.backward_group(tape, dlogp, self.G, on_ready=hook)
-        return dict(loss=loss, kl=kl, logps=lp, ref_logps=ref_lp, mask=mask, lengths=lengths)
+        return dict(loss=loss, kl=kl, logps=lp, ref_logps=ref_lp, mask=mask, lengths=lengths, scored_tokens=int(sum(lens)) if lens is not None else mask.numel())
 
     def sft_forward_backward(self, ids: torch.Tensor, pix, grids, label_mask: torch.Tensor, *, grad_scale: float = 1.0,
                              second_per_grid_ts=None, last_group: bool = False) -> float:

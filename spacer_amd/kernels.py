@@ -824,7 +824,34 @@ def completion_mask(ids, eos_id):
     return mask, lens
 
 
+def gather_f32(src, idx64, *, out=None):
+    """out[j] = src.flat[idx64[j]] (fp32): d loss / d logp of the [G, C] rectangle -> the packed (EOS-trimmed) rows."""
+    n = idx64.numel()
+    assert src.dtype == torch.float32 and src.is_contiguous() and idx64.dtype == torch.int64
+    if out is None:
+        out = torch.empty(n, device=src.device, dtype=torch.float32)
+    check(_lib.load().spacer_gather_f32(_ptr(src), _ptr(idx64), _ptr(out), n, _stream()), "gather_f32")
+    return out
+
+
+def scatter_f32_(src, idx64, dst):
+    """dst.flat[idx64[j]] = src[j] (fp32): packed log-probs -> the [G, C] rectangle (zeroed by the caller)."""
+    n = idx64.numel()
+    assert src.dtype == torch.float32 and dst.dtype == torch.float32 and dst.is_contiguous() and src.is_contiguous() and src.numel() == n
+    check(_lib.load().spacer_scatter_f32(_ptr(src), _ptr(idx64), _ptr(dst), n, _stream()), "scatter_f32")
+    return dst
+
+
 # ----------------------------------------------------------------------------------------- decode helpers
+def eos_schedule_(logits32, step_dev, step_bias, eos_at, eos_id):
+    """Synthetic completion lengths: row b's EOS logit -> -inf, or dominant when *step_dev + step_bias == eos_at[b]."""
+    B, vocab = logits32.shape
+    assert eos_at.dtype == torch.int32 and eos_at.numel() == B
+    check(_lib.load().spacer_eos_schedule(_ptr(logits32), _rowmajor(logits32), B, vocab, _ptr(step_dev), step_bias, _ptr(eos_at), eos_id,
+                                          _stream()), "eos_schedule")
+    return logits32
+
+
 def sample_top_p(logits32, step_dev, *, top_k=50, top_p=0.95, temperature=1.0, seed=0, eos_id=-1, pad_id=0,
                  suppress_eos=False, finished=None, out_ids=None, out_logp=None):
     B, vocab = logits32.shape

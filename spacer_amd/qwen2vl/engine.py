@@ -473,15 +473,16 @@ class Qwen2VLEngine:
         return segs, sel.reshape(-1).int()
 
     def score_group(self, prompt_ids: torch.Tensor, completion_ids: torch.Tensor, pix: Optional[torch.Tensor], grids,
-                    *, tape: Optional[dict] = None, era_rule: bool = False, precise: bool = False) -> torch.Tensor:
+                    *, tape: Optional[dict] = None, era_rule: bool = False, precise: bool = False,
+                    lengths: Optional[Sequence[int]] = None) -> torch.Tensor:
         """Per-token log-probs [K, C] of K completions of one prompt (SG_RLVR_trainer.py:353-366,527-528),
         computed with the prompt shared: the prompt runs once and every rollout attends its keys.  ``precise=True``: the
         forward-only mode that holds the north-star's 1e-3 against an fp32 evaluation at full depth (csrc/precise.hip)."""
-        return self.score_groups([(prompt_ids, pix, grids)], [completion_ids], tape=tape, era_rule=era_rule, precise=precise)
+        return self.score_groups([(prompt_ids, pix, grids)], [completion_ids], tape=tape, era_rule=era_rule, precise=precise, lengths=lengths)
 
     def score_groups(self, prompts: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor], Optional[Sequence]]],
                      completions: Sequence[torch.Tensor], *, tape: Optional[dict] = None, era_rule: bool = False,
-                     precise: bool = False, prefill: Optional[Sequence] = None) -> torch.Tensor:
+                     precise: bool = False, prefill: Optional[Sequence] = None, lengths: Optional[Sequence[int]] = None) -> torch.Tensor:
         """``score_group`` for SEVERAL prompt groups in ONE token-packed pass: prompts[g] = (prompt_ids, pix, grids),
         completions[g] int64 [K, C] (same K, C for all g); returns [G*K, C] in group order.  Groups are independent (their
         segments never see each other), so the numbers are the single-group ones; what changes is the launch shape: every GEMM
@@ -491,11 +492,24 @@ class Qwen2VLEngine:
         rows first, so the completion rows are ONE contiguous block.  ``prefill`` (one ``PrefillSlice`` per group, from
         ``RolloutEngine.generate`` with ``keep_prefill_tape``): the rollout's prefill already ran the ViT and the prompt rows of THIS
         policy with a tape -- the pass then computes the completion rows only and takes the prompt rows of every taped tensor from
-        that tape (SG_RLVR_trainer.py:463 then :517-541 run the same prompt-side forward twice; here it runs once)."""
+        that tape (SG_RLVR_trainer.py:463 then :517-541 run the same prompt-side forward twice; here it runs once).
+        ``lengths`` (round 6; host ints, one per rollout in group order = ``spacer_completion_mask``'s lengths: tokens up to and
+        including the first EOS): EOS-TRIMMED scoring.  The reference multiplies its completion mask into the loss (TR:493-498,
+        :640-643), so positions behind a rollout's first EOS contribute exactly zero to loss, KL and every gradient; the pass then
+        packs only the first lengths[i] tokens of rollout i (segment i has q_len = lengths[i]), scores only those positions and
+        returns 0 for the others.  Row-wise kernels, GEMM rows (K-split tail off) and the attention rows do not depend on the other
+        rows of a launch, so the scored log-probs are the rectangular pass's bit for bit (tests/test_ragged_gpu.py)."""
         cfg = self.cfg
         Kn, C = completions[0].shape
         G = len(prompts)
         assert all(tuple(c.shape) == (Kn, C) for c in completions) and G == len(completions)
+        if lengths is not None:
+            lens = [min(C, max(1, int(n))) for n in lengths]
+            assert len(lens) == G * Kn, "one length per rollout"
+            if all(n == C for n in lens):
+                lens = None                               # nothing to trim: the rectangular layout as it is
+        else:
+            lens = None
         with_video = [g for g, (_, pix, _) in enumerate(prompts) if pix is not None]
         assert len(with_video) in (0, G), "groups of one pass either all carry vision inputs or none does"
         reuse = (prefill is not None and tape is not None and not precise and all(pf is not None for pf in prefill)
@@ -518,34 +532,44 @@ class Qwen2VLEngine:
         for P in plen[:-1]:
             poff.append(poff[-1] + P)
         Pt = sum(plen)                                                     # prompt rows of the pass; completions start here
-        ids_parts = [p[0].reshape(-1) for p in prompts] + [c.reshape(-1) for c in completions]
-        pos_prompt, pos_comp, seg_list, sel_parts, scope = [], [], [], [], []
+        pos_prompt, pos_comp, seg_list, sel_parts, scope, pack_parts = [], [], [], [], [], []
         t = torch.arange(C)
+        c0 = Pt                                                            # next completion row of the pass
         for g, ((prompt_ids, _, grids), comp) in enumerate(zip(prompts, completions)):
             P = plen[g]
             pos3, delta = POS.mrope_positions(prompt_ids.tolist(), list(grids or []), cfg, era_rule)
             comp_pos = (P + delta) + t                                     # same for every rollout of the group
             pos_prompt.append(pos3)
-            pos_comp += [comp_pos.view(1, C).expand(3, C)] * Kn
-            c0 = Pt + g * Kn * C                                           # first completion row of the group
             seg_list.append((poff[g], P, 0, 0))
-            seg_list += [(c0 + k * C, C, poff[g], P) for k in range(Kn)]
-            # rows whose logits predict the completions: the prompt's last row for token 0, then the completion rows
-            sel_parts.append(torch.stack([torch.where(t == 0, torch.full_like(t, poff[g] + P - 1), c0 + k * C + t - 1) for k in range(Kn)]).reshape(-1))
             scope.append((poff[g], poff[g] + P))
-        T = Pt + G * Kn * C
-        ids = torch.cat(ids_parts)
+            for k in range(Kn):
+                n = C if lens is None else lens[g * Kn + k]               # tokens of this rollout in the pass (all C, or up to its EOS)
+                pos_comp.append(comp_pos[:n].view(1, n).expand(3, n))
+                seg_list.append((c0, n, poff[g], P))
+                # rows whose logits predict the completion: the prompt's last row for token 0, then the completion rows
+                sel_parts.append(torch.cat([torch.tensor([poff[g] + P - 1]), c0 + t[:n - 1]]))
+                if lens is not None:
+                    pack_parts.append((g * Kn + k) * C + t[:n])
+                c0 += n
+        T = c0
+        comp_flat = torch.cat([c.reshape(-1) for c in completions]).contiguous()
+        if lens is None:
+            pack_idx, targets = None, comp_flat
+        else:
+            pack_idx = torch.cat(pack_parts).to(self.dev)                  # flat [G*K, C] positions of the packed tokens, int64
+            targets = comp_flat.index_select(0, pack_idx)
+        ids = torch.cat([p[0].reshape(-1) for p in prompts] + [targets])
         cos, sin = POS.mrope_tables(torch.cat(pos_prompt + pos_comp, dim=1), cfg, self.dev)
         sel = torch.cat(sel_parts).int().to(self.dev)
         max_q = max(s[1] for s in seg_list)
-        targets = torch.cat([c.reshape(-1) for c in completions]).contiguous()
+        max_c = max(s[1] for s in seg_list if s[3] > 0)
         llm_tape = [] if tape is not None else None
         if reuse:
             # placeholders sit in the prompt rows only: the vision-row map for embed_bwd is computed from the ids, no embedding of them
             _, vrow = self._vision_rows(ids, scope) if with_video else (None, None)
             xc = K.embed_fwd(ids[Pt:], self.W["llm.embed"], None, None)      # completion rows are ordinary tokens
             comp_segs = [s for s in seg_list if s[3] > 0]
-            x = self._llm_forward_reuse(xc, cos, sin, K.make_segments(comp_segs, self.dev), C, Pt, prefill, llm_tape)
+            x = self._llm_forward_reuse(xc, cos, sin, K.make_segments(comp_segs, self.dev), max_c, Pt, prefill, llm_tape)
             segs = K.make_segments(seg_list, self.dev)
         else:
             segs = K.make_segments(seg_list, self.dev)
@@ -558,8 +582,10 @@ class Qwen2VLEngine:
         logp = self.head_forward(x, sel, targets, tape, precise=precise)
         if tape is not None:
             tape.update(vit=vit_tape, llm=llm_tape, ids=ids, vrow=vrow, cos=cos, sin=sin, segs=segs, max_q=max_q, T=T,
-                        has_video=bool(with_video), reused_prefill=reuse)
-        return logp.view(G * Kn, C)
+                        has_video=bool(with_video), reused_prefill=reuse, pack_idx=pack_idx)
+        if pack_idx is None:
+            return logp.view(G * Kn, C)
+        return K.scatter_f32_(logp, pack_idx, self._zeros(G * Kn, C))      # 0 behind the mask (the loss kernel multiplies by it)
 
     # ------------------------------------------------------------------ prompt-side forward taken from the rollout's prefill
     def _vision_rows(self, ids: torch.Tensor, scopes):
@@ -714,6 +740,9 @@ class Qwen2VLEngine:
         hsel, targets, lse, logits = tape["hsel"], tape["targets"], tape["lse"], tape["logits"]
         rows, V, ch = hsel.shape[0], Wlm.shape[0], self.HEAD_CHUNK
         g = dlogp.reshape(-1).contiguous()
+        if tape.get("pack_idx") is not None:            # EOS-trimmed pass: d loss / d logp of the packed positions (0 elsewhere anyway)
+            g = K.gather_f32(g, tape["pack_idx"])
+        assert g.numel() == rows, (g.numel(), rows)
         buf = None if logits is not None else self._empty(rows, min(ch, V))
         dl_buf = self._empty(rows, min(ch, V), dtype=BF16)
         d_hsel32 = self._empty(rows, H)

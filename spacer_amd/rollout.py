@@ -69,6 +69,11 @@ class SamplingParams:
     seed: int = 0
     suppress_eos: bool = False   # fixed-length "throughput mode" of BASELINE.md
     era_rule: bool = False
+    # seeded SYNTHETIC completion lengths (round 6; a random-init policy never ends a rollout by itself, a trained one does):
+    # (lo, hi) -> rollout b ends with EOS as its L_b-th token, L_b ~ U[lo, hi] drawn from torch.Generator(seed) per generate call
+    # (L_b > max_new_tokens: no EOS).  EOS is forbidden everywhere else (spacer_eos_schedule on the step's logits), the loop ends
+    # when every row has finished, completions are padded behind EOS -- the shape of a real run's batch, with known lengths.
+    synthetic_lengths: Optional[Tuple[int, int]] = None
 
 
 class RolloutEngine:
@@ -234,6 +239,8 @@ class RolloutEngine:
         else:
             st["logits"].zero_()
             K.gemm_skinny_packed_acc(hn, PW["llm.lm_head"], st["logits"], cfg.vocab)
+        if st.get("eos_at") is not None:                 # synthetic lengths: EOS only at the scheduled token index of each row
+            K.eos_schedule_(st["logits"], st["step"], 1, st["eos_at"], cfg.eos_token_id)
         # Philox step / output column = counter + 1 = index of the token being drawn
         K.sample_top_p_step(st["logits"], st["step"], 1, st["out"], top_k=sp.top_k, top_p=sp.top_p, temperature=sp.temperature, seed=sp.seed,
                             eos_id=cfg.eos_token_id, pad_id=cfg.pad_token_id, suppress_eos=sp.suppress_eos,
@@ -242,7 +249,7 @@ class RolloutEngine:
     # ------------------------------------------------------------------ public
     @torch.no_grad()
     def generate(self, prompts: List[PromptInput], num_generations: int, sp: SamplingParams, *, use_graph: bool = True,
-                 stats: Optional[dict] = None, on_decode_start=None) -> torch.Tensor:
+                 stats: Optional[dict] = None, on_decode_start=None, _eos_at: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Returns completion ids int64 [len(prompts) * num_generations, C] (EOS kept, pad_token_id after it),
         rows ordered prompt-major like HF's num_return_sequences expansion.  ``on_decode_start()`` is called once, right after
         the decode step has been captured (graph capture synchronises the device, so work meant to run BESIDE the decode loop on
@@ -250,12 +257,17 @@ class RolloutEngine:
         cfg = self.cfg
         nP, Kn, C = len(prompts), num_generations, sp.max_new_tokens
         B = nP * Kn
+        if sp.synthetic_lengths is not None and _eos_at is None:
+            lo, hi = sp.synthetic_lengths
+            gen = torch.Generator().manual_seed(1_000_003 * sp.seed + 17)
+            _eos_at = (torch.randint(max(1, lo), hi + 1, (B,), generator=gen) - 1).int()      # token index of EOS (length - 1), host
         if B > self.MAX_ROWS:
             outs = []
             per = max(1, self.MAX_ROWS // Kn)
             for a in range(0, nP, per):
                 outs.append(self.generate(prompts[a:a + per], Kn, sp, use_graph=use_graph, stats=stats,
-                                          on_decode_start=on_decode_start if a == 0 else None))
+                                          on_decode_start=on_decode_start if a == 0 else None,
+                                          _eos_at=None if _eos_at is None else _eos_at[a * Kn:(a + per) * Kn]))
             return torch.cat(outs, 0)
         dev = self.dev
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if stats is not None else None
@@ -293,8 +305,13 @@ class RolloutEngine:
             logits=torch.empty(B, cfg.vocab, device=dev, dtype=F32),
         )
         out = st["out"] = torch.full((B, C), cfg.pad_token_id, dtype=torch.int64, device=dev)
+        st["eos_at"] = None if _eos_at is None else _eos_at.to(dev)
+        if st["eos_at"] is not None and sp.suppress_eos:
+            raise ValueError("SamplingParams: synthetic_lengths schedules EOS itself; suppress_eos must be False")
         # token 0 of every rollout comes from the prompt's last-position logits (K independent draws per prompt)
         st["logits"].copy_(first_logits.repeat_interleave(Kn, 0))
+        if st["eos_at"] is not None:
+            K.eos_schedule_(st["logits"], st["step"], 1, st["eos_at"], cfg.eos_token_id)
         K.sample_top_p_step(st["logits"], st["step"], 1, out, top_k=sp.top_k, top_p=sp.top_p, temperature=sp.temperature, seed=sp.seed,
                             eos_id=cfg.eos_token_id, pad_id=cfg.pad_token_id, suppress_eos=sp.suppress_eos,
                             finished=st["finished"], out_ids=st["cur_tok"])
