@@ -76,7 +76,8 @@ def temporal_bonus(rewards_per_func: torch.Tensor, shuffled_rewards_per_func: Op
     """SG_RLVR_trainer.py:598-617.  Column 0 = accuracy reward.  Returns (summed rewards [G], temporal_reward)."""
     if temporal and has_video:
         t = rewards_per_func.clone()
-        if float(t[:, 0].mean()) >= 0.8 * float(shuffled_rewards_per_func[:, 0].mean()):
+        # (fp32 tensor arithmetic as the reference's line: 0.8 * mean in float32, not in Python doubles -- ties decide the bonus)
+        if bool(t[:, 0].mean() >= 0.8 * shuffled_rewards_per_func[:, 0].mean()):
             sel = t[:, 0] > 0.1
             t[sel, 0] += 0.3
             return t.sum(dim=1), 1.0
@@ -88,7 +89,9 @@ def length_bonus(rewards: torch.Tensor, rewards_per_func: torch.Tensor, lengths:
     """SG_RLVR_trainer.py:620-629: +0.2 for 320 <= len <= 512, only when more than one rollout has acc > 0.1."""
     out = rewards.clone()
     if len_control:
-        idx = [i for i in range(rewards.numel()) if float(rewards_per_func[i, 0]) > 0.1]
+        # (tensor comparison as TR:622: an accuracy reward of exactly float32(0.1) is NOT > 0.1; ``float(x) > 0.1`` in Python doubles
+        # says it is -- found by the golden table of the reference's own lines, tests/golden/grpo_lines.json case "len3")
+        idx = torch.nonzero(rewards_per_func[:, 0] > 0.1, as_tuple=True)[0].tolist()
         if len(idx) > 1:
             for i in idx:
                 if 320 <= int(lengths[i]) <= 512:

@@ -59,3 +59,63 @@ def test_loss_and_gradient_closed_form():
     assert abs(float(grad[0, 0]) - (-1 + beta * (1 - math.exp(-0.5))) / 2 / 2) < 1e-7
     assert float(grad[0, 2]) == 0.0
     assert abs(float(grad[1, 1]) - (2 + beta * (1 - math.exp(-0.5))) / 3 / 2) < 1e-7
+
+
+# ----------------------------------------------------------------------------------------------- the reference's own lines
+# tests/golden/grpo_lines.json = inputs + outputs of SG_RLVR_trainer.py:493-498, 551-552, 598-643 EXECUTED from the reference's text
+# (scripts/make_golden_grpo.py: line ranges cut out with asserted anchors, exec'd against a stub ``self``): 60 mask cases, 169 step
+# cases (every flag combination, std = 0 groups, clamp edges at +-10, 0.8x threshold ties, the 320 / 512 length edges, exactly one
+# correct rollout, two groups per batch).  Checked here: the oracle's restatement AND the product's host functions (spacer_amd/grpo.py).
+def _golden():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "grpo_lines.json")) as f:
+        return json.load(f)
+
+
+def _prefix_mask(lengths, C):
+    m = torch.zeros(len(lengths), C, dtype=torch.int32)
+    for k, n in enumerate(lengths):
+        m[k, :n] = 1
+    return m
+
+
+def test_golden_mask_lines_493_498():
+    G = _golden()
+    assert G["meta"]["n_mask"] == len(G["mask"]) >= 60
+    for c in G["mask"]:
+        ids = torch.tensor(c["completion_ids"])
+        assert GR.completion_mask(ids, c["eos_token_id"]).tolist() == c["completion_mask"]
+
+
+def test_golden_step_lines_551_643_oracle_and_host_functions():
+    from spacer_amd import grpo as HOST
+    G = _golden()
+    assert len(G["step"]) >= 160
+    seen = set()
+    for c in G["step"]:
+        Kn, C = c["num_generations"], c["C"]
+        rpf = torch.tensor(c["rewards_per_func"], dtype=torch.float32)
+        srpf = None if c["shuffled_rewards_per_func"] is None else torch.tensor(c["shuffled_rewards_per_func"], dtype=torch.float32)
+        mask = _prefix_mask(c["completion_lengths"], C)
+        lp, ref = torch.tensor(c["per_token_logps"], dtype=torch.float32), torch.tensor(c["ref_per_token_logps"], dtype=torch.float32)
+        want_r, want_a = torch.tensor(c["rewards"], dtype=torch.float32), torch.tensor(c["advantages"], dtype=torch.float32)
+        # ---- oracle restatement (bit-equal on the reward path: same fp32 torch ops in the same order)
+        r_o, t_o = GR.temporal_bonus(rpf, srpf, c["temporal"], c["video"])
+        r_o = GR.length_bonus(r_o, rpf, mask, c["len_control"])
+        a_o, _ = GR.group_advantages(r_o, Kn)
+        assert t_o == c["temporal_rewards"], c["tag"]
+        assert torch.equal(r_o, want_r), (c["tag"], r_o, want_r)
+        assert torch.equal(a_o, want_a), (c["tag"], a_o, want_a)
+        if c["per_token_kl"] is not None:
+            assert torch.equal(GR.k3_kl(ref, lp), torch.tensor(c["per_token_kl"], dtype=torch.float32)), c["tag"]
+        loss_o, g_o = GR.grpo_loss_and_grad(lp, ref, want_a, mask, c["beta"])
+        assert torch.equal(loss_o, torch.tensor(c["loss"], dtype=torch.float32)) or abs(float(loss_o) - c["loss"]) <= 1e-6 * abs(c["loss"]), c["tag"]
+        assert torch.allclose(g_o, torch.tensor(c["dlogp"], dtype=torch.float32), rtol=1e-6, atol=1e-9), c["tag"]
+        # ---- the product's host functions (spacer_amd/grpo.py: what SGRLVRTrainer calls)
+        r_h, t_h = HOST.temporal_bonus(rpf, srpf, c["temporal"], c["video"])
+        r_h = HOST.length_bonus(r_h, rpf, torch.tensor(c["completion_lengths"]), c["len_control"])
+        a_h, _ = HOST.group_advantages(r_h, Kn)
+        assert t_h == c["temporal_rewards"] and torch.equal(r_h, want_r) and torch.equal(a_h, want_a), c["tag"]
+        seen.add((c["temporal"], c["video"], c["len_control"]))
+    assert len(seen) == 8                                  # every flag combination is in the table
