@@ -98,7 +98,9 @@ long spacer_gemm_workspace_bytes(void);
  *   act bf16 [M, inter] = silu(A.Wgate^T + bgate) * (A.Wup^T + bup);   gu bf16 [M, 2*inter] (or NULL) = the rounded gate|up.
  * Same bits as spacer_gemm_bf16_nt into gu + spacer_swiglu_fwd.  Always the 256-tile kernel: needs inter % 128 == 0 and K % 64 == 0
  * (SPACER_EINVAL otherwise); spacer_gemm_swiglu_fused(M, inter, K, plan) != 0 says whether the cost model WOULD put the problem on
- * that tile (large enough M) -- callers take the two-step path (GEMM + spacer_swiglu_fwd) when it returns 0. */
+ * that tile (large enough M) -- callers take the two-step path (GEMM + spacer_swiglu_fwd) when it returns 0.
+ * The predicates (this one, spacer_gemm_pair_fused, spacer_gemm_pair_epilogue_fused, spacer_gemm_tile) never return a negative code:
+ * a plan the library rejects (wrong struct_bytes) answers 0 -- "not fused" / "no tile" -- with spacer_last_error() set. */
 int spacer_gemm_swiglu_fused(int M, int inter, int K, const spacer_plan* plan);
 int spacer_gemm_swiglu_bf16(const void* A, long lda, const void* W, long ldb, const void* bias, void* act, long ld_act, void* gu,
                             long ld_gu, int M, int inter, int K, spacer_stream_t stream);

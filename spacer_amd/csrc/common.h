@@ -35,6 +35,16 @@ static inline bool plan_size_ok(const spacer_plan* p) { return !p || p->struct_b
 #define SP_REQUIRE_PLAN(p)                                                                                              \
     SP_REQUIRE(plan_size_ok(p), SPACER_EINVAL, "spacer_plan: struct_bytes = %d but this library's spacer_plan has %d bytes (stale binding?)", \
                (p) ? (p)->struct_bytes : 0, (int)sizeof(spacer_plan))
+// ... in a PREDICATE entry point (spacer_gemm_*_fused: "!= 0 means fused"; spacer_gemm_tile: 128 / 256): a rejected plan answers 0 --
+// "not fused" / "no tile" -- with the error string set, never a negative code that a caller's truth test would read as "fused"
+#define SP_PLAN_OR_ZERO(p)                                                                                             \
+    do {                                                                                                               \
+        if (!plan_size_ok(p)) {                                                                                        \
+            spacer_set_error("spacer_plan: struct_bytes = %d but this library's spacer_plan has %d bytes (stale binding?)", \
+                             (p) ? (p)->struct_bytes : 0, (int)sizeof(spacer_plan));                                 \
+            return 0;                                                                                                  \
+        }                                                                                                              \
+    } while (0)
 
 // ---- bf16 <-> f32 ----
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }

@@ -349,7 +349,7 @@ static int choose_tile(int M, int N, int K, bool have_ws, const spacer_plan* pla
 extern "C" long spacer_gemm_workspace_bytes(void) { return WS_MAX_SLABS * WS_SLAB_BYTES + WS_TAIL_BYTES; }
 
 extern "C" int spacer_gemm_tile(int M, int N, int K, int have_workspace, const spacer_plan* plan) {
-    SP_REQUIRE_PLAN(plan);
+    SP_PLAN_OR_ZERO(plan);
     return choose_tile(M, N, K, have_workspace != 0, plan);
 }
 
@@ -450,7 +450,7 @@ extern "C" int spacer_gemm_bf16_nt(const void* A, long lda, const void* B, long 
 // [B | B] (the weights are exactly bf16, so only the activation is a pair) instead of two accumulate passes: the fp32 output is
 // written once (no read-modify-write pass) and the launch's fixed costs are paid once.
 extern "C" int spacer_gemm_pair_fused(int M, int N, int K, int have_workspace, const spacer_plan* plan) {
-    SP_REQUIRE_PLAN(plan);
+    SP_PLAN_OR_ZERO(plan);
     return K % BK == 0 && choose_tile(M, N, 2 * K, have_workspace != 0, plan) == 256;
 }
 
@@ -476,7 +476,7 @@ static bool pair_epilogue_ok(int kind, int M, int N, int K, int head_dim, bool h
 }
 
 extern "C" int spacer_gemm_pair_epilogue_fused(int kind, int M, int N, int K, int head_dim, int have_workspace, const spacer_plan* plan) {
-    SP_REQUIRE_PLAN(plan);
+    SP_PLAN_OR_ZERO(plan);
     return pair_epilogue_ok(kind, M, N, K, head_dim, have_workspace != 0, plan) ? 1 : 0;
 }
 
@@ -542,7 +542,7 @@ extern "C" int spacer_gemm_bf16(const void* A, long lda, const void* B, long ldb
 // spacer_gemm_bf16_nt into gu followed by spacer_swiglu_fwd.  Returns SPACER_EINVAL when the problem would not run on the
 // 256 tile (spacer_gemm_swiglu_fused(M, inter, K) == 0): the caller then takes the two-step path.
 extern "C" int spacer_gemm_swiglu_fused(int M, int inter, int K, const spacer_plan* plan) {
-    SP_REQUIRE_PLAN(plan);
+    SP_PLAN_OR_ZERO(plan);
     return inter > 0 && inter % 128 == 0 && K % BK == 0 && choose_tile(M, 2 * inter, K, false, plan) == 256;
 }
 

@@ -370,6 +370,10 @@ class GRPOEngine:
         # (the closure holds the hyper-parameter object, not this engine: a GRPOEngine <-> RolloutEngine reference cycle would keep
         # 165 GB of training state alive until the cyclic collector runs)
         self.roll.keep_prefill_tape = lambda h=hyper: False if (h.recompute or h.precise_logps) else h.reuse_prefill
+        # the auto decision (reuse_prefill = None) is made from STATIC sizes -- the device's memory, the training state allocated below
+        # (2 + 2 + 4 + 4 + 4 + 4 bytes per parameter) and the decode-layout weight copies -- not from the allocator's free memory at the
+        # moment of the call: the same configuration decides the same way on every run, rank and step
+        self.roll.static_bytes = policy.flat.numel() * (2 + 2 + 4 + 4 + 4 + 4 + 2)
         self.master = FlatParams(cfg, policy.flat.float(), policy.specs)
         self.G = policy.like(F32)
         self.m = torch.zeros_like(self.master.flat)
@@ -399,6 +403,16 @@ class GRPOEngine:
         eng = {"policy": self.engine, "ref": self.ref_engine}[which]
         return eng.score_groups([(p.ids, p.pix, p.grids) for p in prompts], completions, era_rule=era_rule, precise=precise)
 
+    def _take_prefill(self, prompts: List[PromptInput], era_rule: bool):
+        """The prompts' shares of a kept prefill tape, detached from the prompts; None -- and the shares released BEFORE the scoring
+        forwards run -- when the policy's pass cannot use them (precise / recompute mode, other weights, mixed passes)."""
+        pf = [getattr(p, "prefill", None) for p in prompts]
+        for p in prompts:
+            p.prefill = None
+        if any(x is None for x in pf) or self.h.precise_logps:
+            return None
+        return pf if self.engine._prefill_usable(pf, [(p.ids, p.pix, p.grids) for p in prompts], era_rule) else None
+
     def score_and_backward(self, prompt: PromptInput, completion_ids: torch.Tensor, advantages: torch.Tensor,
                            grad_scale: float = 1.0, *, era_rule: bool = False, last_group: bool = False) -> Dict[str, torch.Tensor]:
         """One prompt group: masks, reference + policy log-probs, loss, backward into self.G.  ``advantages`` fp32 [K]
@@ -407,13 +421,14 @@ class GRPOEngine:
         cfg = self.cfg
         mask, lengths = K.completion_mask(completion_ids, cfg.eos_token_id)
         lens = lengths.tolist() if self.h.trim_completions else None      # (host read: the rollouts are finished by now)
+        pf = self._take_prefill([prompt], era_rule)
         with torch.no_grad():
             pr = self.h.precise_logps
             ref_lp = self.ref_engine.score_group(prompt.ids, completion_ids, prompt.pix, prompt.grids, era_rule=era_rule, precise=pr, lengths=lens)
             tape: dict = {}
             lp = self.engine.score_groups([(prompt.ids, prompt.pix, prompt.grids)], [completion_ids], tape=tape, era_rule=era_rule, precise=pr,
-                                          prefill=[getattr(prompt, "prefill", None)], lengths=lens)
-            prompt.prefill = None                      # (its share of the kept tape is consumed)
+                                          prefill=pf, lengths=lens)
+            del pf                                     # (its share of the kept tape is consumed)
             if callable(advantages):           # lazy: the host shapes the rewards while the two forwards run (see _multi)
                 advantages = advantages()
                 advantages = (advantages[0] if isinstance(advantages, (list, tuple)) else advantages).to(self.dev)
@@ -442,14 +457,13 @@ class GRPOEngine:
         mask, lengths = K.completion_mask(comp_all, cfg.eos_token_id)
         lens = lengths.tolist() if self.h.trim_completions else None      # (host read: the rollouts are finished by now)
         entries = [(p.ids, p.pix, p.grids) for p in prompts]
+        pf = self._take_prefill(prompts, era_rule)
         with torch.no_grad():
             pr = self.h.precise_logps
             ref_lp = self.ref_engine.score_groups(entries, completions, era_rule=era_rule, precise=pr, lengths=lens)
             tape: dict = {}
-            lp = self.engine.score_groups(entries, completions, tape=tape, era_rule=era_rule, precise=pr,
-                                          prefill=[getattr(p, "prefill", None) for p in prompts], lengths=lens)
-            for p in prompts:
-                p.prefill = None                       # (their share of the kept tape is consumed; the last reference frees it)
+            lp = self.engine.score_groups(entries, completions, tape=tape, era_rule=era_rule, precise=pr, prefill=pf, lengths=lens)
+            del pf                                     # (their share of the kept tape is consumed; the last reference frees it)
             if callable(advantages):
                 advantages = advantages()
             # the loss kernel averages over its rows: G groups of K rows -> mean over G*K rows = (1/G) * sum of group means
@@ -523,9 +537,14 @@ class GRPOEngine:
                           beta2=h.adam_beta2, eps=h.adam_eps, weight_decay=h.weight_decay, step=self.step_count,
                           sumsq=self._sumsq, max_norm=h.max_grad_norm, grad_scale=gscale)
         K.zero_(self.G.flat)
-        self.engine.weights_version += 1               # a kept prefill tape belongs to the weights that produced it
-        self.roll.invalidate()
+        self.weights_changed()
         return lr
+
+    def weights_changed(self) -> None:
+        """EVERY writer of ``policy.flat`` calls this (the optimizer step above, a checkpoint load): a prefill tape kept by the rollout
+        engine belongs to the weights that produced it, and the decode-layout weight copies are stale."""
+        self.engine.weights_version += 1
+        self.roll.invalidate()
 
     def gather_optimizer_state(self) -> None:
         """rs_ag keeps fp32 master weights and Adam moments current only in the owner's shard; before they are saved (or the

@@ -358,19 +358,23 @@ class SGRLVRTrainer:
         G = self.num_generations
         sp = SamplingParams(max_new_tokens=self.max_completion_length, top_k=self.args.top_k, top_p=0.95, temperature=1.0,
                             seed=self._sample_seed + 7919 * self.global_step, era_rule=self.era_rule, suppress_eos=self.suppress_eos)
-        prompts, slots = [], []
-        for prep in preps:
-            slots.append((len(prompts), prep["sproc"] is not None))
-            prompts.append(self._prompt_input(prep["proc"]))
+        # batch order: every sample's own prompt first, the frame-shuffled twins behind them -- the scored prompts are then CONSECUTIVE
+        # in the prefill pass, which is what lets the policy's scoring pass take its prompt rows from a kept prefill tape
+        # (Qwen2VLEngine._prefill_usable; interleaved [p0, twin0, p1, twin1] never qualified with two groups per pass: ADVICE r5)
+        prompts = [self._prompt_input(prep["proc"]) for prep in preps]
+        twin_at = {}
+        for i, prep in enumerate(preps):
             if prep["sproc"] is not None:
+                twin_at[i] = len(prompts)
                 prompts.append(self._prompt_input(prep["sproc"]))
         ids = self._generate(prompts, G, sp)
         host = ids.cpu()       # ONE device-to-host copy for the step, taken when the decode loop has just ended: the reward
         #                        functions read it while the scoring passes run (no sync inside the scoring phase)
         out = []
-        for at, twin in slots:
-            sl = slice((at + 1) * G, (at + 1) * G + self.shuffled_num_generations)
-            out.append(dict(prompt=prompts[at], completion_ids=ids[at * G:(at + 1) * G], completion_host=host[at * G:(at + 1) * G],
+        for i in range(len(preps)):
+            twin = i in twin_at
+            sl = slice(twin_at[i] * G, twin_at[i] * G + self.shuffled_num_generations) if twin else None
+            out.append(dict(prompt=prompts[i], completion_ids=ids[i * G:(i + 1) * G], completion_host=host[i * G:(i + 1) * G],
                             shuffled_ids=ids[sl] if twin else None, shuffled_host=host[sl] if twin else None))
         return out
 
@@ -596,4 +600,4 @@ class SGRLVRTrainer:
                                      "(checkpoint of another architecture / layout version)")
                 dst.copy_(st[name])
             e.step_count = int(st["step_count"])
-        self.engine.roll.invalidate()
+        self.engine.weights_changed()                  # (bumps the prefill-tape version too: every writer of the weights calls this)

@@ -97,6 +97,8 @@ class RolloutEngine:
         # (may also be a callable returning one of those, evaluated per generate call: GRPOEngine ties it to its live hyper-parameters)
         self.keep_prefill_tape = False
         self.prefill_tape_bytes = 0
+        self.static_bytes = 0            # bytes that live beside the tape for the whole step (GRPOEngine: the training state); see _tape_fits
+        self._fit_logged = set()
 
     # ------------------------------------------------------------------ decode-layout weights
     def invalidate(self) -> None:
@@ -137,10 +139,20 @@ class RolloutEngine:
         patches = sum(p.pix.shape[0] for p in prompts if p.pix is not None)
         need = toks * per_tok + patches * per_patch
         self.prefill_tape_bytes = need
-        free, total = torch.cuda.mem_get_info(self.dev)
-        free += torch.cuda.memory_reserved(self.dev) - torch.cuda.memory_allocated(self.dev)      # the caching allocator's own pool
-        # the scoring passes that follow need ~ (K C / P + 1) x the tape of their groups on top of it; keep a third of the part free
-        return need * 4 < free and need < 0.15 * total
+        # STATIC sizes only (a decision taken from the allocator's free memory at call time made the numerics of a run depend
+        # on what happened to be allocated -- the reuse pass equals the full pass bit for bit only under one GEMM summation order): the
+        # device's memory minus what lives beside the tape for the whole step.  The scoring passes that follow need ~ (K C / P + 1) x
+        # the tape of their groups on top of it; keep a third of the part free
+        total = torch.cuda.get_device_properties(self.dev).total_memory
+        avail = total - self.static_bytes
+        fits = need * 4 < avail and need < 0.15 * total
+        key = (toks, patches, fits)
+        if key not in self._fit_logged and len(self._fit_logged) < 8:
+            self._fit_logged.add(key)
+            import sys
+            print(f"[spacer_amd] prefill tape ({need / 1e9:.1f} GB for {toks} prompt tokens, {patches} patches) "
+                  f"{'kept for' if fits else 'NOT kept for'} the policy's scoring pass: {avail / 1e9:.0f} GB beside the training state", file=sys.stderr)
+        return fits
 
     def _prefill(self, prompts: List[PromptInput], era_rule: bool, keep_tape: bool = False):
         """ViT + LLM prefill of ALL prompts as one token-packed pass (one attention segment per prompt, one set of GEMMs

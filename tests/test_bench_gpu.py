@@ -32,7 +32,10 @@ def test_bench_json_contract_tiny(dev):
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "samples/s" and cb["sample"]
     v = d["variants"]
-    assert set(v) == {"temporal", "free_running", "through_trainer", "precise_scoring", "decode_cfg4_rows", "precise_step"}, set(v)
+    assert set(v) == {"temporal", "free_running", "ragged", "through_trainer", "precise_scoring", "decode_cfg4_rows", "precise_step"}, set(v)
+    rg = v["ragged"]        # EOS-trimmed scoring vs the [K, C] rectangle on the same seeded variable-length rollouts
+    assert rg["trimmed"]["completion_tokens_scored_per_step"] < rg["rectangular"]["completion_tokens_scored_per_step"] == rg["trimmed"]["rectangle_tokens_per_step"]
+    assert rg["trimmed"]["samples_per_s"] > 0 and rg["rectangular"]["samples_per_s"] > 0 and rg["speedup_trimmed_vs_rectangular"] > 0
     assert all("samples_per_s" in v[k] for k in ("temporal", "free_running", "through_trainer", "precise_step")), v
     assert v["through_trainer"]["gradient_accumulation_steps"] == 2 and v["through_trainer"]["vs_headline"] > 0
     assert v["through_trainer"]["steps"] == 4 and v["precise_step"]["vs_headline_step_time"] > 0

@@ -35,6 +35,22 @@ def test_library_exports_every_declared_symbol():
     assert rc == -1 and b"null operand" in lib.spacer_last_error()
 
 
+def test_plan_predicates_answer_zero_on_a_rejected_plan():
+    """the predicate entry points (``!= 0 means fused``; tile 128 / 256) must never hand a negative error code to a caller's
+    truth test -- a plan of the wrong size (stale binding) answers 0 with the error string set.  Pure host functions: no GPU."""
+    import ctypes as C
+    lib = _lib.load()
+    good, bad = _lib.Plan(), _lib.Plan()
+    bad.struct_bytes = C.sizeof(_lib.Plan) - 4
+    assert lib.spacer_gemm_tile(5498, 3584, 3584, 1, C.byref(good)) in (128, 256)
+    assert lib.spacer_gemm_swiglu_fused(5498, 18944, 3584, C.byref(good)) == 1
+    for call in (lambda: lib.spacer_gemm_tile(5498, 3584, 3584, 1, C.byref(bad)),
+                 lambda: lib.spacer_gemm_swiglu_fused(5498, 18944, 3584, C.byref(bad)),
+                 lambda: lib.spacer_gemm_pair_fused(5498, 3584, 3584, 1, C.byref(bad)),
+                 lambda: lib.spacer_gemm_pair_epilogue_fused(_lib.SPACER_PAIR_SWIGLU, 5498, 37888, 3584, 128, 1, C.byref(bad))):
+        assert call() == 0 and b"struct_bytes" in lib.spacer_last_error()
+
+
 def test_kernels_refuse_cpu_tensors():
     from spacer_amd import kernels as K
     with pytest.raises(K.SpacerError):
