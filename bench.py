@@ -370,6 +370,13 @@ def main():
                     help="create the process group (and run the reducer / barrier / max-over-ranks code) even for a world of ONE rank: "
                          "exercises the RCCL path of the multi-GPU job on a one-GPU box (tests)")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 --pmc passes for roofline.traffic (use the committed table)")
+    ap.add_argument("--synthetic-lengths", default=None, metavar="LO,HI",
+                    help="rollouts END: seeded completion lengths ~U[LO, HI] per rollout (SamplingParams.synthetic_lengths; other lengths on "
+                         "every rank and step) instead of the fixed-length throughput mode -- ranks then arrive at the gradient exchange at "
+                         "different times (rank_compute_ms), the scoring passes are EOS-trimmed")
+    ap.add_argument("--no-strong", action="store_true",
+                    help="N > 1: skip the second measured region with ONE prompt group per rank (the reference script's launch shape; "
+                         "object strong_cfg4 of the line)")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra --temporal / free-running measurements (N = 1)")
     ap.add_argument("--phase-times", action="store_true", help="print per-phase wall times (adds synchronisations)")
     ap.add_argument("--gemm-shapes", action="store_true", help="also print the GEMM time broken down by (M,N,K) to stderr")
@@ -438,6 +445,10 @@ def main():
     random_init_(params, seed=1234)
     ge = GRPOEngine(cfg, params, hyper, process_group=pg)
     sp = SamplingParams(max_new_tokens=C, top_k=50, top_p=0.95, temperature=1.0, seed=1234 + rank, suppress_eos=True)
+    if args.synthetic_lengths:
+        from dataclasses import replace as _rep
+        lo_hi = tuple(int(x) for x in args.synthetic_lengths.split(","))
+        sp = _rep(sp, suppress_eos=False, synthetic_lengths=(lo_hi[0], lo_hi[1]))
     frames = [synthetic_frames(rank * groups + g, F, Hpx, Wpx, dev) for g in range(groups)]   # resident in HBM
     phase = {}
     roll_stats = {}
@@ -451,11 +462,18 @@ def main():
         return t0
 
     gpp_default = args.groups_per_pass or (2 if args.workload in ("cfg3", "cfg3_qwen25", "cfg2", "tiny") else 1)
+    groups_all = groups
 
     tok_stats = {"scored": 0, "rectangle": 0}
 
-    def step(step_idx, temporal=args.temporal, sp=sp, groups_per_pass=None):
+    arrive = {"on": False, "events": []}      # per step: (event at step start, event right before the gradient exchange) on the launch stream
+
+    def step(step_idx, temporal=args.temporal, sp=sp, groups_per_pass=None, groups_n=None):
+        groups = groups_n or groups_all            # (groups_n = 1: the reference script's launch shape inside a weak-scaling run)
         t0 = time.perf_counter()
+        if arrive["on"]:
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record()
         if sp.synthetic_lengths is not None:          # other lengths every step (seeded: identical on every run)
             from dataclasses import replace as _replace
             sp = _replace(sp, seed=sp.seed + 7919 * step_idx)
@@ -496,6 +514,10 @@ def main():
             tok_stats["scored"] += res["scored_tokens"]             # completion tokens in the scoring passes / the backward
             tok_stats["rectangle"] += res["mask"].numel()           # ... of the [K, C] rectangle the reference scores (TR:527-541)
         t0 = tick("score+backward", t0)
+        if arrive["on"]:      # this rank's own work of the step is queued: the time up to here is what a straggler is late by
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record()
+            arrive["events"].append((ev0, ev1))
         ge.reduce_gradients()
         ge.optimizer_step(world)
         tick("reduce+adamw", t0)
@@ -506,6 +528,37 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(n_steps, first_idx, **kw):
+        """EXACTLY n_steps steps between barrier + synchronize on both sides; returns (wall seconds, MAX over ranks; this rank's mean
+        milliseconds of own work per step before the gradient exchange, from HIP events on the launch stream)."""
+        arrive["events"].clear()
+        arrive["on"] = dist_on
+        barrier()
+        t_start = time.perf_counter()
+        for i in range(n_steps):
+            step(first_idx + i, **kw)
+        barrier()
+        dt = time.perf_counter() - t_start
+        arrive["on"] = False
+        own_ms = sum(a.elapsed_time(b) for a, b in arrive["events"]) / max(1, len(arrive["events"])) if arrive["events"] else None
+        if dist_on:
+            import torch.distributed as dist
+            t = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t)
+        return dt, own_ms
+
+    def rank_spread(own_ms):
+        """min / max over ranks of the per-step time a rank needs for its own work before the exchange: the straggler spread the
+        all-reduce waits for (rollout lengths differ per rank in a real run; throughput mode fixes C)."""
+        if not dist_on or own_ms is None:
+            return None
+        import torch.distributed as dist
+        parts = [None] * world
+        dist.all_gather_object(parts, float(own_ms))
+        return {"min": round(min(parts), 1), "max": round(max(parts), 1), "what": "ms per step of a rank's own work (rollout + scoring + backward "
+                "queued up to the gradient exchange), HIP events on the launch stream; max - min = what the fastest rank waits at the exchange"}
+
     for i in range(args.warmup):
         step(i)
     phase.clear()
@@ -513,20 +566,37 @@ def main():
     K.PROFILER.reset(enabled=True)
     K.PROFILER.by_shape = args.gemm_shapes
     ge.comm_timing(True)
-    barrier()
-    t_start = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    barrier()
-    elapsed = time.perf_counter() - t_start
+    tok_stats.update(scored=0, rectangle=0)
+    elapsed, own_ms = timed(args.steps, args.warmup)
+    tok_main = dict(tok_stats)
     K.PROFILER.enabled = False
     comm = ge.comm_stats(args.steps)
     ge.comm_timing(False)
-    if dist_on:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
+    spread = rank_spread(own_ms)
+    # ---- N > 1: the OTHER reading of BASELINE configs[3]: ONE prompt group per rank and step -- at N = 8 the reference
+    # script's own global batch of 64 rollouts (run_SpaceR_SG_RLVR.sh:21,39) -- measured in the same job right after the weak-scaling
+    # region.  Its step is 80 % a C-step decode loop whose time does not depend on the row count, so it scales against ONE GPU
+    # running the same 64 rollouts (the cfg3 headline) only up to ~2.4x at N = 8 ("two readings")
+    strong = None
+    if dist_on and groups_all > 1 and not args.no_strong:
+        try:
+            main_stats_keep = dict(roll_stats)
+            for i in range(1):
+                step(50_000 + i, groups_n=1)
+            ge.comm_timing(True)
+            n_s = max(2, min(args.steps, 5))
+            dt_s, own_s = timed(n_s, 50_100, groups_n=1)
+            strong = {"groups_per_gpu": 1, "global_batch": Kgen * world, "value": round(Kgen * world * n_s / dt_s, 4), "unit": "samples/s",
+                      "ms_per_step": round(1e3 * dt_s / n_s, 2), "steps": n_s, "warmup": 1, "scaling": "strong against one GPU running the same "
+                      "N x K rollouts (at N = 8: the cfg3 headline's 64 rollouts)", "rccl_world": world,
+                      "comm": ge.comm_stats(n_s), "rank_compute_ms": rank_spread(own_s),
+                      "what": "--groups 1: ONE prompt group (K rollouts) per rank and step = the reference script's launch shape; at N = 8 "
+                              "its global batch of 64 rollouts (BASELINE configs[3], --workload cfg4)"}
+            ge.comm_timing(False)
+            roll_stats.clear()
+            roll_stats.update(main_stats_keep)
+        except Exception as exc:      # noqa: BLE001 -- the weak-scaling line must survive
+            strong = {"error": f"{type(exc).__name__}: {exc}"[:300]}
     replicas_identical = None
     if dist_on and args.check_replicas:
         import torch.distributed as dist
@@ -679,7 +749,7 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {preset} random-init bf16, {F} frames {Hpx}x{Wpx}, {n_text} text tokens, "
-                                   f"K={Kgen}, C={C} (EOS suppressed), {groups} prompt groups/GPU, full step "
+                                   f"K={Kgen}, C={C} ({'EOS suppressed' if sp.suppress_eos else 'rollouts end at seeded lengths U' + str(list(sp.synthetic_lengths))}), {groups} prompt groups/GPU, full step "
                                    f"(rollout+ref/policy scoring+backward+AdamW)",
                        "global_batch": groups * Kgen * world, "parallelism": f"dp{world}", "decode_graph": not args.no_graph,
                        "grad_comm": args.grad_comm, "grad_algo": args.grad_algo, "overlap_comm": not args.no_overlap, "backend": args.backend, "groups_per_pass": max(1, min(gpp_default, groups)),
@@ -733,6 +803,17 @@ def main():
                 out["roofline_hbm"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
         if comm is not None:
             out["comm"] = comm
+        if spread is not None:
+            out["rank_compute_ms"] = spread
+        if tok_main["rectangle"]:
+            out["completion_tokens_scored_per_step"] = tok_main["scored"] // args.steps       # EOS-trimmed scoring (GRPOHyper.trim_completions)
+            out["rectangle_tokens_per_step"] = tok_main["rectangle"] // args.steps            # ... of the [K, C] rectangle the reference scores
+        if strong is not None:
+            out["strong_cfg4"] = strong
+        if dist_on:
+            # what a multi-GPU line does NOT contain, so that N = 1, 2, 4, 8 back to back stay inside the driver's window: no variants,
+            # no CPU baseline, no PMC passes (all N = 1 only)
+            out["n_gt_1_skips"] = ["variants", "cpu_baseline", "roofline.traffic (PMC)", "roofline_hbm"] if world > 1 else []
         if replicas_identical is not None:
             out["replicas_identical"] = replicas_identical
         if variants:

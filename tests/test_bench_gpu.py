@@ -73,21 +73,27 @@ def test_bench_two_ranks_control_flow_on_one_gpu(dev, algo):
     assert d["comm"]["rccl_world"] == 2 and d["comm"]["bytes_on_wire_per_gpu_per_step"] > 0 and algo.split("_")[0] in d["comm"]["algo"]
 
 
-@pytest.mark.parametrize("groups", [None, 1], ids=["2-groups-per-rank", "cfg4-style-1-group-per-rank"])
+@pytest.mark.parametrize("groups,ragged", [(None, False), (1, False), (None, True)],
+                         ids=["2-groups-per-rank", "cfg4-style-1-group-per-rank", "2-groups-per-rank-other-lengths-on-every-rank"])
 @pytest.mark.parametrize("algo", ["allreduce", "rs_ag"])
-def test_bench_eight_ranks_on_one_gpu(dev, algo, groups):
+def test_bench_eight_ranks_on_one_gpu(dev, algo, groups, ragged):
     """Multi-GPU readiness at the world size the driver's scaling run uses (run_SpaceR_SG_RLVR.sh:9-13 launches 8
     ranks, zero3.json:14-33 = overlapped bf16 gradient exchange): `bench.py --gpus 8 --backend gloo` = 8 processes on the box's ONE GPU
     (gradients staged through the host) -- shard bounds of the sharded exchange at n = 8, bucket schedule of the overlapped reducer, the
     packed metric gather, per-rank seeds, barrier + max-over-ranks timing.  Replicas must end bit-identical and the comm object must
     state 2 (n-1)/n x gradient bytes on the wire per GPU (all-reduce) / (n-1)/n x (gradient + weight bytes) (rs_ag), on the bf16 wire.
-    With --groups 1 every rank holds ONE prompt group per step: the reference script's own launch shape (cfg4)."""
+    With --groups 1 every rank holds ONE prompt group per step: the reference script's own launch shape (cfg4).  Round 6: with
+    --synthetic-lengths every rank's rollouts END at other seeded lengths (EOS-trimmed scoring passes of other sizes on every rank: the
+    collectives and the replicas must not care), and a weak-scaling line (groups > 1) carries the SECOND reading of the DP = 8 config --
+    ``strong_cfg4`` (one group per rank, measured in the same job) -- plus the per-rank straggler spread; an N > 1 line never runs the
+    variants, the CPU baseline or PMC passes (the driver runs N = 1, 2, 4, 8 back to back)."""
     from spacer_amd.qwen2vl.config import TINY
     from spacer_amd.qwen2vl.weights import param_specs, total_numel
     n = 8
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tiny", "--gpus", str(n), "--steps", "2", "--warmup", "1",
-           "--backend", "gloo", "--grad-algo", algo, "--check-replicas"] + (["--groups", str(groups)] if groups else [])
+           "--backend", "gloo", "--grad-algo", algo, "--check-replicas"] + (["--groups", str(groups)] if groups else []) \
+        + (["--synthetic-lengths", "3,32"] if ragged else [])
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
@@ -101,6 +107,19 @@ def test_bench_eight_ranks_on_one_gpu(dev, algo, groups):
     want = 2 * (n - 1) / n * numel * 2 if algo == "allreduce" else (n - 1) / n * (numel * 2 + numel * 2)
     assert d["comm"]["rccl_world"] == n and d["comm"]["wire_dtype"] == "bf16"
     assert d["comm"]["bytes_on_wire_per_gpu_per_step"] == round(want), (d["comm"], want)
+    assert "variants" not in d and "cpu_baseline" not in d and "roofline_hbm" not in d and d["roofline"]["traffic"] is None
+    assert set(d["n_gt_1_skips"]) >= {"variants", "cpu_baseline"}
+    assert d["rank_compute_ms"]["max"] >= d["rank_compute_ms"]["min"] > 0
+    if g > 1:        # the reference script's launch shape measured in the same job
+        sc = d["strong_cfg4"]
+        assert sc["groups_per_gpu"] == 1 and sc["global_batch"] == n * 4 and sc["value"] > 0 and sc["rccl_world"] == n
+        assert sc["comm"]["bytes_on_wire_per_gpu_per_step"] == round(want) and sc["rank_compute_ms"]["min"] > 0
+    else:
+        assert "strong_cfg4" not in d
+    if ragged:
+        assert d["completion_tokens_scored_per_step"] < d["rectangle_tokens_per_step"] and "rollouts end" in d["config"]["workload"]
+    else:
+        assert d["completion_tokens_scored_per_step"] == d["rectangle_tokens_per_step"]
 
 
 @pytest.mark.parametrize("algo", ["allreduce", "rs_ag"])
