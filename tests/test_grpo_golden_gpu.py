@@ -1,7 +1,7 @@
 """GPU: ``spacer_completion_mask`` and ``spacer_grpo_loss`` against tests/golden/grpo_lines.json -- the outputs of the reference's OWN
 lines (SG_RLVR_trainer.py:493-498, 551-552, 640-643 executed from its text by scripts/make_golden_grpo.py).  Mask and lengths
-bit-exact; loss, d loss / d logp and the KL metric (TR:682, from the table's per-token KL) within 1e-6 relative (the kernel uses the
-hardware exp and combines row sums with fp32 atomics)."""
+bit-exact; loss, d loss / d logp and the KL metric (TR:682, from the table's per-token KL) within 2e-6 relative plus a few fp32 ulps of
+the exponential (the kernel uses the hardware exp and combines row sums with fp32 atomics)."""
 import json
 import os
 
@@ -49,6 +49,8 @@ def test_grpo_loss_kernel_equals_the_reference_lines(dev):
         if c["per_token_kl"] is not None:
             pk = torch.tensor(c["per_token_kl"], dtype=torch.float32)
             want_kl = float(((pk * mask).sum(1) / mask.sum(1)).mean())                     # TR:682
-            assert abs(float(kl) - want_kl) <= 2e-6 * max(abs(want_kl), 1e-6), (c["tag"], float(kl), want_kl)
+            # e^x - x - 1 cancels: for |x| ~ 0.1 the value is ~ x^2 / 2 while e^x carries an fp32 rounding of ~1e-7 ABSOLUTE (in the
+            # reference's torch.exp as in the kernel's hardware exp) -- so the bound has an absolute term of a few ulps of 1.0
+            assert abs(float(kl) - want_kl) <= 2e-6 * abs(want_kl) + 3e-7, (c["tag"], float(kl), want_kl)
         n += 1
     assert n >= 160

@@ -611,14 +611,18 @@ def test_precise_grpo_step_matches_the_cpu_oracle_at_full_depth(dev, depth):
         assert torch.equal(r["mask"].cpu(), mask)
         del ge, r
         torch.cuda.empty_cache()
+    # round 6: the step scores only the tokens up to each rollout's first EOS (GRPOHyper.trim_completions); the positions behind it
+    # enter the reference's loss multiplied by a zero mask (TR:640-643), so log-probs are compared where the mask is 1
+    mb = mask.bool()
     for mode, tag in ((False, "fast step   "), (True, "precise step")):
         r = res[mode]
-        print(f"   {tag}: max |logp - oracle| policy {float((r['lp'] - lp_o.detach()).abs().max()):.2e} reference "
-              f"{float((r['ref'] - ref_o).abs().max()):.2e}; loss {r['loss']:+.6f} (oracle {float(loss_o.detach()):+.6f}); kl {r['kl']:.6f} (oracle {kl_o:.6f})")
+        assert float(r["lp"][~mb].abs().max()) == 0.0                        # (not scored: row 1 ends after 16 of 24 tokens)
+        print(f"   {tag}: max |logp - oracle| policy {float((r['lp'] - lp_o.detach())[mb].abs().max()):.2e} reference "
+              f"{float((r['ref'] - ref_o)[mb].abs().max()):.2e}; loss {r['loss']:+.6f} (oracle {float(loss_o.detach()):+.6f}); kl {r['kl']:.6f} (oracle {kl_o:.6f})")
     print(f"   Qwen2-VL-{depth.upper()}: oracle (2 forwards + autograd backward on the host, weight export): {t_oracle:.0f} s")
     r = res[True]
     assert kl_o > 1e-3                                                       # the case is not the trivial ref == policy one
-    assert float((r["lp"] - lp_o.detach()).abs().max()) <= 1e-3 and float((r["ref"] - ref_o).abs().max()) <= 1e-3
+    assert float((r["lp"] - lp_o.detach())[mb].abs().max()) <= 1e-3 and float((r["ref"] - ref_o)[mb].abs().max()) <= 1e-3
     assert abs(r["loss"] - float(loss_o.detach())) <= 1e-3 and abs(r["kl"] - kl_o) <= 1e-3
     got = r["G"]
     got["visual.patch_embed.proj.weight"] = got["visual.patch_embed.proj.weight"].reshape(cfg.vit_dim, -1)

@@ -181,14 +181,18 @@ def test_step_trimmed_equals_rectangular_and_the_oracle(dev):
     assert res[True][5] == 1 + 7 + 8 + 16 + 16 + 3 + 16 + 2 + 1 + 15 and res[False][5] == 10 * C
     assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
     # (the loss kernel combines its per-row sums with fp32 atomics in arrival order: equal inputs, last-digit differences in the scalars)
-    assert abs(res[True][2] - res[False][2]) <= 2e-6 * abs(res[False][2]) and abs(res[True][3] - res[False][3]) <= 2e-6 * abs(res[False][3])
-    assert float((res[True][4].float() - res[False][4].float()).abs().max()) <= 1e-6
+    # (and the loss is a small difference of O(|A|) row terms -- the advantages of a group sum to zero -- so its tolerance is absolute)
+    assert abs(res[True][2] - res[False][2]) <= 1e-6 and abs(res[True][3] - res[False][3]) <= 2e-6 * abs(res[False][3])
+    # updated bf16 weights: equal except where the gradients' summation-order noise (see _check_pass) moved an fp32 master weight across
+    # a bf16 rounding boundary -- at most one bf16 ulp (2^-7 relative), on a handful of the 2.9 M parameters
+    wa, wb = res[True][4].float(), res[False][4].float()
+    assert bool(((wa - wb).abs() <= 2.0 ** -7 * wb.abs() + 1e-30).all()) and float((wa != wb).float().mean()) < 1e-3
     # oracle restatement of TR:493-498, 551-552, 640-643 on the engine's own log-probs: the trimmed step's loss / KL
     mask_o = GR.completion_mask(torch.cat(comps, 0).cpu(), TINY.eos_token_id)
     assert torch.equal(mask_o.int(), res[True][6].int())
     adv2 = torch.cat([adv, adv])
     loss_o = GR.grpo_loss(res[True][7], res[True][8], adv2, mask_o, 0.04)
-    assert abs(float(loss_o) - res[True][2]) <= 1e-5 * max(1.0, abs(float(loss_o)))
+    assert abs(float(loss_o) - res[True][2]) <= 1e-5
 
 
 def test_synthetic_lengths_rollout(dev):
