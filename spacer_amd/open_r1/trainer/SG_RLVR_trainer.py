@@ -158,7 +158,13 @@ class SGRLVRTrainer:
         if peft_config is not None:
             raise NotImplementedError("PEFT adapters are outside the SG-RLVR hot path of this engine")
         if any(isinstance(f, str) for f in (reward_funcs if isinstance(reward_funcs, list) else [reward_funcs])):
-            raise NotImplementedError("string reward_funcs (sequence-classification reward models) are not used by SpaceR")
+            # The reference still LOADS a string as AutoModelForSequenceClassification (TR:240-244), but its compute_loss calls every
+            # reward function as ``reward_func(prompts=, completions=, video_path=, **columns)`` (TR:579-592): TRL's
+            # ``isinstance(reward_func, PreTrainedModel)`` branch (tokenise prompt + completion, read logits[:, 0]) was removed there, so a
+            # reward MODEL fails at the reference's first step with a TypeError.  Refused here at construction, with the reason.
+            raise NotImplementedError("string reward_funcs (sequence-classification reward models): the reference loads them (TR:240-244) but its "
+                                      "compute_loss calls every reward function as a plain callable (TR:579-592), which a PreTrainedModel is not; "
+                                      "pass Python callables (open_r1.rewards.accuracy_reward / format_reward, or your own)")
         if attn_implementation not in (None, "flash_attention_2", "sdpa", "eager"):
             raise ValueError(f"unknown attn_implementation {attn_implementation!r}")
         self._log_lines: List[str] = []
