@@ -40,7 +40,9 @@ def test_grpo_loss_kernel_equals_the_reference_lines(dev):
         adv = torch.tensor(c["advantages"], dtype=torch.float32, device=dev)
         loss, kl, dlogp = K.grpo_loss(lp, ref, adv, mask.to(dev), c["beta"])
         want_loss = c["loss"]
-        assert abs(float(loss) - want_loss) <= 1e-6 * max(abs(want_loss), 1e-3) + 1e-7 * float(adv.abs().max()), (c["tag"], float(loss), want_loss)
+        # the loss is a mean of row terms of size |A| that cancel across the group (advantages sum to zero); a row term is itself a sum
+        # of up to 516 fp32 values -- the bound is relative to |A| (a few fp32 ulps of the row sums, in torch's order or the kernel's)
+        assert abs(float(loss) - want_loss) <= 1e-6 * abs(want_loss) + 5e-7 * max(float(adv.abs().max()), 1e-3), (c["tag"], float(loss), want_loss)
         want_g = torch.tensor(c["dlogp"], dtype=torch.float32)
         got_g = dlogp.cpu()
         scale = float(want_g.abs().max())
