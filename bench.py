@@ -499,7 +499,9 @@ def main():
             rpf = synthetic_rewards(step_idx, rank * groups + g, Kgen)
             srpf = synthetic_rewards(step_idx + 100003, rank * groups + g, Kgen // 2) if scomp is not None else None
             rewards, _ = temporal_bonus(rpf, srpf, scomp is not None, True)
-            rewards = length_bonus(rewards, rpf, torch.full((Kgen,), cg.shape[1]), hyper.len_control)
+            # (rollouts that end -- synthetic lengths / free-running -- enter the length rule with their own lengths, TR:620-629)
+            lens_g = torch.full((Kgen,), cg.shape[1]) if sp.suppress_eos else K.completion_mask(cg, cfg.eos_token_id)[1].cpu()
+            rewards = length_bonus(rewards, rpf, lens_g, hyper.len_control)
             advs.append(group_advantages(rewards, Kgen)[0])
         gpp = max(1, min(groups_per_pass or gpp_default, groups))
         for g0 in range(0, groups, gpp):

@@ -950,8 +950,11 @@ static int launch_skinny_swiglu(const void* A, long lda, const void* Bpacked, vo
         SP_CHECK_LAUNCH();
         return SPACER_OK;
     }
-    if (one_round || small) {
-        // (<= 16 rows outside the one-round window: one whole-K workgroup per 64 columns, no tail balance -- the small models' shapes)
+    if (one_round || normed) {
+        // (the norm-folded form outside the one-round window: one whole-K workgroup per 64 columns, no tail balance -- the small models'
+        // shapes, measured at 16 rows of 2B in profiles/r05_decode_small_rows.md; every workgroup must cover all of K to sum x^2 itself, so
+        // plan->skinny_blocks / skinny_no_balance do not apply to it.  ADVICE r5: the NON-normed <= 16-row launches outside the window
+        // keep the tail-balanced path below, which honours those switches, as before round 5)
         const dim3 grid(one_round ? slots1 : col_groups, 1);
 #define SKINNY_SWIGLU_LAUNCH(NRM, SML)                                                                                              \
         hipLaunchKernelGGL((gemm_skinny_kernel<true, true, 1, NRM, SML>), grid, dim3(256), 0, stream, (const bf16_t*)A, lda,       \
