@@ -1,5 +1,6 @@
 """Generate tests/golden/grpo_lines.json by EXECUTING the reference's own text for the GRPO lines of ``SGRLVRTrainer.compute_loss``
-(SG_RLVR_trainer.py:493-498 first-EOS mask, :551-552 k3 KL, :598-643 T-GRPO bonus / length bonus / group advantage / loss) on seeded
+(SG_RLVR_trainer.py:493-498 first-EOS mask, :551-552 k3 KL, :598-643 T-GRPO bonus / length bonus / group advantage / loss, :650-683 the
+logged metrics of an emulated multi-rank world) on seeded
 cases.  The module cannot be imported here (top-level ``import trl`` / ``qwen_vl_utils``), so the three line ranges are cut out of the
 file (anchors asserted, so that drift of the reference is loud), dedented and exec'd against a stub ``self`` and CPU tensors;
 ``.to('cuda')`` (TR:610-613) is redirected to the CPU for the duration of the exec.  Data only: inputs and the reference's outputs
@@ -22,6 +23,8 @@ OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 RANGES = {
     "mask": (493, 498, {493: "is_eos = completion_ids == self.processing_class.eos_token_id", 498: "completion_mask = (sequence_indices <= eos_idx.unsqueeze(1)).int()"}),
     "kl": (551, 552, {551: "x_clamped = torch.clamp(ref_per_token_logps - per_token_logps, min=-10, max=10)", 552: "per_token_kl = torch.exp(x_clamped) - x_clamped - 1"}),
+    "metrics": (650, 683, {650: "completion_length = self.accelerator.gather_for_metrics(completion_mask.sum(1)).float().mean().item()",
+                           665: "wrong_devices = (rewards_per_device <= 1).all(dim=1)", 683: 'self._metrics["kl"].append(self.accelerator.gather_for_metrics(mean_kl).mean().item())'}),
     "loss": (598, 643, {598: "if self.temporal and video_inputs:", 620: "if self.len_control:", 638: "advantages = (rewards - mean_grouped_rewards) / (std_grouped_rewards + 1e-4)",
                         643: "loss = ((per_token_loss * completion_mask).sum(dim=1) / completion_mask.sum(dim=1)).mean()"}),
 }
@@ -76,12 +79,54 @@ def run_loss(code_kl, code_loss, *, temporal, video, len_control, K, beta, rpf, 
                 advantages=f32(ns["advantages"]), loss=f32(ns["loss"]), dlogp=f32(lp.grad))
 
 
+def run_metrics(code, ranks, *, temporal, K, func_names):
+    """TR:650-683 on every rank of an emulated world: ``accelerator.gather_for_metrics`` returns the concatenation over ranks of the
+    k-th gathered tensor (pass 1 records what every rank hands to its k-th gather call -- the control flow is rank-independent --, pass 2
+    replays with the concatenations; 0-dim tensors gather to one element per rank, as accelerate does).  Returns rank 0's metric dict
+    (asserted equal on every rank)."""
+    import collections
+
+    def funcs():
+        out = []
+        for n in func_names:
+            f = lambda **kw: None  # noqa: E731
+            f.__name__ = n
+            out.append(f)
+        return out
+
+    def one(rank, gather):
+        r = ranks[rank]
+        me = types.SimpleNamespace(accelerator=types.SimpleNamespace(gather_for_metrics=gather), _metrics=collections.defaultdict(list),
+                                   reward_funcs=funcs(), num_generations=K, temporal=temporal)
+        ns = {"torch": torch, "self": me, "PreTrainedModel": type("PreTrainedModel", (), {}), "completion_mask": r["mask"],
+              "rewards_per_func": r["rpf"], "rewards": r["rewards"], "temporal_rewards": r["temporal_rewards"],
+              "std_grouped_rewards": r["std"], "per_token_kl": r["kl"]}
+        exec(code, ns)
+        return {k: v[0] for k, v in me._metrics.items()}
+    record = [[] for _ in ranks]
+    for rk in range(len(ranks)):
+        one(rk, lambda t, rk=rk: (record[rk].append(t.clone()), t)[1])
+    n_calls = len(record[0])
+    assert all(len(x) == n_calls for x in record)
+    outs = []
+    for rk in range(len(ranks)):
+        k = [0]
+
+        def gather(t, k=k):
+            parts = [record[q][k[0]] for q in range(len(ranks))]
+            k[0] += 1
+            return torch.cat([p.reshape(1) if p.dim() == 0 else p for p in parts])
+        outs.append(one(rk, gather))
+    assert all(o == outs[0] for o in outs)
+    return outs[0]
+
+
 def main():
     lines = open(REF, encoding="utf-8").read().split("\n")
-    code_mask, code_kl, code_loss = cut(lines, "mask"), cut(lines, "kl"), cut(lines, "loss")
+    code_mask, code_kl, code_loss, code_metrics = cut(lines, "mask"), cut(lines, "kl"), cut(lines, "loss"), cut(lines, "metrics")
     g = torch.Generator().manual_seed(20260929)
     R = lambda *shape: torch.rand(*shape, generator=g)  # noqa: E731
-    cases = {"mask": [], "step": []}
+    cases = {"mask": [], "step": [], "metrics": []}
 
     # ---- TR:493-498: no EOS, EOS at 0, several EOS, all EOS, EOS last, one-column matrices
     eos = 7
@@ -178,8 +223,32 @@ def main():
         add(f"twogroups{i}", temporal=False, video=True, len_control=bool(i % 2), K=Kn, beta=0.04, rpf=rpf, srpf=None,
             mask=masks(2 * Kn, 9, [int(torch.randint(1, 10, (1,), generator=g)) for _ in range(2 * Kn)]), lp=lp, ref=ref)
 
-    meta = {"source": "SpaceR-SG-RLVR/src/r1-v/src/open_r1/trainer/SG_RLVR_trainer.py lines 493-498, 551-552, 598-643, executed by scripts/make_golden_grpo.py",
-            "torch": torch.__version__, "n_mask": len(cases["mask"]), "n_step": len(cases["step"])}
+    # ---- TR:650-683: the logged metrics of a world of W ranks (one prompt group of K rollouts per rank, as the reference script runs)
+    for i in range(40):
+        W, Kn = (1, 2, 3, 8)[i % 4], (2, 4, 8)[i % 3]
+        temporal = bool(i % 2)
+        C = int(torch.randint(4, 12, (1,), generator=g))
+        ranks = []
+        for rk in range(W):
+            kind = int(torch.randint(0, 4, (1,), generator=g))      # 0 / 1: mixed, 2: every reward <= 1 (all_wrong rank), 3: every reward >= 2 (all_correct rank)
+            rpf = rewards(Kn)
+            if kind == 2:
+                rpf = torch.stack([torch.zeros(Kn), torch.randint(0, 2, (Kn,), generator=g).float()], 1)
+            if kind == 3:
+                rpf = torch.stack([1.0 + R(Kn), torch.ones(Kn)], 1)
+            rw = rpf.sum(1)
+            lens = [int(torch.randint(1, C + 1, (1,), generator=g)) for _ in range(Kn)]
+            std = rw.view(-1, Kn).std(dim=1).repeat_interleave(Kn, dim=0)
+            ranks.append(dict(rpf=rpf, rewards=rw, mask=masks(Kn, C, lens), temporal_rewards=torch.tensor([(1.0, 0.0, 0.5)[int(torch.randint(0, 3, (1,), generator=g))]]),
+                              std=std, kl=R(Kn, C) * 0.1, lens=lens))
+        out = run_metrics(code_metrics, ranks, temporal=temporal, K=Kn, func_names=["accuracy_reward", "format_reward"])
+        cases["metrics"].append(dict(world=W, num_generations=Kn, temporal=temporal, C=C,
+                                     ranks=[dict(completion_lengths=r["lens"], rewards_per_func=f32(r["rpf"]), rewards=f32(r["rewards"]),
+                                                 temporal_rewards=f32(r["temporal_rewards"].reshape(())), std_grouped_rewards=f32(r["std"]), per_token_kl=f32(r["kl"])) for r in ranks],
+                                     metrics={k: float(v) for k, v in out.items()}))
+
+    meta = {"source": "SpaceR-SG-RLVR/src/r1-v/src/open_r1/trainer/SG_RLVR_trainer.py lines 493-498, 551-552, 598-643, 650-683, executed by scripts/make_golden_grpo.py",
+            "torch": torch.__version__, "n_mask": len(cases["mask"]), "n_step": len(cases["step"]), "n_metrics": len(cases["metrics"])}
     with open(OUT, "w") as f:
         json.dump(dict(meta=meta, **cases), f, separators=(",", ":"))
     print("wrote", OUT, meta, os.path.getsize(OUT), "bytes")

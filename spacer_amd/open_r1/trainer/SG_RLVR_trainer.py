@@ -123,8 +123,11 @@ def reduce_metrics(stacked: torch.Tensor, func_names: Sequence[str], temporal: b
     out = {"completion_length": float(m[1])}
     for i, n in enumerate(func_names):
         out[f"rewards/{n}"] = float(m[8 + i])
-    out["all_wrong"] = float(m[6])
-    out["all_correct"] = float(m[7])
+    # (TR:665-669: integer counts of ranks divided in Python doubles -- 1 / 3 is 0.3333333333333333 in the reference's log, not the fp32 mean
+    # 0.3333333432674408; pinned by tests/golden/grpo_lines.json "metrics")
+    world = stacked.shape[0]
+    out["all_wrong"] = int(stacked[:, 6].sum().item()) / world
+    out["all_correct"] = int(stacked[:, 7].sum().item()) / world
     if temporal:
         out["temporal_rewards"] = float(m[5])
     out["reward"] = float(m[2])

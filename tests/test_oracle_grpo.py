@@ -119,3 +119,33 @@ def test_golden_step_lines_551_643_oracle_and_host_functions():
         assert t_h == c["temporal_rewards"] and torch.equal(r_h, want_r) and torch.equal(a_h, want_a), c["tag"]
         seen.add((c["temporal"], c["video"], c["len_control"]))
     assert len(seen) == 8                                  # every flag combination is in the table
+
+
+def test_golden_metric_lines_650_683_packed_gather():
+    """The logged metrics (TR:650-683: nine ``gather_for_metrics`` calls per micro-batch) executed from the reference's text on emulated
+    worlds of 1 / 2 / 3 / 8 ranks (one prompt group per rank) vs the product's ONE packed vector per rank (``pack_metrics``) and its
+    reduction (``reduce_metrics``): same keys, same values (means of equal-sized rank means re-associate an fp32 sum: 1e-6 relative);
+    ``all_wrong`` / ``all_correct`` are fractions of ranks, exact."""
+    from spacer_amd.open_r1.trainer import SG_RLVR_trainer as T
+    G = _golden()
+    assert G["meta"]["n_metrics"] == len(G["metrics"]) >= 40
+    worlds = set()
+    for c in G["metrics"]:
+        packed = []
+        for r in c["ranks"]:
+            mask = _prefix_mask(r["completion_lengths"], c["C"])
+            kl = torch.tensor(r["per_token_kl"], dtype=torch.float32)
+            mean_kl = float(((kl * mask).sum(1) / mask.sum(1)).mean())
+            packed.append(T.pack_metrics(torch.tensor(r["completion_lengths"]), torch.tensor(r["rewards_per_func"], dtype=torch.float32),
+                                         torch.tensor(r["rewards"], dtype=torch.float32), r["temporal_rewards"],
+                                         torch.tensor(r["std_grouped_rewards"], dtype=torch.float32), mean_kl))
+        got = T.reduce_metrics(torch.stack(packed), ["accuracy_reward", "format_reward"], c["temporal"])
+        want = c["metrics"]
+        assert list(got) == list(want), (list(got), list(want))             # same keys in the reference's order
+        for k in want:
+            if k in ("all_wrong", "all_correct"):
+                assert got[k] == want[k], (k, got[k], want[k])
+            else:
+                assert abs(got[k] - want[k]) <= 2e-6 * max(abs(want[k]), 1e-3), (k, got[k], want[k], c["world"])
+        worlds.add(c["world"])
+    assert worlds == {1, 2, 3, 8}
