@@ -1,5 +1,5 @@
 """Generate tests/golden/grpo_lines.json by EXECUTING the reference's own text for the GRPO lines of ``SGRLVRTrainer.compute_loss``
-(SG_RLVR_trainer.py:493-498 first-EOS mask, :551-552 k3 KL, :598-643 T-GRPO bonus / length bonus / group advantage / loss, :650-683 the
+(SG_RLVR_trainer.py:357-366 + 528 per-token log-probs of a stub model's logits and the completion slice, :493-498 first-EOS mask, :551-552 k3 KL, :598-643 T-GRPO bonus / length bonus / group advantage / loss, :650-683 the
 logged metrics of an emulated multi-rank world) on seeded
 cases.  The module cannot be imported here (top-level ``import trl`` / ``qwen_vl_utils``), so the three line ranges are cut out of the
 file (anchors asserted, so that drift of the reference is loud), dedented and exec'd against a stub ``self`` and CPU tensors;
@@ -23,6 +23,9 @@ OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 RANGES = {
     "mask": (493, 498, {493: "is_eos = completion_ids == self.processing_class.eos_token_id", 498: "completion_mask = (sequence_indices <= eos_idx.unsqueeze(1)).int()"}),
     "kl": (551, 552, {551: "x_clamped = torch.clamp(ref_per_token_logps - per_token_logps, min=-10, max=10)", 552: "per_token_kl = torch.exp(x_clamped) - x_clamped - 1"}),
+    "logps": (357, 366, {357: "logits = model(input_ids, **kwargs).logits", 358: "logits = logits[:, :-1, :]", 363: "log_probs = logits_row.log_softmax(dim=-1)",
+                         366: "return torch.stack(per_token_logps)"}),
+    "slice": (528, 528, {528: "per_token_logps = per_token_logps[:, prompt_length - 1 :]"}),
     "metrics": (650, 683, {650: "completion_length = self.accelerator.gather_for_metrics(completion_mask.sum(1)).float().mean().item()",
                            665: "wrong_devices = (rewards_per_device <= 1).all(dim=1)", 683: 'self._metrics["kl"].append(self.accelerator.gather_for_metrics(mean_kl).mean().item())'}),
     "loss": (598, 643, {598: "if self.temporal and video_inputs:", 620: "if self.len_control:", 638: "advantages = (rewards - mean_grouped_rewards) / (std_grouped_rewards + 1e-4)",
@@ -79,6 +82,23 @@ def run_loss(code_kl, code_loss, *, temporal, video, len_control, K, beta, rpf, 
                 advantages=f32(ns["advantages"]), loss=f32(ns["loss"]), dlogp=f32(lp.grad))
 
 
+def run_logps(lines, logits, input_ids, prompt_length):
+    """TR:357-366 (the body of ``_get_per_token_logps``, wrapped back into a function because it ends in ``return``) on a stub model that
+    returns the given logits, then TR:528 (the completion slice)."""
+    a, b, anchors = RANGES["logps"]
+    for ln, text in anchors.items():
+        assert text in lines[ln - 1], f"reference drifted: line {ln} is {lines[ln - 1]!r}"
+    body = textwrap.dedent("\n".join(lines[a - 1:b]))
+    src = "def _get_per_token_logps(model, input_ids, **kwargs):\n" + textwrap.indent(body, "    ")
+    ns = {"torch": torch}
+    exec(compile(src, f"{REF}:{a}-{b}", "exec"), ns)
+    model = lambda ids, **kw: types.SimpleNamespace(logits=logits)  # noqa: E731
+    per_token_logps = ns["_get_per_token_logps"](model, input_ids)
+    ns2 = {"per_token_logps": per_token_logps, "prompt_length": prompt_length}
+    exec(cut(lines, "slice"), ns2)
+    return per_token_logps, ns2["per_token_logps"]
+
+
 def run_metrics(code, ranks, *, temporal, K, func_names):
     """TR:650-683 on every rank of an emulated world: ``accelerator.gather_for_metrics`` returns the concatenation over ranks of the
     k-th gathered tensor (pass 1 records what every rank hands to its k-th gather call -- the control flow is rank-independent --, pass 2
@@ -126,7 +146,7 @@ def main():
     code_mask, code_kl, code_loss, code_metrics = cut(lines, "mask"), cut(lines, "kl"), cut(lines, "loss"), cut(lines, "metrics")
     g = torch.Generator().manual_seed(20260929)
     R = lambda *shape: torch.rand(*shape, generator=g)  # noqa: E731
-    cases = {"mask": [], "step": [], "metrics": []}
+    cases = {"mask": [], "step": [], "metrics": [], "logps": []}
 
     # ---- TR:493-498: no EOS, EOS at 0, several EOS, all EOS, EOS last, one-column matrices
     eos = 7
@@ -247,8 +267,22 @@ def main():
                                                  temporal_rewards=f32(r["temporal_rewards"].reshape(())), std_grouped_rewards=f32(r["std"]), per_token_kl=f32(r["kl"])) for r in ranks],
                                      metrics={k: float(v) for k, v in out.items()}))
 
-    meta = {"source": "SpaceR-SG-RLVR/src/r1-v/src/open_r1/trainer/SG_RLVR_trainer.py lines 493-498, 551-552, 598-643, 650-683, executed by scripts/make_golden_grpo.py",
-            "torch": torch.__version__, "n_mask": len(cases["mask"]), "n_step": len(cases["step"]), "n_metrics": len(cases["metrics"])}
+    # ---- TR:357-366 + 528: log_softmax(logits[:, :-1])[ids[:, 1:]] and the completion slice (logits of widely different scales, a row
+    # whose target carries almost all / almost none of the mass)
+    for i in range(24):
+        B, L, V = int(torch.randint(1, 5, (1,), generator=g)), int(torch.randint(3, 14, (1,), generator=g)), (17, 40, 129)[i % 3]
+        P = int(torch.randint(1, L, (1,), generator=g))
+        logits = (R(B, L, V) - 0.5) * (1.0, 8.0, 40.0, 0.01)[i % 4]
+        ids = torch.randint(0, V, (B, L), generator=g)
+        if i % 6 == 0:
+            logits[0, 0, ids[0, 1]] += 60.0             # probability ~ 1: log-prob ~ -0
+        if i % 6 == 3:
+            logits[0, 0, ids[0, 1]] -= 60.0             # probability ~ e-60
+        full, sliced = run_logps(lines, logits, ids, P)
+        cases["logps"].append(dict(logits=f32(logits), input_ids=ids.tolist(), prompt_length=P, per_token_logps=f32(full), completion_logps=f32(sliced)))
+
+    meta = {"source": "SpaceR-SG-RLVR/src/r1-v/src/open_r1/trainer/SG_RLVR_trainer.py lines 357-366, 493-498, 528, 551-552, 598-643, 650-683, executed by scripts/make_golden_grpo.py",
+            "torch": torch.__version__, "n_mask": len(cases["mask"]), "n_step": len(cases["step"]), "n_metrics": len(cases["metrics"]), "n_logps": len(cases["logps"])}
     with open(OUT, "w") as f:
         json.dump(dict(meta=meta, **cases), f, separators=(",", ":"))
     print("wrote", OUT, meta, os.path.getsize(OUT), "bytes")

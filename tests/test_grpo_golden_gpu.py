@@ -56,3 +56,30 @@ def test_grpo_loss_kernel_equals_the_reference_lines(dev):
             assert abs(float(kl) - want_kl) <= 2e-6 * abs(want_kl) + 3e-7, (c["tag"], float(kl), want_kl)
         n += 1
     assert n >= 160
+
+
+def test_logprob_kernels_equal_the_reference_lines(dev):
+    """``spacer_logprob_fwd`` and the chunked online form (``spacer_lse_chunk`` / ``spacer_lse_finish``: what the head runs over vocabulary
+    chunks) against TR:357-366 executed on the same logits: log-probs of the completion positions within 1e-6 of the reference's fp32
+    log_softmax (relative to the row's logit scale: both sides subtract a row maximum of that size)."""
+    for c in _golden()["logps"]:
+        logits = torch.tensor(c["logits"], dtype=torch.float32)
+        ids = torch.tensor(c["input_ids"])
+        B, L, V = logits.shape
+        P = c["prompt_length"]
+        rows = logits[:, P - 1:L - 1].reshape(-1, V)                         # the rows that predict the completion tokens
+        tgt = ids[:, P:].reshape(-1).to(dev)
+        want = torch.tensor(c["completion_logps"], dtype=torch.float32).reshape(-1)
+        Vp = (V + 3) // 4 * 4
+        buf = torch.zeros(rows.shape[0], Vp, device=dev)
+        buf[:, :V] = rows.to(dev)
+        lp, _ = K.logprob_fwd(buf[:, :V], tgt)
+        scale = max(1.0, float(rows.abs().max()))
+        assert float((lp.cpu() - want).abs().max()) <= 2e-6 * scale, (float((lp.cpu() - want).abs().max()), scale)
+        state = torch.empty(3, rows.shape[0], device=dev)
+        ch = 16
+        for c0 in range(0, V, ch):
+            c1 = min(V, c0 + ch)
+            K.lse_chunk_(buf[:, c0:c1], tgt, c0, state, first=c0 == 0)
+        lp2, _ = K.lse_finish(state)
+        assert float((lp2.cpu() - want).abs().max()) <= 2e-6 * scale

@@ -149,3 +149,17 @@ def test_golden_metric_lines_650_683_packed_gather():
                 assert abs(got[k] - want[k]) <= 2e-6 * max(abs(want[k]), 1e-3), (k, got[k], want[k], c["world"])
         worlds.add(c["world"])
     assert worlds == {1, 2, 3, 8}
+
+
+def test_golden_logp_lines_357_366_and_the_completion_slice():
+    """TR:357-366 executed on a stub model's logits (+ TR:528, the ``[:, prompt_length - 1:]`` slice): the oracle's ``per_token_logps``
+    restatement, row by row."""
+    from oracle import qwen2vl_fp32 as O
+    G = _golden()
+    assert G["meta"]["n_logps"] == len(G["logps"]) >= 24
+    for c in G["logps"]:
+        logits, ids = torch.tensor(c["logits"], dtype=torch.float32), torch.tensor(c["input_ids"])
+        want = torch.tensor(c["per_token_logps"], dtype=torch.float32)
+        got = torch.stack([O.per_token_logps(logits[b], ids[b]) for b in range(ids.shape[0])])
+        assert torch.equal(got, want) or float((got - want).abs().max()) <= 1e-6 * max(1.0, float(want.abs().max()))
+        assert torch.equal(want[:, c["prompt_length"] - 1:], torch.tensor(c["completion_logps"], dtype=torch.float32))
