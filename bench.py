@@ -484,11 +484,11 @@ def main():
             for g in range(groups):
                 perm = torch.randperm(F, generator=torch.Generator().manual_seed(77 + step_idx * 1009 + rank * groups + g)).to(dev)
                 sprompts.append(make_prompt(cfg, rank * groups + g, F, Hpx, Wpx, n_text, dev, frames_u8=frames[g][perm])[0])
-            # main and twin rollouts decode as ONE batch (2 x groups x K rows <= 128: the weights stream once); the twin's
-            # surplus K/2 rollouts per prompt are dropped, as SGRLVRTrainer does
-            both = ge.roll.generate(prompts + sprompts, Kgen, sp, use_graph=not args.no_graph, stats=roll_stats)
+            # main and twin rollouts decode as ONE batch (groups x (K + K/2) rows <= 128: the weights stream once)
+            # (round 6: the twins generate K / 2 rollouts each, as TR:473 -- 96 decode rows per 8 groups instead of 128)
+            both = ge.roll.generate(prompts + sprompts, [Kgen] * groups + [Kgen // 2] * groups, sp, use_graph=not args.no_graph, stats=roll_stats)
             comp = both[:groups * Kgen]
-            scomp = both[groups * Kgen:].view(groups, Kgen, -1)[:, :Kgen // 2].reshape(groups * (Kgen // 2), -1)
+            scomp = both[groups * Kgen:]
         else:
             comp = ge.roll.generate(prompts, Kgen, sp, use_graph=not args.no_graph, stats=roll_stats)
         t0 = tick("rollout", t0)

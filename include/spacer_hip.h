@@ -222,6 +222,14 @@ int spacer_attn_decode_shared(const void* q, const void* prefix_k, const void* p
                               const int* prompt_of, const void* tail_k, const void* tail_v, const int* tail_len_dev, void* o,
                               void* workspace, int B, int Kn, int Pmax, int Cmax, int Hq, int Hkv, int D, float scale,
                               spacer_stream_t stream);
+/* The same with PER-PROMPT rollout counts (round 6): prompt p owns the decode rows [row0[p], row0[p + 1]) (row0 int32 [n_prompts + 1] on the
+ * device; at most Kmax rows per prompt, Kmax * Hq / Hkv <= 64).  The reference's T-GRPO branch generates G / 2 rollouts for the
+ * frame-shuffled twin of a sample (TR:473 num_return_sequences = self.shuffled_num_generations): main + twin rollouts of 8 samples decode as
+ * 8 x 8 + 8 x 4 = 96 rows instead of 128 (4.87 instead of 5.47 ms per token-step).  workspace as spacer_attn_decode_shared. */
+int spacer_attn_decode_shared_rows(const void* q, const void* prefix_k, const void* prefix_v, const int* prefix_len,
+                                   const int* prompt_of, const int* row0, const void* tail_k, const void* tail_v,
+                                   const int* tail_len_dev, void* o, void* workspace, int B, int n_prompts, int Kmax, int Pmax,
+                                   int Cmax, int Hq, int Hkv, int D, float scale, spacer_stream_t stream);
 
 /* Decode-step helpers (all read the step / tail length from device memory so that one decode step can be
  * captured in a hipGraph and replayed):

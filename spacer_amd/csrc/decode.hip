@@ -588,7 +588,9 @@ __global__ __launch_bounds__(256, 2) void attn_decode_split_kernel(const bf16_t*
                                                                    const bf16_t* __restrict__ tk, const bf16_t* __restrict__ tv,
                                                                    const int* __restrict__ tail_len, float* __restrict__ pre,
                                                                    float* __restrict__ tailp, int n_prefix_blocks, int Kn, int Pmax,
-                                                                   int Cmax, int Hq, int Hkv, float scale) {
+                                                                   int Cmax, int Hq, int Hkv, float scale, const int* __restrict__ row0) {
+    // row0 != nullptr (round 6): prompt pr owns the rows [row0[pr], row0[pr + 1]) -- per-prompt rollout counts (the T-GRPO twins take
+    // G / 2 rollouts, TR:473); nullptr: the uniform layout, prompt pr owns rows [pr Kn, (pr + 1) Kn)
     constexpr int D = 128, DC = 4, DF = 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];               // 64 KiB: A: K + V images; B: 4 wave-private V images
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -639,7 +641,8 @@ __global__ __launch_bounds__(256, 2) void attn_decode_split_kernel(const bf16_t*
         const int tiles = (P + 63) >> 6, tps = (tiles + PRE_SPLITS - 1) / PRE_SPLITS;
         const int t0 = sp * tps, t1 = min(tiles, t0 + tps);
         const int col = wave * 16 + l15;                       // (rollout, head) column of this lane
-        const bool col_ok = col < Kn * REP;
+        const int r0 = row0 ? row0[pr] : pr * Kn, kcnt = row0 ? row0[pr + 1] - r0 : Kn;
+        const bool col_ok = col < kcnt * REP;
         const long row_stride = (long)Hkv * D;
         bf16x8 qf[DC];
         uint4 ka[4], va[4], kb[4], vb[4];
@@ -666,7 +669,7 @@ __global__ __launch_bounds__(256, 2) void attn_decode_split_kernel(const bf16_t*
         };
         {   // q fragments first, then the tile requests (in-order vmcnt: the first tile does not wait for the later ones)
             const int kr = col_ok ? col / REP : 0, hr = col_ok ? col % REP : 0;
-            const bf16_t* qp = q + ((long)(pr * Kn + kr) * Hq + hk * REP + hr) * D;
+            const bf16_t* qp = q + ((long)(r0 + kr) * Hq + hk * REP + hr) * D;
 #pragma unroll
             for (int dc = 0; dc < DC; ++dc) {
                 uint4 t = make_uint4(0, 0, 0, 0);
@@ -775,12 +778,13 @@ __global__ __launch_bounds__(256, 2) void attn_decode_split_kernel(const bf16_t*
 // trip (the records were just written from other XCDs); the 256-thread form looped 3.5 outputs per thread, a round trip each.
 template <int REP>
 __global__ __launch_bounds__(REP * 128) void attn_decode_merge_kernel(const float* __restrict__ pre, const float* __restrict__ tailp,
-                                                                      bf16_t* __restrict__ o, int Kn, int Hq, int Hkv) {
+                                                                      bf16_t* __restrict__ o, int Kn, int Hq, int Hkv,
+                                                                      const int* __restrict__ prompt_of, const int* __restrict__ row0) {
     constexpr int D = 128;
-    const int b = blockIdx.x, hk = blockIdx.y, pr = b / Kn;
+    const int b = blockIdx.x, hk = blockIdx.y, pr = row0 ? prompt_of[b] : b / Kn;
     const int qh = threadIdx.x >> 7, d = threadIdx.x & 127;
     const float* tp = tailp + ((long)b * Hkv + hk) * REP * (D + 2) + qh * (D + 2);
-    const int col = (b - pr * Kn) * REP + qh;
+    const int col = (b - (row0 ? row0[pr] : pr * Kn)) * REP + qh;
     const float* pp = pre + ((long)(pr * Hkv + hk) * PRE_SPLITS * 64 + col) * (D + 2);
     float ms[PRE_SPLITS + 1], ls[PRE_SPLITS + 1], os[PRE_SPLITS + 1];
 #pragma unroll
@@ -1055,7 +1059,7 @@ extern "C" int spacer_swiglu_f32_fwd(float* acc32, void* y, int B, int inter, sp
 static int launch_attn_decode(const void* q, const void* prefix_k, const void* prefix_v, const int* prefix_len,
                               const int* prompt_of, const void* tail_k, const void* tail_v, const int* tail_len_dev,
                               void* o, float* pre_ws, int Kn, int B, int Pmax, int Cmax, int Hq, int Hkv, int D, float scale,
-                              spacer_stream_t stream) {
+                              spacer_stream_t stream, const int* row0 = nullptr, int n_prompts = 0) {
     SP_REQUIRE(D == 128, SPACER_EINVAL, "attn_decode: head_dim %d unsupported (128)", D);
     SP_REQUIRE(Hkv > 0 && Hq % Hkv == 0, SPACER_EINVAL, "attn_decode: bad head counts");
     if (B <= 0) return SPACER_OK;
@@ -1071,9 +1075,11 @@ static int launch_attn_decode(const void* q, const void* prefix_k, const void* p
                            (const bf16_t*)tail_v, tail_len_dev, (bf16_t*)o, Pmax, Cmax, Hq, Hkv, scale, (float*)nullptr, Kn); \
     }
     if (pre_ws) {
-        SP_REQUIRE(Kn > 0 && Kn * rep <= 64 && B % Kn == 0, SPACER_EINVAL, "attn_decode_shared: Kn*rep=%d must be <= 64", Kn * rep);
-        const int nA = (B / Kn) * Hkv * PRE_SPLITS;
-        float* tailp = pre_ws + (long)(B / Kn) * Hkv * PRE_SPLITS * 64 * (128 + 2);
+        SP_REQUIRE(Kn > 0 && Kn * rep <= 64 && (row0 || B % Kn == 0), SPACER_EINVAL, "attn_decode_shared: Kn*rep=%d must be <= 64", Kn * rep);
+        SP_REQUIRE(!row0 || (n_prompts > 0 && prompt_of), SPACER_EINVAL, "attn_decode_shared_rows: n_prompts and prompt_of are required");
+        const int np = row0 ? n_prompts : B / Kn;
+        const int nA = np * Hkv * PRE_SPLITS;
+        float* tailp = pre_ws + (long)np * Hkv * PRE_SPLITS * 64 * (128 + 2);
 #define LAUNCH_SPLIT(R)                                                                                                 \
         {                                                                                                               \
             static const int once = hipFuncSetAttribute((const void*)attn_decode_split_kernel<R>,                       \
@@ -1081,9 +1087,9 @@ static int launch_attn_decode(const void* q, const void* prefix_k, const void* p
             (void)once;                                                                                                 \
             hipLaunchKernelGGL((attn_decode_split_kernel<R>), dim3(nA + B * Hkv), dim3(256), 4 * AT_RM_BYTES, s, (const bf16_t*)q, \
                                (const bf16_t*)prefix_k, (const bf16_t*)prefix_v, prefix_len, (const bf16_t*)tail_k,       \
-                               (const bf16_t*)tail_v, tail_len_dev, pre_ws, tailp, nA, Kn, Pmax, Cmax, Hq, Hkv, scale);   \
+                               (const bf16_t*)tail_v, tail_len_dev, pre_ws, tailp, nA, Kn, Pmax, Cmax, Hq, Hkv, scale, row0); \
             hipLaunchKernelGGL((attn_decode_merge_kernel<R>), dim3(B, Hkv), dim3(R * 128), 0, s, (const float*)pre_ws,   \
-                               (const float*)tailp, (bf16_t*)o, Kn, Hq, Hkv);                                           \
+                               (const float*)tailp, (bf16_t*)o, Kn, Hq, Hkv, prompt_of, row0);                          \
         }
         switch (rep) {
             case 1: LAUNCH_SPLIT(1); break; case 2: LAUNCH_SPLIT(2); break; case 3: LAUNCH_SPLIT(3); break; case 4: LAUNCH_SPLIT(4); break;
@@ -1131,3 +1137,16 @@ extern "C" int spacer_attn_decode_shared(const void* q, const void* prefix_k, co
     return launch_attn_decode(q, prefix_k, prefix_v, prefix_len, prompt_of, tail_k, tail_v, tail_len_dev, o, (float*)workspace, Kn,
                               B, Pmax, Cmax, Hq, Hkv, D, scale, stream);
 }
+
+// Per-prompt rollout counts (round 6): prompt p owns the decode rows [row0[p], row0[p + 1]) (row0 int32 [n_prompts + 1], device), at most
+// Kmax of them (Kmax * Hq / Hkv <= 64).  The T-GRPO twin of a sample generates G / 2 rollouts (TR:473): a step's main + twin rollouts decode
+// as 8 x 8 + 8 x 4 = 96 rows instead of 128.  workspace: spacer_attn_decode_workspace_bytes(n_prompts, Hkv).
+extern "C" int spacer_attn_decode_shared_rows(const void* q, const void* prefix_k, const void* prefix_v, const int* prefix_len,
+                                              const int* prompt_of, const int* row0, const void* tail_k, const void* tail_v,
+                                              const int* tail_len_dev, void* o, void* workspace, int B, int n_prompts, int Kmax, int Pmax,
+                                              int Cmax, int Hq, int Hkv, int D, float scale, spacer_stream_t stream) {
+    SP_REQUIRE(workspace != nullptr && row0 != nullptr, SPACER_EINVAL, "attn_decode_shared_rows: workspace and row0 required");
+    return launch_attn_decode(q, prefix_k, prefix_v, prefix_len, prompt_of, tail_k, tail_v, tail_len_dev, o, (float*)workspace, Kmax,
+                              B, Pmax, Cmax, Hq, Hkv, D, scale, stream, row0, n_prompts);
+}
+

@@ -439,6 +439,22 @@ def attn_decode_shared(q, prefix_k, prefix_v, prefix_len, prompt_of, tail_k, tai
     return out
 
 
+def attn_decode_shared_rows(q, prefix_k, prefix_v, prefix_len, prompt_of, row0, tail_k, tail_v, tail_len_dev, Kmax, Hq, Hkv, D, scale, *,
+                            out=None, workspace=None):
+    """attn_decode_shared with per-prompt rollout counts: prompt p owns rows [row0[p], row0[p + 1]) (int32 [n_prompts + 1]), <= Kmax each."""
+    B, nP = q.shape[0], prefix_k.shape[0]
+    assert row0.dtype == torch.int32 and row0.numel() == nP + 1 and prompt_of.numel() == B
+    if out is None:
+        out = torch.empty(B, Hq * D, device=q.device, dtype=BF16)
+    if workspace is None:
+        workspace = torch.empty(_lib.load().spacer_attn_decode_workspace_bytes(nP, Hkv) // 4, device=q.device, dtype=torch.float32)
+    check(_lib.load().spacer_attn_decode_shared_rows(_ptr(q), _ptr(prefix_k), _ptr(prefix_v), _ptr(prefix_len), _ptr(prompt_of), _ptr(row0),
+                                                     _ptr(tail_k), _ptr(tail_v), _ptr(tail_len_dev), _ptr(out), _ptr(workspace), B, nP, Kmax,
+                                                     prefix_k.shape[1], tail_k.shape[1], Hq, Hkv, D, scale, _stream()),
+          "attn_decode_shared_rows")
+    return out
+
+
 # ----------------------------------------------------------------------------------------- element-wise
 def swiglu_fwd(gu, *, out=None):
     rows, two_i = gu.shape

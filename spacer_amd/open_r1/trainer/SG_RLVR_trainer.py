@@ -330,8 +330,9 @@ class SGRLVRTrainer:
             out[:, i] = torch.tensor([float(v) for v in vals], dtype=torch.float32)
         return out
 
-    def _generate(self, prompts: List[PromptInput], n: int, sp: SamplingParams) -> torch.Tensor:
-        """TR:463-481: n sampled completions per prompt, int64 [len(prompts) * n, C].  The rollout-server trainer overrides this."""
+    def _generate(self, prompts: List[PromptInput], n, sp: SamplingParams) -> torch.Tensor:
+        """TR:463-481: n sampled completions per prompt (an int, or one count per prompt: the shuffled twins take G // 2, TR:473),
+        int64 [sum of counts, C].  The rollout-server trainer overrides this."""
         return self.engine.roll.generate(prompts, n, sp, use_graph=self.args.use_decode_graph)
 
     # ------------------------------------------------------------------ the step (TR:384-686)
@@ -376,13 +377,18 @@ class SGRLVRTrainer:
             if prep["sproc"] is not None:
                 twin_at[i] = len(prompts)
                 prompts.append(self._prompt_input(prep["sproc"]))
-        ids = self._generate(prompts, G, sp)
+        # the twins generate G // 2 rollouts each, as the reference (TR:473): 8 x 8 + 8 x 4 = 96 decode rows per 8 samples instead of 128
+        # (a token-step costs 4.87 instead of 5.47 ms; until round 6 every prompt decoded G rows and the twins' surplus was dropped)
+        sg, n_main = self.shuffled_num_generations, len(preps)
+        counts = [G] * n_main + [sg] * (len(prompts) - n_main)
+        ids = self._generate(prompts, counts if len(prompts) > n_main else G, sp)
         host = ids.cpu()       # ONE device-to-host copy for the step, taken when the decode loop has just ended: the reward
         #                        functions read it while the scoring passes run (no sync inside the scoring phase)
         out = []
         for i in range(len(preps)):
             twin = i in twin_at
-            sl = slice(twin_at[i] * G, twin_at[i] * G + self.shuffled_num_generations) if twin else None
+            t0 = n_main * G + (twin_at[i] - n_main) * sg if twin else 0
+            sl = slice(t0, t0 + sg) if twin else None
             out.append(dict(prompt=prompts[i], completion_ids=ids[i * G:(i + 1) * G], completion_host=host[i * G:(i + 1) * G],
                             shuffled_ids=ids[sl] if twin else None, shuffled_host=host[sl] if twin else None))
         return out

@@ -40,9 +40,16 @@ class Qwen2VLGRPOVLLMTrainerModified(SGRLVRTrainer):
         self._note(f"generation on the dedicated rollout rank {topology.server_rank}; --vllm_gpu_memory_utilization accepted and "
                    "ignored (the rollout rank holds one bf16 policy copy + KV caches)")
 
-    def _generate(self, prompts: List[PromptInput], n: int, sp: SamplingParams) -> torch.Tensor:
+    def _generate(self, prompts: List[PromptInput], n, sp: SamplingParams) -> torch.Tensor:
         # weights_version = global_step: pushed once per optimizer step, not per accumulation micro-step (:526, :545)
-        return self.client.generate(prompts, n, sp, weights_version=self.global_step)
+        if isinstance(n, int):
+            return self.client.generate(prompts, n, sp, weights_version=self.global_step)
+        # per-prompt counts (the twins' G // 2): the rollout rank's protocol carries ONE count -- generate max(n) everywhere and keep the
+        # first n[i] rollouts of prompt i
+        top = max(n)
+        ids = self.client.generate(prompts, top, sp, weights_version=self.global_step)
+        keep = torch.cat([torch.arange(i * top, i * top + k) for i, k in enumerate(n)]).to(ids.device)
+        return ids.index_select(0, keep)
 
     def train(self, resume_from_checkpoint: Optional[str] = None):
         try:

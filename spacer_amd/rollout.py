@@ -232,7 +232,10 @@ class RolloutEngine:
                 K.gemm_skinny_packed_acc(h, PW[p + "qkv_w"], st["acc_qkv"], cfg.qkv_dim)
                 K.decode_qkv_finish(st["acc_qkv"], W[p + "qkv_b"], st["cos"], st["sin"], st["q"], st["tk"][i], st["tv"][i],
                                     st["tail_len"], Hq, Hkv, D)
-            if st["shared_prefix"]:      # prompt keys scored once per prompt for its K rollouts
+            if st["shared_prefix"] and st["row0"] is not None:      # ... with per-prompt rollout counts (the T-GRPO twins: G / 2)
+                o = K.attn_decode_shared_rows(st["q"], st["pk"][i], st["pv"][i], st["plen"], st["prompt_of"], st["row0"], st["tk"][i],
+                                              st["tv"][i], st["tail_len"], st["Kn"], Hq, Hkv, D, scale, out=st["o"], workspace=st["attn_ws"])
+            elif st["shared_prefix"]:      # prompt keys scored once per prompt for its K rollouts
                 o = K.attn_decode_shared(st["q"], st["pk"][i], st["pv"][i], st["plen"], st["prompt_of"], st["tk"][i], st["tv"][i],
                                          st["tail_len"], st["Kn"], Hq, Hkv, D, scale, out=st["o"], workspace=st["attn_ws"])
             else:
@@ -260,26 +263,43 @@ class RolloutEngine:
 
     # ------------------------------------------------------------------ public
     @torch.no_grad()
-    def generate(self, prompts: List[PromptInput], num_generations: int, sp: SamplingParams, *, use_graph: bool = True,
+    def generate(self, prompts: List[PromptInput], num_generations, sp: SamplingParams, *, use_graph: bool = True,
                  stats: Optional[dict] = None, on_decode_start=None, _eos_at: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Returns completion ids int64 [len(prompts) * num_generations, C] (EOS kept, pad_token_id after it),
-        rows ordered prompt-major like HF's num_return_sequences expansion.  ``on_decode_start()`` is called once, right after
+        """Returns completion ids int64 [sum of generations, C] (EOS kept, pad_token_id after it), rows ordered prompt-major like HF's
+        num_return_sequences expansion.  ``num_generations``: one int for every prompt, or (round 6) one count PER PROMPT -- the T-GRPO
+        twin of a sample needs only G // 2 rollouts (TR:473 ``num_return_sequences = self.shuffled_num_generations``), and a decode
+        token-step costs 3.99 / 4.87 / 5.47 ms at 64 / 96 / 128 rows (scripts/probes/decode_rows_time.py): a step's main + twin
+        rollouts decode as 8 x 8 + 8 x 4 = 96 rows instead of 128.  Prompt p then owns the rows [row0[p], row0[p + 1]) of the batch
+        (``spacer_attn_decode_shared_rows``: the shared-prefix decode attention with per-prompt column counts; a first version ran
+        non-uniform counts as virtual prompts of gcd(counts) rollouts with repeated KV slots -- twice the prompt-key workgroups for the
+        main prompts, 5.43 instead of 4.9 ms per token-step).  ``on_decode_start()`` is called once, right after
         the decode step has been captured (graph capture synchronises the device, so work meant to run BESIDE the decode loop on
         another stream must be enqueued after it): the hook for prompt-only work of the step that can overlap the HBM-bound loop."""
         cfg = self.cfg
-        nP, Kn, C = len(prompts), num_generations, sp.max_new_tokens
-        B = nP * Kn
+        C = sp.max_new_tokens
+        counts = [int(num_generations)] * len(prompts) if isinstance(num_generations, int) else [int(k) for k in num_generations]
+        assert len(counts) == len(prompts) and all(k >= 1 for k in counts)
+        uniform = len(set(counts)) == 1
+        Kn = max(counts)                                  # rows per prompt (uniform) / the most rows any prompt owns
+        nP = len(prompts)
+        B = sum(counts)
         if sp.synthetic_lengths is not None and _eos_at is None:
             lo, hi = sp.synthetic_lengths
             gen = torch.Generator().manual_seed(1_000_003 * sp.seed + 17)
             _eos_at = (torch.randint(max(1, lo), hi + 1, (B,), generator=gen) - 1).int()      # token index of EOS (length - 1), host
         if B > self.MAX_ROWS:
-            outs = []
-            per = max(1, self.MAX_ROWS // Kn)
-            for a in range(0, nP, per):
-                outs.append(self.generate(prompts[a:a + per], Kn, sp, use_graph=use_graph, stats=stats,
+            if nP == 1:
+                raise ValueError(f"generate: {B} rollouts of one prompt exceed the decode batch of {self.MAX_ROWS} rows")
+            outs, a, r0 = [], 0, 0
+            while a < nP:                                  # consecutive prompts, at most MAX_ROWS rows per decode batch
+                b, rows = a, 0
+                while b < nP and (b == a or rows + counts[b] <= self.MAX_ROWS):
+                    rows += counts[b]
+                    b += 1
+                outs.append(self.generate(prompts[a:b], counts[a:b], sp, use_graph=use_graph, stats=stats,
                                           on_decode_start=on_decode_start if a == 0 else None,
-                                          _eos_at=None if _eos_at is None else _eos_at[a * Kn:(a + per) * Kn]))
+                                          _eos_at=None if _eos_at is None else _eos_at[r0:r0 + rows]))
+                a, r0 = b, r0 + rows
             return torch.cat(outs, 0)
         dev = self.dev
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if stats is not None else None
@@ -301,10 +321,11 @@ class RolloutEngine:
         L, Hkv, D, H = cfg.layers, cfg.kv_heads, cfg.head_dim, cfg.hidden
         st = dict(
             B=B, pk=pk, pv=pv, packed=self._pack(B), Kn=Kn, shared_prefix=Kn * (cfg.heads // cfg.kv_heads) <= 64 and Kn > 1 and not (DECODE_SMALL_ATTN1 and B <= 16),
+            row0=None if uniform else torch.tensor([sum(counts[:i]) for i in range(nP + 1)], dtype=torch.int32, device=dev),
             attn_ws=torch.empty(K.attn_decode_workspace_bytes(nP, cfg.kv_heads) // 4, device=dev, dtype=F32),
             plen=torch.tensor(plen, dtype=torch.int32, device=dev),
-            prompt_of=torch.arange(B, dtype=torch.int32, device=dev) // Kn,
-            pos_base=torch.tensor(pos_base, dtype=torch.int32, device=dev).repeat_interleave(Kn).contiguous(),
+            prompt_of=torch.repeat_interleave(torch.arange(nP, dtype=torch.int32), torch.tensor(counts)).to(dev),
+            pos_base=torch.repeat_interleave(torch.tensor(pos_base, dtype=torch.int32), torch.tensor(counts)).to(dev).contiguous(),
             tk=K.zeros(L, B, C, Hkv, D, device=dev, dtype=BF16), tv=K.zeros(L, B, C, Hkv, D, device=dev, dtype=BF16),
             tail_len=torch.full((1,), -1, dtype=torch.int32, device=dev), step=torch.full((1,), -1, dtype=torch.int32, device=dev),
             finished=torch.zeros(B, dtype=torch.int32, device=dev), cur_tok=torch.empty(B, dtype=torch.int64, device=dev),
@@ -321,7 +342,7 @@ class RolloutEngine:
         if st["eos_at"] is not None and sp.suppress_eos:
             raise ValueError("SamplingParams: synthetic_lengths schedules EOS itself; suppress_eos must be False")
         # token 0 of every rollout comes from the prompt's last-position logits (K independent draws per prompt)
-        st["logits"].copy_(first_logits.repeat_interleave(Kn, 0))
+        st["logits"].copy_(first_logits.index_select(0, st["prompt_of"].long()))
         if st["eos_at"] is not None:
             K.eos_schedule_(st["logits"], st["step"], 1, st["eos_at"], cfg.eos_token_id)
         K.sample_top_p_step(st["logits"], st["step"], 1, out, top_k=sp.top_k, top_p=sp.top_p, temperature=sp.temperature, seed=sp.seed,

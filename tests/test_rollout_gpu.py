@@ -140,3 +140,31 @@ def test_more_than_64_rows_decode_as_one_batch(tiny, dev):
     small = roll.generate(prompts, 24, sp, use_graph=False)
     assert torch.equal(big, small)
     assert torch.equal(big[:24], big[48:])                                      # same prompt, greedy -> same rollouts
+
+
+def test_per_prompt_generation_counts_share_the_prefill(tiny, dev):
+    """Round 6: ``generate(prompts, [k_0, k_1, ...])`` -- the T-GRPO twins take G // 2 rollouts (TR:473), so a step's main + twin rollouts
+    decode as fewer rows: prompt p owns the rows [row0[p], row0[p + 1]) of the batch (``spacer_attn_decode_shared_rows``).  Greedy
+    decoding makes every rollout of a prompt THE arg-max continuation, which must not depend on how many siblings it has or on where its
+    rows sit: rows of a [4, 2] / [3, 6] batch == the rows of uniform batches of the same prompts; eager == graph; the prefill runs once
+    per prompt (its kept tape has one slice per prompt)."""
+    eng = Qwen2VLEngine(TINY, tiny["params"])
+    roll = RolloutEngine(eng)
+    sp = SamplingParams(max_new_tokens=9, top_k=1, top_p=1.0, suppress_eos=True)
+    with K.plan(skinny_blocks=1):
+        ref = roll.generate(tiny["prompts"], 2, sp, use_graph=False)                    # [2 prompts x 2, 9]
+        outs = [roll.generate(tiny["prompts"], [4, 2], sp, use_graph=g) for g in (False, True)]
+        mixed3 = roll.generate(tiny["prompts"], [3, 6], sp, use_graph=False)            # 3 x 2 = 6 and 6 x 2 = 12 attention columns
+    assert outs[0].shape == (6, 9) and torch.equal(outs[0], outs[1])
+    for r in range(4):
+        assert torch.equal(outs[0][r], ref[0])                                         # prompt 0: four copies of its greedy continuation
+    for r in (4, 5):
+        assert torch.equal(outs[0][r], ref[2])                                         # prompt 1 (text-only): two copies
+    assert mixed3.shape == (9, 9) and all(torch.equal(mixed3[r], ref[0]) for r in range(3)) and all(torch.equal(mixed3[r], ref[2]) for r in range(3, 9))
+    # sampled rollouts: shapes, pads behind EOS, and the prefill tape kept per real prompt
+    roll.keep_prefill_tape = True
+    vid = [tiny["prompts"][0], PromptInput(tiny["prompts"][0].ids, tiny["prompts"][0].pix, tiny["prompts"][0].grids)]
+    out = roll.generate(vid, [4, 2], SamplingParams(max_new_tokens=12, seed=5))
+    assert out.shape == (6, 12) and vid[0].prefill is not None and vid[1].prefill.index == 1 and vid[0].prefill.shared is vid[1].prefill.shared
+    with pytest.raises(ValueError):
+        roll.generate(tiny["prompts"][:1], 200, sp)
