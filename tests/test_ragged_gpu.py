@@ -215,7 +215,7 @@ def test_synthetic_lengths_rollout(dev):
         for b, n in enumerate(want.tolist()):
             assert int(out[b, n - 1]) == TINY.eos_token_id and bool((out[b, :n - 1] != TINY.eos_token_id).all())
             assert bool((out[b, n:] == TINY.pad_token_id).all())
-        assert st["decode_steps"] < C - 1                       # the loop left once all rows had finished (checked every 32 steps)
+        assert st["decode_steps"] <= 40 + 8 < C - 1                     # the loop left once all rows had finished (checked every 8 steps)
         outs.append(out)
     assert torch.equal(outs[0], outs[1])
     with pytest.raises(ValueError):
