@@ -384,6 +384,15 @@ int spacer_sample_top_p_step(const float* logits, long ld, int B, int vocab, int
                              int64_t* out_ids, int64_t* out_matrix, long out_ld, spacer_stream_t stream);
 int spacer_decode_embed(const int64_t* ids, const void* table, float* out, int B, int H, int* counter0, int* counter1,
                         spacer_stream_t stream);
+/* Round 6: spacer_sample_top_p / spacer_sample_top_p_step_ws with a workspace of spacer_sample_workspace_bytes(B, vocab) bytes (16-byte
+ * aligned, scratch, no initialisation) run the two passes over a row's logits with several workgroups per row when the batch alone cannot
+ * fill the chip (B < 256 rows of >= 64 K logits): 32.6 / 39.4 / 46.9 / 58.3 -> 30.4 / 30.7 / 34.3 / 47.2 us per call at 8 / 12 / 64 / 128 rows
+ * (scripts/probes/sampler_time.py; what remains is the select / sort / draw chain of three dependent launches, not the passes).  Same token for the same logits and counter as the
+ * one-workgroup-per-row form (the candidate list is sorted by (value, index) before the exact top-k trim); workspace NULL = that form. */
+int spacer_sample_top_p_step_ws(const float* logits, long ld, int B, int vocab, int top_k, float top_p, float temperature, uint64_t seed,
+                                const int* step_dev, int step_bias, int eos_id, int pad_id, int suppress_eos, int* finished,
+                                int64_t* out_ids, int64_t* out_matrix, long out_ld, void* workspace, long workspace_bytes,
+                                spacer_stream_t stream);
 /* Synthetic completion lengths (the seeded variable-length mode of the benchmark / tests; SURVEY 8(d) "free-running mode"): on the
  * step's logits, right before spacer_sample_top_p_step with suppress_eos = 0 -- row b's EOS logit becomes -inf, except at token index
  * *step_dev + step_bias == eos_at[b] where it dominates the row, so rollout b ends with EOS as its eos_at[b]-th token (length

@@ -93,6 +93,7 @@ SIGNATURES = {
     "spacer_scatter_f32": [_p, _p, _p, _l, _p],
     "spacer_sample_top_p": [_p, _l, _i, _i, _i, _f, _f, _u64, _p, _i, _i, _i, _p, _p, _p, _p, _l, _p],
     "spacer_sample_top_p_step": [_p, _l, _i, _i, _i, _f, _f, _u64, _p, _i, _i, _i, _i, _p, _p, _p, _l, _p],
+    "spacer_sample_top_p_step_ws": [_p, _l, _i, _i, _i, _f, _f, _u64, _p, _i, _i, _i, _i, _p, _p, _p, _l, _p, _l, _p],
     "spacer_decode_embed": [_p, _p, _p, _i, _i, _p, _p, _p],
     "spacer_eos_schedule": [_p, _l, _i, _i, _p, _i, _p, _i, _p],
     "spacer_decode_rope_table": [_p, _p, _f, _p, _p, _i, _i, _p],

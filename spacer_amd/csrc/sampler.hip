@@ -46,12 +46,69 @@ __device__ __forceinline__ float block_excl_scan(float v, float* wsum, float& to
     return base + inc - v;
 }
 
+// exact k-th largest key of `count` values produced by load(i): 4-pass radix select, wave-aggregated LDS atomics (hist: 256 ints of LDS)
+template <class Load>
+__device__ __forceinline__ uint32_t kth_key_fn(Load&& load, int count, int k, int* hist, int& sel_bin, int& sel_k) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    uint32_t prefix = 0;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        for (int i = tid; i < 256; i += SNT) hist[i] = 0;
+        __syncthreads();
+        for (int i0 = 0; i0 < count; i0 += SNT) {
+            const int i = i0 + tid;
+            bool live = i < count;
+            const uint32_t key = live ? okey(load(i)) : 0u;
+            if (pass > 0) live = live && ((key >> (shift + 8)) == prefix);
+            const int bin = (key >> shift) & 255;
+            unsigned long long act = __ballot(live);
+            while (act) {
+                const int leader = __ffsll((long long)act) - 1;
+                const int lb = __shfl(bin, leader, 64);
+                const unsigned long long same = __ballot(live && bin == lb);
+                if (lane == leader) atomicAdd(&hist[lb], __popcll(same));
+                act &= ~same;
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            // first bin, walking down from 255, where the running count reaches k -- by one wave (4 bins per lane, shuffle
+            // prefix) instead of one thread walking 256 dependent LDS reads per pass (that walk was half of the kernel's time)
+            int hb[4], own = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { hb[q] = hist[255 - (lane * 4 + q)]; own += hb[q]; }
+            int incl = own;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+            int cum = incl - own, pos = 256, cum_at = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (pos == 256 && cum + hb[q] >= k) { pos = lane * 4 + q; cum_at = cum; }
+                cum += hb[q];
+            }
+            int first = pos;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o, 64));
+            if (first == 256) { if (lane == 63) { sel_bin = 0; sel_k = k - incl; } }  // k exceeds the population (cannot happen for count >= k): what the serial walk left
+            else if (pos == first) { sel_bin = 255 - pos; sel_k = k - cum_at; }
+        }
+        __syncthreads();
+        prefix = (prefix << 8) | (uint32_t)sel_bin;
+        k = sel_k;
+        __syncthreads();
+    }
+    return prefix;
+}
+
 __global__ __launch_bounds__(SNT) void sample_kernel(const float* __restrict__ logits, long ld, int vocab, int top_k,
                                                      float top_p, float inv_temp, uint64_t seed,
                                                      const int* __restrict__ step_dev, int eos, int pad, int suppress_eos,
                                                      int* __restrict__ finished, int64_t* __restrict__ out_ids,
                                                      float* __restrict__ out_logp, int step_bias, int64_t* __restrict__ out_mat,
-                                                     long out_ld) {
+                                                     long out_ld, const float* __restrict__ pre_val, const int* __restrict__ pre_idx,
+                                                     const int* __restrict__ pre_n) {
+    // pre_n != nullptr (wide form): the candidates of row b were gathered by sample_gather_kernel into pre_val / pre_idx [b][CAP]; a row whose
+    // candidates overflowed CAP falls back to this kernel's own two-pass / radix-select path
     __shared__ int hist[256];
     __shared__ int sel_bin, sel_k, ncand;
     __shared__ float cval[CAP];
@@ -72,57 +129,7 @@ __global__ __launch_bounds__(SNT) void sample_kernel(const float* __restrict__ l
     auto val = [&](int i) -> float { return fix(row[i], i); };
     const bool vec_ok = (ld % 4 == 0) && (((uintptr_t)logits & 15) == 0);
 
-    // exact k-th largest key of `count` values produced by load(i): 4-pass radix select, wave-aggregated LDS atomics
-    auto kth_key = [&](auto&& load, int count, int k) -> uint32_t {
-        uint32_t prefix = 0;
-        for (int pass = 0; pass < 4; ++pass) {
-            const int shift = 24 - 8 * pass;
-            for (int i = tid; i < 256; i += SNT) hist[i] = 0;
-            __syncthreads();
-            for (int i0 = 0; i0 < count; i0 += SNT) {
-                const int i = i0 + tid;
-                bool live = i < count;
-                const uint32_t key = live ? okey(load(i)) : 0u;
-                if (pass > 0) live = live && ((key >> (shift + 8)) == prefix);
-                const int bin = (key >> shift) & 255;
-                unsigned long long act = __ballot(live);
-                while (act) {
-                    const int leader = __ffsll((long long)act) - 1;
-                    const int lb = __shfl(bin, leader, 64);
-                    const unsigned long long same = __ballot(live && bin == lb);
-                    if (lane == leader) atomicAdd(&hist[lb], __popcll(same));
-                    act &= ~same;
-                }
-            }
-            __syncthreads();
-            if (tid < 64) {
-                // first bin, walking down from 255, where the running count reaches k -- by one wave (4 bins per lane, shuffle
-                // prefix) instead of one thread walking 256 dependent LDS reads per pass (that walk was half of the kernel's time)
-                int hb[4], own = 0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { hb[q] = hist[255 - (lane * 4 + q)]; own += hb[q]; }
-                int incl = own;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-                int cum = incl - own, pos = 256, cum_at = 0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (pos == 256 && cum + hb[q] >= k) { pos = lane * 4 + q; cum_at = cum; }
-                    cum += hb[q];
-                }
-                int first = pos;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o, 64));
-                if (first == 256) { if (lane == 63) { sel_bin = 0; sel_k = k - incl; } }  // k exceeds the population (cannot happen for count >= k): what the serial walk left
-                else if (pos == first) { sel_bin = 255 - pos; sel_k = k - cum_at; }
-            }
-            __syncthreads();
-            prefix = (prefix << 8) | (uint32_t)sel_bin;
-            k = sel_k;
-            __syncthreads();
-        }
-        return prefix;
-    };
+    auto kth_key = [&](auto&& load, int count, int k) -> uint32_t { return kth_key_fn(load, count, k, hist, sel_bin, sel_k); };
     auto gather = [&](uint32_t thr) {
         if (tid == 0) ncand = 0;
         __syncthreads();
@@ -149,6 +156,13 @@ __global__ __launch_bounds__(SNT) void sample_kernel(const float* __restrict__ l
     // lower bound of the top_k-th largest logit, so "logit >= bound" keeps a superset of the top-k (typically ~2k
     // values) that is then trimmed exactly after the sort.  Pathological rows (mass ties) overflow CAP and take the
     // exact 4-pass radix select over the whole row.
+    bool trimmed_exactly = false;
+    const bool pre = pre_n && pre_n[b] <= CAP;
+    if (pre) {
+        if (tid == 0) ncand = pre_n[b];
+        if (tid < pre_n[b]) { cval[tid] = pre_val[(long)b * CAP + tid]; cidx[tid] = pre_idx[(long)b * CAP + tid]; }
+        __syncthreads();
+    } else {
     float lmax = -INFINITY;
     if (vec_ok) {
         for (int i4 = tid; i4 < (vocab >> 2); i4 += SNT) {
@@ -164,11 +178,11 @@ __global__ __launch_bounds__(SNT) void sample_kernel(const float* __restrict__ l
     const uint32_t bound = kth_key([&](int i) { return cval[i]; }, SNT, top_k);
     __syncthreads();
     gather(bound);
-    bool trimmed_exactly = false;
     if (ncand > CAP) {
         const uint32_t kth = kth_key(val, vocab, top_k);
         gather(kth);
         trimmed_exactly = true;
+    }
     }
     const int n = min(ncand, CAP);   // (ties beyond CAP are dropped)
     int np2 = 1;
@@ -245,6 +259,76 @@ __global__ __launch_bounds__(SNT) void sample_kernel(const float* __restrict__ l
     }
 }
 
+// ---- wide form (round 6): the two passes over a row's logits by S workgroups per row instead of one.  At decode batch sizes (8 ... 128 rows of
+// 152 064 logits) one workgroup per row leaves most CUs idle and each reads 1.2 MB alone.  Measured (scripts/probes/sampler_time.py):
+// 32.6 / 39.4 / 46.9 / 58.3 us per call at 8 / 12 / 64 / 128 rows in that form, 30.4 / 30.7 / 34.3 / 47.2 us in this one -- the passes shrink, the
+// select / sort / draw chain (now three dependent launches) stays.  Here
+//   sample_partmax_kernel   (B x S workgroups)  per-thread maxima of a slice of the row -> pmax[b][S x 1024]
+//   sample_gather_kernel    (B x S workgroups)  bound = top_k-th largest of the row's S x 1024 maxima (each is a logit of the row, so
+//                                               the bound is <= the top_k-th largest logit: the candidates are a superset of the top-k,
+//                                               as in the single-workgroup form, with a tighter bound); slice candidates >= bound are
+//                                               collected in LDS and appended to the row's list with ONE global atomic per workgroup
+//   sample_kernel (pre_*)   (B workgroups)      sort / exact top-k trim / nucleus / draw on the gathered list -- the same code, hence the
+//                                               same token for the same logits and counter (the sort orders by (value, index))
+__global__ __launch_bounds__(SNT) void sample_partmax_kernel(const float* __restrict__ logits, long ld, int vocab, int S, float inv_temp,
+                                                             int eos, int suppress_eos, const int* __restrict__ finished,
+                                                             float* __restrict__ pmax, int* __restrict__ pre_n) {
+    const int b = blockIdx.x / S, sl = blockIdx.x % S, tid = threadIdx.x;
+    if (sl == 0 && tid == 0) pre_n[b] = 0;
+    if (finished && finished[b]) return;
+    const float* row = logits + (long)b * ld;
+    auto fix = [&](float raw, int i) -> float { return (suppress_eos && i == eos) ? -INFINITY : raw * inv_temp; };
+    const int n4 = vocab >> 2, per = (n4 + S - 1) / S, q0 = sl * per, q1 = min(n4, q0 + per);
+    float lmax = -INFINITY;
+    for (int i4 = q0 + tid; i4 < q1; i4 += SNT) {
+        const float4 v = *(const float4*)(row + i4 * 4);
+        lmax = fmaxf(fmaxf(lmax, fmaxf(fix(v.x, i4 * 4), fix(v.y, i4 * 4 + 1))), fmaxf(fix(v.z, i4 * 4 + 2), fix(v.w, i4 * 4 + 3)));
+    }
+    if (sl == S - 1)
+        for (int i = (vocab & ~3) + tid; i < vocab; i += SNT) lmax = fmaxf(lmax, fix(row[i], i));
+    pmax[((long)b * S + sl) * SNT + tid] = lmax;
+}
+
+constexpr int WIDE_MAX_S = 8;
+__global__ __launch_bounds__(SNT) void sample_gather_kernel(const float* __restrict__ logits, long ld, int vocab, int S, int top_k, float inv_temp,
+                                                            int eos, int suppress_eos, const int* __restrict__ finished,
+                                                            const float* __restrict__ pmax, float* __restrict__ pre_val,
+                                                            int* __restrict__ pre_idx, int* __restrict__ pre_n) {
+    __shared__ float mx[WIDE_MAX_S * SNT];
+    __shared__ int hist[256];
+    __shared__ int sel_bin, sel_k, nloc, base;
+    __shared__ float lval[CAP];
+    __shared__ int lidx[CAP];
+    const int b = blockIdx.x / S, sl = blockIdx.x % S, tid = threadIdx.x;
+    if (finished && finished[b]) return;
+    for (int i = tid; i < S * SNT; i += SNT) mx[i] = pmax[(long)b * S * SNT + i];
+    if (tid == 0) nloc = 0;
+    __syncthreads();
+    const uint32_t thr = kth_key_fn([&](int i) { return mx[i]; }, S * SNT, top_k, hist, sel_bin, sel_k);
+    const float* row = logits + (long)b * ld;
+    auto fix = [&](float raw, int i) -> float { return (suppress_eos && i == eos) ? -INFINITY : raw * inv_temp; };
+    auto consider = [&](float x, int i) {
+        if (okey(x) >= thr) {
+            const int slot = atomicAdd(&nloc, 1);
+            if (slot < CAP) { lval[slot] = x; lidx[slot] = i; }
+        }
+    };
+    const int n4 = vocab >> 2, per = (n4 + S - 1) / S, q0 = sl * per, q1 = min(n4, q0 + per);
+    for (int i4 = q0 + tid; i4 < q1; i4 += SNT) {
+        const float4 v = *(const float4*)(row + i4 * 4);
+        consider(fix(v.x, i4 * 4), i4 * 4); consider(fix(v.y, i4 * 4 + 1), i4 * 4 + 1);
+        consider(fix(v.z, i4 * 4 + 2), i4 * 4 + 2); consider(fix(v.w, i4 * 4 + 3), i4 * 4 + 3);
+    }
+    if (sl == S - 1)
+        for (int i = (vocab & ~3) + tid; i < vocab; i += SNT) consider(fix(row[i], i), i);
+    __syncthreads();
+    if (tid == 0) base = atomicAdd(&pre_n[b], nloc);          // (a slice that overflowed CAP pushes the row's count past CAP: fallback)
+    __syncthreads();
+    const int n = min(nloc, CAP);
+    for (int i = tid; i < n; i += SNT)
+        if (base + i < CAP) { pre_val[(long)b * CAP + base + i] = lval[i]; pre_idx[(long)b * CAP + base + i] = lidx[i]; }
+}
+
 // Synthetic completion lengths (bench / tests): row b may emit EOS at token index eos_at[b] and nowhere else.  Runs on the step's
 // logits right before the sampler: the EOS logit becomes -inf (never drawn) or, at the scheduled index, so large that every other
 // candidate's probability underflows to 0 (the nucleus keeps the top candidate unconditionally).
@@ -257,19 +341,44 @@ __global__ void eos_schedule_kernel(float* __restrict__ logits, long ld, int B, 
 
 }  // namespace
 
-extern "C" long spacer_sample_workspace_bytes(int B, int vocab) { (void)B; (void)vocab; return 0; }
+// workspace of the wide form: per row WIDE_MAX_S x 1024 partial maxima + CAP candidate (value, index) pairs + a counter
+extern "C" long spacer_sample_workspace_bytes(int B, int vocab) {
+    (void)vocab;
+    return (long)B * ((long)WIDE_MAX_S * SNT * 4 + (long)CAP * 8 + 4);
+}
 
 static int sample_launch(const float* logits, long ld, int B, int vocab, int top_k, float top_p, float temperature, uint64_t seed,
                          const int* step_dev, int step_bias, int eos_id, int pad_id, int suppress_eos, int* finished, int64_t* out_ids,
-                         float* out_logp, int64_t* out_mat, long out_ld, spacer_stream_t stream) {
+                         float* out_logp, int64_t* out_mat, long out_ld, spacer_stream_t stream, void* ws = nullptr, long ws_bytes = 0) {
     SP_REQUIRE(top_k >= 1 && top_k <= CAP, SPACER_EINVAL,
                "sample_top_p: top_k=%d must be in 1..%d (full-vocabulary nucleus, top_k=0, is not implemented yet)", top_k, CAP);
     SP_REQUIRE(top_p > 0.f && top_p <= 1.f && temperature > 0.f, SPACER_EINVAL, "sample_top_p: bad top_p/temperature");
     SP_REQUIRE(vocab >= top_k, SPACER_EINVAL, "sample_top_p: vocab < top_k");
     if (B <= 0) return SPACER_OK;
+    // wide form: S workgroups per row for the two passes over the logits when the batch alone cannot fill the chip (a caller's
+    // workspace selects it; rows of >= 64 K logits, 16-byte aligned)
+    int S = B >= 256 ? 1 : (256 + B - 1) / B;
+    S = S > WIDE_MAX_S ? WIDE_MAX_S : S;
+    const bool wide = ws && ws_bytes >= spacer_sample_workspace_bytes(B, vocab) && S > 1 && vocab >= 65536 && ld % 4 == 0 &&
+                      ((uintptr_t)logits & 15) == 0 && ((uintptr_t)ws & 15) == 0 && top_k <= WIDE_MAX_S * SNT;
+    if (wide) {
+        float* pmax = (float*)ws;
+        float* pre_val = pmax + (long)B * WIDE_MAX_S * SNT;
+        int* pre_idx = (int*)(pre_val + (long)B * CAP);
+        int* pre_n = pre_idx + (long)B * CAP;
+        hipLaunchKernelGGL(sample_partmax_kernel, dim3(B * S), dim3(SNT), 0, (hipStream_t)stream, logits, ld, vocab, S, 1.f / temperature,
+                           eos_id, suppress_eos, (const int*)finished, pmax, pre_n);
+        hipLaunchKernelGGL(sample_gather_kernel, dim3(B * S), dim3(SNT), 0, (hipStream_t)stream, logits, ld, vocab, S, top_k,
+                           1.f / temperature, eos_id, suppress_eos, (const int*)finished, (const float*)pmax, pre_val, pre_idx, pre_n);
+        hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(SNT), 0, (hipStream_t)stream, logits, ld, vocab, top_k, top_p,
+                           1.f / temperature, seed, step_dev, eos_id, pad_id, suppress_eos, finished, out_ids, out_logp, step_bias, out_mat,
+                           out_ld, (const float*)pre_val, (const int*)pre_idx, (const int*)pre_n);
+        SP_CHECK_LAUNCH();
+        return SPACER_OK;
+    }
     hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(SNT), 0, (hipStream_t)stream, logits, ld, vocab, top_k, top_p,
                        1.f / temperature, seed, step_dev, eos_id, pad_id, suppress_eos, finished, out_ids, out_logp, step_bias, out_mat,
-                       out_ld);
+                       out_ld, (const float*)nullptr, (const int*)nullptr, (const int*)nullptr);
     SP_CHECK_LAUNCH();
     return SPACER_OK;
 }
@@ -278,9 +387,8 @@ extern "C" int spacer_sample_top_p(const float* logits, long ld, int B, int voca
                                    float temperature, uint64_t seed, const int* step_dev, int eos_id, int pad_id,
                                    int suppress_eos, int* finished, int64_t* out_ids, float* out_logp, void* workspace,
                                    long workspace_bytes, spacer_stream_t stream) {
-    (void)workspace; (void)workspace_bytes;
     return sample_launch(logits, ld, B, vocab, top_k, top_p, temperature, seed, step_dev, 0, eos_id, pad_id, suppress_eos, finished,
-                         out_ids, out_logp, nullptr, 0, stream);
+                         out_ids, out_logp, nullptr, 0, stream, workspace, workspace_bytes);
 }
 
 extern "C" int spacer_sample_top_p_step(const float* logits, long ld, int B, int vocab, int top_k, float top_p, float temperature,
@@ -288,6 +396,14 @@ extern "C" int spacer_sample_top_p_step(const float* logits, long ld, int B, int
                                         int* finished, int64_t* out_ids, int64_t* out_matrix, long out_ld, spacer_stream_t stream) {
     return sample_launch(logits, ld, B, vocab, top_k, top_p, temperature, seed, step_dev, step_bias, eos_id, pad_id, suppress_eos,
                          finished, out_ids, nullptr, out_matrix, out_ld, stream);
+}
+
+extern "C" int spacer_sample_top_p_step_ws(const float* logits, long ld, int B, int vocab, int top_k, float top_p, float temperature,
+                                           uint64_t seed, const int* step_dev, int step_bias, int eos_id, int pad_id, int suppress_eos,
+                                           int* finished, int64_t* out_ids, int64_t* out_matrix, long out_ld, void* workspace,
+                                           long workspace_bytes, spacer_stream_t stream) {
+    return sample_launch(logits, ld, B, vocab, top_k, top_p, temperature, seed, step_dev, step_bias, eos_id, pad_id, suppress_eos,
+                         finished, out_ids, nullptr, out_matrix, out_ld, stream, workspace, workspace_bytes);
 }
 
 extern "C" int spacer_eos_schedule(float* logits, long ld, int B, int vocab, const int* step_dev, int step_bias, const int* eos_at,

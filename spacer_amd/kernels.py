@@ -868,22 +868,35 @@ def eos_schedule_(logits32, step_dev, step_bias, eos_at, eos_id):
     return logits32
 
 
+def sample_workspace(B, vocab, device) -> torch.Tensor:
+    """Scratch of the sampler's wide form (several workgroups per row for the two passes over the logits)."""
+    return torch.empty(_lib.load().spacer_sample_workspace_bytes(B, vocab) // 4, device=device, dtype=torch.float32)
+
+
 def sample_top_p(logits32, step_dev, *, top_k=50, top_p=0.95, temperature=1.0, seed=0, eos_id=-1, pad_id=0,
-                 suppress_eos=False, finished=None, out_ids=None, out_logp=None):
+                 suppress_eos=False, finished=None, out_ids=None, out_logp=None, workspace=None):
     B, vocab = logits32.shape
     if out_ids is None:
         out_ids = torch.empty(B, device=logits32.device, dtype=torch.int64)
     check(_lib.load().spacer_sample_top_p(_ptr(logits32), _rowmajor(logits32), B, vocab, top_k, top_p, temperature, seed,
                                           _ptr(step_dev), eos_id, pad_id, int(suppress_eos), _ptr(finished), _ptr(out_ids),
-                                          _ptr(out_logp), None, 0, _stream()), "sample_top_p")
+                                          _ptr(out_logp), _ptr(workspace), 0 if workspace is None else workspace.numel() * 4, _stream()),
+          "sample_top_p")
     return out_ids
 
 
 def sample_top_p_step(logits32, step_dev, step_bias, out_matrix, *, top_k=50, top_p=0.95, temperature=1.0, seed=0, eos_id=-1, pad_id=0,
-                      suppress_eos=False, finished=None, out_ids=None):
-    """sample_top_p for the decode loop: Philox step = *step_dev + step_bias; the token also lands in out_matrix[:, step]."""
+                      suppress_eos=False, finished=None, out_ids=None, workspace=None):
+    """sample_top_p for the decode loop: Philox step = *step_dev + step_bias; the token also lands in out_matrix[:, step].  ``workspace``
+    (sample_workspace): the wide form."""
     B, vocab = logits32.shape
     assert out_matrix.dtype == torch.int64 and out_matrix.stride(1) == 1
+    if workspace is not None:
+        check(_lib.load().spacer_sample_top_p_step_ws(_ptr(logits32), _rowmajor(logits32), B, vocab, top_k, top_p, temperature, seed,
+                                                      _ptr(step_dev), step_bias, eos_id, pad_id, int(suppress_eos), _ptr(finished),
+                                                      _ptr(out_ids), _ptr(out_matrix), out_matrix.stride(0), _ptr(workspace),
+                                                      workspace.numel() * 4, _stream()), "sample_top_p_step_ws")
+        return out_ids
     check(_lib.load().spacer_sample_top_p_step(_ptr(logits32), _rowmajor(logits32), B, vocab, top_k, top_p, temperature, seed,
                                                _ptr(step_dev), step_bias, eos_id, pad_id, int(suppress_eos), _ptr(finished),
                                                _ptr(out_ids), _ptr(out_matrix), out_matrix.stride(0), _stream()), "sample_top_p_step")

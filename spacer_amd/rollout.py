@@ -32,6 +32,9 @@ DECODE_NORM_FOLD = os.environ.get("SPACER_DECODE_NORM", "fold") != "separate"   
 # (measured slower at 8 rows: 3.69 vs 3.28 ms per token-step -- each rollout's workgroup re-reads the prompt's keys).
 _SMALL = set(filter(None, os.environ.get("SPACER_DECODE_SMALL", "fold").split(",")))
 DECODE_SMALL_FOLD, DECODE_SMALL_ATTN1 = "fold" in _SMALL, "attn1" in _SMALL
+# the sampler's wide form (several workgroups per row for the two passes over the logits; same tokens): SPACER_SAMPLER=narrow keeps one
+# workgroup per row (A/B)
+SAMPLER_WIDE = os.environ.get("SPACER_SAMPLER", "wide") != "narrow"
 
 @dataclass
 class PromptInput:
@@ -259,7 +262,7 @@ class RolloutEngine:
         # Philox step / output column = counter + 1 = index of the token being drawn
         K.sample_top_p_step(st["logits"], st["step"], 1, st["out"], top_k=sp.top_k, top_p=sp.top_p, temperature=sp.temperature, seed=sp.seed,
                             eos_id=cfg.eos_token_id, pad_id=cfg.pad_token_id, suppress_eos=sp.suppress_eos,
-                            finished=st["finished"], out_ids=st["cur_tok"])
+                            finished=st["finished"], out_ids=st["cur_tok"], workspace=st["sample_ws"])
 
     # ------------------------------------------------------------------ public
     @torch.no_grad()
@@ -336,6 +339,7 @@ class RolloutEngine:
             rowss=torch.zeros(cfg.layers, max(B, 1), device=dev, dtype=F32),     # per layer: sum of x^2 per row (norm-folded q|k|v)
             cos=torch.empty(B, D, device=dev, dtype=F32), sin=torch.empty(B, D, device=dev, dtype=F32),
             logits=torch.empty(B, cfg.vocab, device=dev, dtype=F32),
+            sample_ws=K.sample_workspace(B, cfg.vocab, dev) if SAMPLER_WIDE else None,
         )
         out = st["out"] = torch.full((B, C), cfg.pad_token_id, dtype=torch.int64, device=dev)
         st["eos_at"] = None if _eos_at is None else _eos_at.to(dev)
@@ -347,7 +351,7 @@ class RolloutEngine:
             K.eos_schedule_(st["logits"], st["step"], 1, st["eos_at"], cfg.eos_token_id)
         K.sample_top_p_step(st["logits"], st["step"], 1, out, top_k=sp.top_k, top_p=sp.top_p, temperature=sp.temperature, seed=sp.seed,
                             eos_id=cfg.eos_token_id, pad_id=cfg.pad_token_id, suppress_eos=sp.suppress_eos,
-                            finished=st["finished"], out_ids=st["cur_tok"])
+                            finished=st["finished"], out_ids=st["cur_tok"], workspace=st["sample_ws"])
         graph = None
         n_steps = 0
         for s in range(1, C):

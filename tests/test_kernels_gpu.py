@@ -801,3 +801,41 @@ def test_sampler_mass_ties_take_the_exact_select_path(dev):
         step.fill_(s)
         seen.update(K.sample_top_p(logits2, step, top_k=5, top_p=1.0, seed=9).tolist())
     assert seen <= set(hot[:5].tolist()) and len(seen) >= 3
+
+
+@pytest.mark.parametrize("B", [1, 8, 12, 64, 100])
+def test_sampler_wide_form_draws_the_same_tokens(dev, B):
+    """Round 6: the sampler's wide form (several workgroups per row for the two passes over the logits: partial maxima -> bound -> candidate
+    gather -> the same sort / top-k trim / nucleus / draw) must return the SAME token as the one-workgroup-per-row form for the same logits
+    and Philox counter: Qwen2-VL's vocabulary (152 064, and a ragged 152 067 in a padded buffer), per-row different logits, several steps,
+    top_k 1 / 50 / 1024, temperature, EOS suppression, finished rows; a row with 2000 tied maxima overflows the candidate list and takes the
+    single-workgroup fallback inside the final kernel."""
+    for V in (152064, 152067):
+        Vp = (V + 3) // 4 * 4
+        g = torch.Generator().manual_seed(B + V)
+        buf = torch.zeros(B, Vp, device=dev)
+        buf[:, :V] = (torch.randn(B, V, generator=g) * 2.5).to(dev)
+        if B >= 8:
+            buf[3, torch.randperm(V, generator=g)[:2000].to(dev)] = 11.0       # mass tie: > CAP candidates in this row
+        logits = buf[:, :V]
+        ws = K.sample_workspace(B, V, dev)
+        step = torch.zeros(1, dtype=torch.int32, device=dev)
+        fin0 = torch.zeros(B, dtype=torch.int32, device=dev)
+        if B > 5:
+            fin0[5] = 1
+        for s, (tk, tp, temp, sup) in enumerate(((50, 0.95, 1.0, False), (1, 1.0, 1.0, True), (1024, 0.9, 0.7, False), (50, 1.0, 1.3, True), (7, 0.5, 1.0, False))):
+            step.fill_(s)
+            eos = int(logits[0].argmax())
+            fa, fb = fin0.clone(), fin0.clone()
+            a = K.sample_top_p(logits, step, top_k=tk, top_p=tp, temperature=temp, seed=11, eos_id=eos, pad_id=3, suppress_eos=sup, finished=fa)
+            b = K.sample_top_p(logits, step, top_k=tk, top_p=tp, temperature=temp, seed=11, eos_id=eos, pad_id=3, suppress_eos=sup, finished=fb,
+                               workspace=ws)
+            assert torch.equal(a, b), (V, s, (a != b).nonzero().flatten().tolist())
+            assert torch.equal(fa, fb)
+        # the decode-loop form (token also written into the [B, C] matrix at the device-side step)
+        out_a = torch.zeros(B, 4, dtype=torch.int64, device=dev); out_b = torch.zeros_like(out_a)
+        ia, ib = torch.empty(B, dtype=torch.int64, device=dev), torch.empty(B, dtype=torch.int64, device=dev)
+        step.fill_(1)
+        K.sample_top_p_step(logits, step, 1, out_a, seed=5, out_ids=ia)
+        K.sample_top_p_step(logits, step, 1, out_b, seed=5, out_ids=ib, workspace=ws)
+        assert torch.equal(out_a, out_b) and torch.equal(ia, ib) and bool((out_a[:, 2] == ia).all())
