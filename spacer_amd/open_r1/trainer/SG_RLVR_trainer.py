@@ -201,6 +201,9 @@ class SGRLVRTrainer:
         self.num_generations = args.num_generations
         self.shuffled_num_generations = self.num_generations // 2
         self.temporal = bool(self.script_args.temporal)
+        if self.temporal and self.shuffled_num_generations < 1:
+            # (TR:473 would ask HF generate for num_return_sequences = 0 on the shuffled twin)
+            raise ValueError("--temporal true needs --num_generations >= 2: the frame-shuffled twin generates num_generations // 2 rollouts")
         self.len_control = bool(self.script_args.len_control)
         self.beta = args.beta
         self.era_rule = bool(getattr(self.script_args, "mrope_era_rule", True))
