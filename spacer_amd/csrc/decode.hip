@@ -372,15 +372,24 @@ __global__ __launch_bounds__(256) void decode_qkv_finish_kernel(float* __restric
     const int total = B * heads * half;
     const int pos = *tail_len;
     if (rowss_zero && blockIdx.x == 0 && threadIdx.x < B) rowss_zero[threadIdx.x] = 0.f;
+    // every load of an element is issued before the first use (round 6): with the uses next to the loads (row sum -> rsqrt, sums + bias,
+    // the rotary tables behind `if (hh < ...)`) the kernel was four dependent round trips; absent operands (no bias / no folded norm) read a
+    // valid dummy address and are masked, so there is no branch between the loads
+    const bf16_t* bias_p = bias ? bias : (const bf16_t*)cs;
+    const float* rowss_p = rowss ? rowss : cs;
+    const float bias_on = bias ? 1.f : 0.f;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int j = i % half, hh = (i / half) % heads, b = i / (half * heads);
         float* a = acc + ((long)b * heads + hh) * D;
-        const float rs = rowss ? rsqrtf(rowss[b] / (float)norm_cols + eps) : 1.f;
-        float x1 = a[j] * rs + (bias ? bf2f(bias[hh * D + j]) : 0.f);
-        float x2 = a[j + half] * rs + (bias ? bf2f(bias[hh * D + j + half]) : 0.f);
+        const float rsum = rowss_p[rowss ? b : 0];
+        const float a1 = a[j], a2 = a[j + half];
+        const bf16_t b1 = bias_p[bias ? hh * D + j : 0], b2 = bias_p[bias ? hh * D + j + half : 0];
+        const float c1 = cs[b * D + j], s1 = sn[b * D + j], c2 = cs[b * D + j + half], s2 = sn[b * D + j + half];
+        const float rs = rowss ? rsqrtf(rsum / (float)norm_cols + eps) : 1.f;
+        float x1 = a1 * rs + bias_on * bf2f(b1);
+        float x2 = a2 * rs + bias_on * bf2f(b2);
         a[j] = 0.f; a[j + half] = 0.f;
         if (hh < Hq + Hkv) {   // rotary on q and k heads
-            const float c1 = cs[b * D + j], s1 = sn[b * D + j], c2 = cs[b * D + j + half], s2 = sn[b * D + j + half];
             const float r1 = x1 * c1 - x2 * s1, r2 = x2 * c2 + x1 * s2;
             x1 = r1; x2 = r2;
         }

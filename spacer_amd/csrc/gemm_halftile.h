@@ -129,9 +129,15 @@ __global__ __launch_bounds__(512) void gemm_tail_reduce_kernel(GemmArgs g, PairA
     tile_of_256(g.full_tiles + lt, g, tm, tn);
     const float4* p = (const float4*)g.slabs + (size_t)lt * g.splits * SLAB4 + f * 512 + tid;
     f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int sp = 0; sp < g.splits; ++sp) {
-        const float4 v = p[(size_t)sp * SLAB4];
-        sum[0] += v.x; sum[1] += v.y; sum[2] += v.z; sum[3] += v.w;
+    // the slabs of up to 8 splits are requested together, then summed in split order (round 6: as a rolled loop every split was its own
+    // dependent round trip -- load, s_waitcnt vmcnt(0), add -- and the kernel took 17 us for a few MB of slabs); same order of additions
+    for (int s0 = 0; s0 < g.splits; s0 += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (s0 + u < g.splits) ? p[(size_t)(s0 + u) * SLAB4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (s0 + u < g.splits) { sum[0] += v[u].x; sum[1] += v[u].y; sum[2] += v[u].z; sum[3] += v[u].w; }
     }
     const EpiArgs e = {g.C, g.bias, g.resid, g.ldc, g.ldr, g.M, g.N, g.out_f32, g.act, g.alpha};
     const int m = tm * 256 + wr * 128 + i * 16 + (lane & 15), nl = wc * 64 + j * 16 + (lane >> 4) * 4;      // row, column inside the tile

@@ -42,12 +42,30 @@ __global__ __launch_bounds__(NT) void norm_fwd_kernel(const void* __restrict__ x
         const long base = (long)row * cols;
         float xv[MAXIT][4];
         float s = 0.f;
+        // all of the row's loads are issued before the first value is used (round 6): with the use inside each `if (c < cols)` block hipcc
+        // emitted load / s_waitcnt vmcnt(0) / add per block -- up to 8 dependent round trips per row; in the decode loop (64 x 3584 rows,
+        // one row per workgroup) the kernel is nothing but that latency.  Columns past the row read column 0 again and are zeroed.
+        const int nit = (cols + NT * 4 - 1) / (NT * 4);
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
             const int c = (it * NT + threadIdx.x) * 4;
-            if (c < cols) {
-                load4<XF32>(x, base + c, xv[it]);
-                s += xv[it][0] + xv[it][1] + xv[it][2] + xv[it][3];
+            if (it < nit) load4<XF32>(x, base + (c < cols ? c : 0), xv[it]);
+        }
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int c = (it * NT + threadIdx.x) * 4;
+            if (it < nit && c < cols) s += xv[it][0] + xv[it][1] + xv[it][2] + xv[it][3];
+        }
+        // (the weight / bias values do not depend on the statistics: requested before the reductions, all at once, for the same reason)
+        // (raw bf16 bits: the conversion would be a use, and a use inside the block puts the wait right behind the load again)
+        uint2 wraw[MAXIT], braw[MAXIT];
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int c = (it * NT + threadIdx.x) * 4;
+            wraw[it] = make_uint2(0, 0); braw[it] = make_uint2(0, 0);
+            if (it < nit) {
+                wraw[it] = *(const uint2*)(w + (c < cols ? c : 0));
+                if (LAYER) braw[it] = *(const uint2*)(b + (c < cols ? c : 0));
             }
         }
         float mu = 0.f;
@@ -56,7 +74,7 @@ __global__ __launch_bounds__(NT) void norm_fwd_kernel(const void* __restrict__ x
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
             const int c = (it * NT + threadIdx.x) * 4;
-            if (c < cols) {
+            if (it < nit && c < cols) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { const float d = xv[it][e] - mu; ss += d * d; }
             }
@@ -70,12 +88,12 @@ __global__ __launch_bounds__(NT) void norm_fwd_kernel(const void* __restrict__ x
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
             const int c = (it * NT + threadIdx.x) * 4;
-            if (c < cols) {
-                float wv[4], bv[4] = {0.f, 0.f, 0.f, 0.f}, o[4];
-                loadbf4(w, c, wv);
-                if (LAYER) loadbf4(b, c, bv);
+            if (it < nit && c < cols) {
+                const float wv[4] = {bf_lo(wraw[it].x), bf_hi(wraw[it].x), bf_lo(wraw[it].y), bf_hi(wraw[it].y)};
+                const float bv[4] = {bf_lo(braw[it].x), bf_hi(braw[it].x), bf_lo(braw[it].y), bf_hi(braw[it].y)};
+                float o[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (xv[it][e] - mu) * rstd * wv[e] + bv[e];
+                for (int e = 0; e < 4; ++e) o[e] = (xv[it][e] - mu) * rstd * wv[e] + (LAYER ? bv[e] : 0.f);
                 store4<false>(y, base + c, o);
             }
         }
