@@ -13,7 +13,7 @@ import sys
 
 import torch
 
-REPS, LAUNCHES = 5, 6
+REPS, LAUNCHES = 9, 6
 _p, _i, _l = C.c_void_p, C.c_int, C.c_long
 
 
@@ -49,8 +49,12 @@ def main():
     ws = torch.empty(libs[-1][1].spacer_gemm_workspace_bytes() // 4 + 64, device=dev)
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
-    def epi(residual=None, f32=0):
-        return Epi(None, residual.data_ptr() if residual is not None else None, residual.stride(0) if residual is not None else 0, f32, 0, 1.0,
+    b_qkv, Tv, Hv = rnd(QKV), 13824, 1280                                                       # vision tower: 1280 wide, 3840 q|k|v, 5120 MLP
+    xv, wv_qkv, wv_fc1, bv_qkv, bv_fc1 = rnd(Tv, Hv), rnd(3 * Hv, Hv), rnd(4 * Hv, Hv), rnd(3 * Hv), rnd(4 * Hv)
+    outv_qkv, outv_fc1 = torch.empty(Tv, 3 * Hv, device=dev, dtype=torch.bfloat16), torch.empty(Tv, 4 * Hv, device=dev, dtype=torch.bfloat16)
+
+    def epi(residual=None, f32=0, bias=None, act=0):
+        return Epi(bias.data_ptr() if bias is not None else None, residual.data_ptr() if residual is not None else None, residual.stride(0) if residual is not None else 0, f32, act, 1.0,
                    ws.data_ptr(), ws.numel() * 4, None)
 
     def nt(lib, a, w, out, e):
@@ -61,6 +65,9 @@ def main():
         ("gate|up + SwiGLU <t,f,f,t>", 2.0 * T * 2 * I * H,
          lambda lib: lib.spacer_gemm_swiglu_bf16(x.data_ptr(), H, w_gu.data_ptr(), H, None, out_a.data_ptr(), I, out_gu.data_ptr(), 2 * I, T, I, H, stream)),
         ("q|k|v bf16 out <t,f,f,t>", 2.0 * T * QKV * H, lambda lib: nt(lib, x, w_qkv, out_qkv, epi())),
+        ("q|k|v + bias bf16 out <t,f,f,t>", 2.0 * T * QKV * H, lambda lib: nt(lib, x, w_qkv, out_qkv, epi(bias=b_qkv))),
+        ("ViT q|k|v + bias (13824 x 3840 x 1280)", 2.0 * Tv * 3 * Hv * Hv, lambda lib: nt(lib, xv, wv_qkv, outv_qkv, epi(bias=bv_qkv))),
+        ("ViT fc1 + bias + act (13824 x 5120 x 1280)", 2.0 * Tv * 4 * Hv * Hv, lambda lib: nt(lib, xv, wv_fc1, outv_fc1, epi(bias=bv_fc1, act=1))),
         ("o fp32 + residual <t,f,f,f>", 2.0 * T * H * H, lambda lib: nt(lib, x, w_o, out32, epi(res, 1))),
         ("down fp32 + residual <t,f,f,f>", 2.0 * T * H * I, lambda lib: nt(lib, xi, w_dn, out32, epi(res, 1))),
         ("dX of gate|up <t,f,t,t>", 2.0 * T * H * 2 * I,

@@ -120,13 +120,16 @@ __global__ __launch_bounds__(NT) void norm_fwd_wave_kernel(const void* __restric
         const long base = (long)row * cols;
         float xv[WG][4];
         float s = 0.f;
+        // (all loads of the row before the first use, as in norm_fwd_kernel: columns past the row re-read column 0 and are not summed)
 #pragma unroll
         for (int it = 0; it < WG; ++it) {
             const int c = (it * 64 + lane) * 4;
-            if (c < cols) {
-                load4<XF32>(x, base + c, xv[it]);
-                s += xv[it][0] + xv[it][1] + xv[it][2] + xv[it][3];
-            }
+            load4<XF32>(x, base + (c < cols ? c : 0), xv[it]);
+        }
+#pragma unroll
+        for (int it = 0; it < WG; ++it) {
+            const int c = (it * 64 + lane) * 4;
+            if (c < cols) s += xv[it][0] + xv[it][1] + xv[it][2] + xv[it][3];
         }
         const float mu = LAYER ? wave_sum(s) / cols : 0.f;
         float ss = 0.f;
