@@ -35,16 +35,17 @@ def tiny(dev):
     return dict(g=g, params=params, wb=wb, prompts=prompts, rows=rows.to(torch.bfloat16).float(), grid=tuple(grid))
 
 
-def test_greedy_rollout_is_oracle_argmax(tiny, dev):
+@pytest.mark.parametrize("Kn", [2, 10])       # 4 rows: the <= 16-row decode forms; 20 rows: the 17..64-row forms (norm on the o launch)
+def test_greedy_rollout_is_oracle_argmax(tiny, dev, Kn):
     eng = Qwen2VLEngine(TINY, tiny["params"])
     roll = RolloutEngine(eng)
     sp = SamplingParams(max_new_tokens=7, top_k=1, top_p=1.0, suppress_eos=True)
-    out = roll.generate(tiny["prompts"], 2, sp, use_graph=False)
-    assert out.shape == (4, 7)
-    assert torch.equal(out[0], out[1]) and torch.equal(out[2], out[3])          # greedy: the K rollouts coincide
+    out = roll.generate(tiny["prompts"], Kn, sp, use_graph=False)
+    assert out.shape == (2 * Kn, 7)
+    assert all(torch.equal(out[0], out[i]) and torch.equal(out[Kn], out[Kn + i]) for i in range(Kn))   # greedy: the K rollouts coincide
     g = tiny["g"]
     for pi, (pids, rows, grids) in enumerate(((g["prompt"], tiny["rows"], [tiny["grid"]]), (g["prompt"][-9:], None, None))):
-        comp = out[2 * pi].cpu()
+        comp = out[Kn * pi].cpu()
         ids = torch.cat([pids, comp])
         lg = O.full_logits(tiny["wb"], g["cfg"], ids, rows, grids)
         P = pids.numel()
@@ -54,7 +55,8 @@ def test_greedy_rollout_is_oracle_argmax(tiny, dev):
             assert float(row.max() - row[comp[t]]) < 3e-2, (pi, t, float(row.max() - row[comp[t]]))
 
 
-def test_graph_replay_equals_eager_and_scoring_agrees(tiny, dev, monkeypatch):
+@pytest.mark.parametrize("Kn", [3, 12])
+def test_graph_replay_equals_eager_and_scoring_agrees(tiny, dev, monkeypatch, Kn):
     # split-K flushes of the decode GEMMs are fp32 atomics (arrival order = last-bit noise in the residual stream, which
     # can flip a sampled token whose draw sits on a CDF boundary); one K range per block makes the sums reproducible so
     # that "replay == eager" can be asserted bit for bit
@@ -62,9 +64,9 @@ def test_graph_replay_equals_eager_and_scoring_agrees(tiny, dev, monkeypatch):
     eng = Qwen2VLEngine(TINY, tiny["params"])
     roll = RolloutEngine(eng)
     sp = SamplingParams(max_new_tokens=12, top_k=50, top_p=0.95, seed=11, suppress_eos=True)
-    a = roll.generate(tiny["prompts"], 3, sp, use_graph=False)
+    a = roll.generate(tiny["prompts"], Kn, sp, use_graph=False)
     st = {}
-    b = roll.generate(tiny["prompts"], 3, sp, use_graph=True, stats=st)
+    b = roll.generate(tiny["prompts"], Kn, sp, use_graph=True, stats=st)
     assert st["graph"] and torch.equal(a, b)
     assert len({tuple(r.tolist()) for r in a[:3]}) > 1                           # sampling: rollouts of one prompt differ
     # log-prob of the sampled tokens: scoring path (packed, shared prefix) vs the oracle
