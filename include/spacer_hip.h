@@ -246,19 +246,6 @@ int spacer_attn_decode_shared_rows(const void* q, const void* prefix_k, const vo
  *                  Wp = spacer_pack_weight_frag_swiglu of W diag(w_norm); workspace / plan as spacer_gemm_skinny_swiglu_bf16_ws. */
 int spacer_gemm_skinny_swiglu_normed(const float* x32, long ldx, const void* Bpacked, void* Y, long ldy, int M, int inter, int K,
                                      float eps, void* workspace, long workspace_bytes, const spacer_plan* plan, spacer_stream_t stream);
-/* Round 6: HF's o_proj + residual add + post_attention_layernorm + gate_proj / up_proj + act_fn of one generate step (TR:463) for 17..64
- * rows in TWO launches instead of three, no second pass over the residual stream:
- *   acc_ln:     C32[M,N] += A . Wp^T (o into the fp32 residual stream); the last K range of every 64-column block then writes
- *               h[M,N] = bf16(C32 * ln_w) and ss_part[N / 64][64] = that block's row sums of C32^2 (plain stores, fixed order).
- *               tickets: N / 64 ints ZERO-initialised once by the caller (left zeroed); launches sharing them ordered on one stream.
- *               M <= 64, N % 64 == 0, K % 256 == 0; equal K ranges only (plan.skinny_skew <= 0).
- *   swiglu_ss:  Y[M, inter] = silu(rstd g) * (rstd u), [g | u] = h . Wp^T, rstd[m] = rsqrt(sum_parts ss_part[.][m] / K + eps);
- *               Wp = spacer_pack_weight_frag_swiglu of the UNFOLDED gate|up weight; n_parts = K / 64 <= 64. */
-int spacer_gemm_skinny_packed_acc_ln(const void* A, long lda, const void* Bpacked, float* C32, long ldc, int M, int N, int K,
-                                     const void* ln_w, void* h, long ldh, float* ss_part, int* tickets, const spacer_plan* plan,
-                                     spacer_stream_t stream);
-int spacer_gemm_skinny_swiglu_ss(const void* H, long ldh, const void* Bpacked, void* Y, long ldy, int M, int inter, int K,
-                                 const float* ss_part, int n_parts, float eps, const spacer_plan* plan, spacer_stream_t stream);
 int spacer_decode_rope_table(const int* pos_base, const int* step_dev, float theta, float* cos_t, float* sin_t, int B,
                              int D, spacer_stream_t stream);
 int spacer_decode_qkv_finish(float* acc32, const void* bias, const float* cos_t, const float* sin_t, void* q_out,

@@ -101,8 +101,6 @@ SIGNATURES = {
     "spacer_decode_qkv_finish_normed": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _f, _i, _i, _i, _i, _i, _p],
     "spacer_gemm_skinny_packed_normed": [_p, _l, _p, _p, _l, _p, _i, _i, _i, C.POINTER(Plan), _p],
     "spacer_gemm_skinny_swiglu_normed": [_p, _l, _p, _p, _l, _i, _i, _i, _f, _p, _l, C.POINTER(Plan), _p],
-    "spacer_gemm_skinny_packed_acc_ln": [_p, _l, _p, _p, _l, _i, _i, _i, _p, _p, _l, _p, _p, C.POINTER(Plan), _p],
-    "spacer_gemm_skinny_swiglu_ss": [_p, _l, _p, _p, _l, _i, _i, _i, _p, _i, _f, C.POINTER(Plan), _p],
     "spacer_swiglu_f32_fwd": [_p, _p, _i, _i, _p],
     "spacer_gemm_swiglu_bf16": [_p, _l, _p, _l, _p, _p, _l, _p, _l, _i, _i, _i, _p],
     "spacer_resize_bicubic_aa_u8": [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _i, _p, _p],

@@ -52,34 +52,15 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 // workgroup costs 16 x 256 x 4 B per slice beside 40 KB of weights -- at 64 rows the same fold measured slower), every
 // workgroup sums x^2 per row over its whole K (the SWIGLU forms never split K), rstd meets the epilogue through LDS, and the packed
 // weights carry W diag(w_ln2): y = silu(rstd g) * (rstd u).  One ~5 us launch (the norm) less per layer of an 8-row decode step.
-// FIN (round 6; packed weights, MT = 1; 17..64 rows): the post-attention RMSNorm without its launch and without a second pass over x.
-//   FIN = 1 (K-split accumulate form: the o projection, C = the fp32 residual stream): every workgroup takes a ticket of its column
-//   group after its atomics are performed; the LAST of the group's K ranges reads the finished 64 x 64 block of x back at the coherence
-//   point (returning atomics, as the SwiGLU tail balance does), writes h = bf16(x * w_ln) for its columns and the block's row sums of x^2
-//   into ss_part[column group][row] (plain stores: fixed order, no clearing).
-//   FIN = 2 (SwiGLU form): A = that h; the 64 x n_parts partial sums are requested before the K loop (16 independent loads per thread),
-//   summed in part order after it, rstd meets the epilogue through LDS: y = silu(rstd g) * (rstd u) -- rstd is a per-row scalar, so
-//   bf16(x w) . W^T * rstd is norm(x) . W^T with the rounding of h taken before instead of after the scaling (same relative error).
-//   Costs the o launch a ticket round trip + one 16 KB block per column group, saves the ~6 us norm launch per layer.
-struct SkinnyFin {
-    const bf16_t* ln_w;     // FIN = 1: norm weight [N]
-    bf16_t* h;              // FIN = 1: bf16 [M, ldh] out
-    long ldh;
-    float* ss_part;         // FIN = 1: out [N / 64][64];  FIN = 2: in [n_parts][64]
-    int n_parts;            // FIN = 2 (<= 64)
-};
-
-template <bool PACKED, bool SWIGLU = false, int MT = 1, bool NORMA = false, bool SMALL = false, int FIN = 0>
+template <bool PACKED, bool SWIGLU = false, int MT = 1, bool NORMA = false, bool SMALL = false>
 __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __restrict__ A, long lda,
                                                              const bf16_t* __restrict__ B, long ldb,
                                                              float* __restrict__ C, long ldc, int M, int N, int K,
                                                              int slices_per_range, int mflush, int overwrite,
                                                              int split_groups = 0, int split_ranges = 1,
                                                              float* __restrict__ scratch = nullptr, int* __restrict__ tickets = nullptr,
-                                                             float* __restrict__ rowss = nullptr, int wide_groups = 0, float eps = 0.f,
-                                                             SkinnyFin fin = SkinnyFin{nullptr, nullptr, 0, nullptr, 0}) {
+                                                             float* __restrict__ rowss = nullptr, int wide_groups = 0, float eps = 0.f) {
     static_assert(!SMALL || MT == 1, "SMALL is a 64-row-block form");
-    static_assert(FIN == 0 || (PACKED && MT == 1 && !NORMA && !SMALL && (FIN == 1) == !SWIGLU), "FIN: 1 = K-split accumulate form, 2 = SwiGLU form");
     constexpr int KS = 256 / MT, ROWB = KS * 2;            // LDS row bytes (512 / 256); 16-byte chunk index ^= row & 15
     constexpr int NU = KS / 32, MF = SMALL ? 1 : 4 * MT;   // MFMA k-steps per slice, 16-row A fragments
     constexpr int NJ = SMALL ? 2 : 8;                      // staging instructions per thread (8 rows each)
@@ -218,15 +199,6 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __res
     u32x4 wa[NU], wb[NU], wa5[N5], wb5[N5];
 #pragma unroll
     for (int q = 0; q < N5; ++q) { wa5[q] = (u32x4){0u, 0u, 0u, 0u}; wb5[q] = (u32x4){0u, 0u, 0u, 0u}; }
-    float pss[FIN == 2 ? 16 : 1];                      // FIN = 2: row (tid & 63), parts (tid >> 6) + 4 i -- clamped address, masked value
-    if (FIN == 2) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int part = (tid >> 6) + 4 * i;
-            const float v = fin.ss_part[(long)min(part, fin.n_parts - 1) * 64 + (tid & 63)];
-            pss[FIN == 2 ? i : 0] = part < fin.n_parts ? v : 0.f;
-        }
-    }
     load_a(s_begin);
     load_w(wa, s_begin);
     if (wide) load_w5(wa5, s_begin);
@@ -243,19 +215,7 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __res
         compute(wb, wb5, smem[1]);
         if (++s >= s_end) break;
     }
-    __shared__ float rstd_lds[SWIGLU && (NORMA || FIN == 2) ? 64 : 1];
-    if (FIN == 2) {
-        // part order: this thread's 16 parts in order, then the four part groups in order -- one fixed summation order per row
-        float* part4 = (float*)&smem[0][0];           // [4][64]; every wave has left the A buffers: barrier first
-        float sp = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) sp += pss[FIN == 2 ? i : 0];
-        __syncthreads();
-        part4[tid] = sp;
-        __syncthreads();
-        if (tid < 64) rstd_lds[SWIGLU && (NORMA || FIN == 2) ? tid : 0] = rsqrtf((part4[tid] + part4[64 + tid] + part4[128 + tid] + part4[192 + tid]) / (float)K + eps);
-        __syncthreads();
-    }
+    __shared__ float rstd_lds[SWIGLU && NORMA ? 64 : 1];
     if (NORMA && sums) {
         // the CH = 32 threads that share a row are one half wave: reduce, one atomic per row per K range
 #pragma unroll
@@ -264,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __res
 #pragma unroll
             for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
             const int row = ar0 + (256 / CH) * j;
-            if (SWIGLU) { if (ach == 0) rstd_lds[SWIGLU && (NORMA || FIN == 2) ? row : 0] = rsqrtf(v / (float)K + eps); }   // whole K in this workgroup
+            if (SWIGLU) { if (ach == 0) rstd_lds[SWIGLU && NORMA ? row : 0] = rsqrtf(v / (float)K + eps); }   // whole K in this workgroup
             else if (ach == 0 && row < M) atomicAdd(rowss + row, v);
         }
     }
@@ -308,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __res
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = mf * 16 + g * 4 + r;
-                const float rs = (SWIGLU && (NORMA || FIN == 2)) ? rstd_lds[SWIGLU && (NORMA || FIN == 2) ? m : 0] : 1.f;
+                const float rs = (SWIGLU && NORMA) ? rstd_lds[SWIGLU && NORMA ? m : 0] : 1.f;
                 const float other = __shfl_xor(acc[mf][r], 8) * rs;
                 if (l15 < 8 && m < mflush && n < N) {
                     const float gv = acc[mf][r] * rs;
@@ -338,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __res
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = mf * 16 + g * 4 + r;
-                    const float rs = (SWIGLU && (NORMA || FIN == 2)) ? rstd_lds[SWIGLU && (NORMA || FIN == 2) ? m : 0] : 1.f;
+                    const float rs = (SWIGLU && NORMA) ? rstd_lds[SWIGLU && NORMA ? m : 0] : 1.f;
                     const float other = __shfl_xor(v[r], 8) * rs, gv = v[r] * rs;
                     if (l15 < 8 && m < mflush && n5 + l15 < N)
                         Y[(long)m * ldc + col5] = f2bf(gv / (1.f + __expf(-gv)) * other);
@@ -360,46 +320,6 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16_t* __res
                     else atomicAdd(c, acc[mf][r]);
                 }
             }
-    }
-    if (FIN == 1) {
-        // ticket of the column group once this workgroup's adds are performed; the last K range finishes the block
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        __shared__ int fin_last;
-        if (tid == 0) {
-            int t = (int)gridDim.y - 1;
-            if (!whole_k) t = __hip_atomic_fetch_add(tickets + cgroup, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            fin_last = (t == (int)gridDim.y - 1);
-        }
-        __syncthreads();
-        if (!fin_last) return;
-        float* ssl = (float*)&smem[0][0];             // [4 waves][64 rows]
-        const float wn = n < N ? bf2f(fin.ln_w[n]) : 0.f;
-        float xv[MF][4];
-#pragma unroll
-        for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = mf * 16 + g * 4 + r;
-                // the finished sums, read where the adds were performed (a plain load could be served by this XCD's L2)
-                // (a whole-K workgroup re-reads its own plain stores: same thread, same address)
-                float* c = C + (long)m * ldc + n;
-                xv[mf][r] = (m < mflush && n < N) ? (whole_k ? *c : __hip_atomic_fetch_add(c, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.f;
-            }
-#pragma unroll
-        for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = mf * 16 + g * 4 + r;
-                if (m < mflush && n < N) fin.h[(long)m * fin.ldh + n] = f2bf(xv[mf][r] * wn);
-                float q = xv[mf][r] * xv[mf][r];
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);         // the 16 columns of this wave
-                if (l15 == 0) ssl[wave * 64 + m] = q;
-            }
-        __syncthreads();
-        if (tid < 64) fin.ss_part[(long)cgroup * 64 + tid] = ssl[tid] + ssl[64 + tid] + ssl[128 + tid] + ssl[192 + tid];
-        if (tid == 0 && !whole_k) __hip_atomic_exchange(tickets + cgroup, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -991,30 +911,6 @@ extern "C" int spacer_gemm_skinny_packed_normed(const float* X32, long ldx, cons
     return SPACER_OK;
 }
 
-// C32[M,N] += A . Wp^T (the o projection into the fp32 residual stream), and from the finished C:  h[M,N] = bf16(C * ln_w),
-// ss_part[N / 64][64] = per 64-column block the row sums of C^2 (gemm_skinny_kernel FIN = 1).  tickets: N / 64 ints, ZERO-initialised once
-// by the caller (the kernel leaves them zeroed); launches sharing them must be ordered on one stream.  M <= 64, N % 64 == 0.
-extern "C" int spacer_gemm_skinny_packed_acc_ln(const void* A, long lda, const void* Bpacked, float* C, long ldc, int M, int N, int K,
-                                                const void* ln_w, void* h, long ldh, float* ss_part, int* tickets,
-                                                const spacer_plan* plan, spacer_stream_t stream) {
-    SP_REQUIRE(A && Bpacked && C && ln_w && h && ss_part && tickets, SPACER_EINVAL, "gemm_skinny_acc_ln: null operand");
-    SP_REQUIRE_PLAN(plan);
-    SP_REQUIRE(M > 0 && M <= 64 && K % 256 == 0 && N % 64 == 0 && lda % 8 == 0, SPACER_EINVAL,
-               "gemm_skinny_acc_ln: need 0 < M <= 64, K %% 256 == 0, N %% 64 == 0, lda %% 8 == 0 (M=%d N=%d K=%d)", M, N, K);
-    SP_REQUIRE(!plan || plan->skinny_skew <= 0, SPACER_EINVAL, "gemm_skinny_acc_ln: equal K ranges only (plan.skinny_skew = %d)", plan->skinny_skew);
-    const int col_groups = N / 64, slices = K / 256;
-    const int target_blocks = skinny_target_blocks(plan);
-    int ranges = col_groups < target_blocks - target_blocks / 8 ? max(1, min(slices, target_blocks / col_groups)) : 1;
-    const int spr = cdiv(slices, ranges);
-    ranges = cdiv(slices, spr);                            // every range non-empty: the ticket counts gridDim.y arrivals
-    SkinnyFin fin{(const bf16_t*)ln_w, (bf16_t*)h, ldh, ss_part, 0};
-    hipLaunchKernelGGL((gemm_skinny_kernel<true, false, 1, false, false, 1>), dim3(col_groups, ranges), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)A, lda, (const bf16_t*)Bpacked, 0L, C, ldc, M, N, K, spr, M, 0, 0, 1, (float*)nullptr, tickets,
-                       (float*)nullptr, 0, 0.f, fin);
-    SP_CHECK_LAUNCH();
-    return SPACER_OK;
-}
-
 extern "C" int spacer_gemm_skinny_packed_store_bf16(const void* A, long lda, const void* Bpacked, void* C, long ldc, int M, int N,
                                                     int K, const spacer_plan* plan, spacer_stream_t stream) {
     return launch_skinny(A, lda, Bpacked, 0, C, ldc, M, N, K, nullptr, true, plan, (hipStream_t)stream, true);
@@ -1124,29 +1020,6 @@ extern "C" int spacer_gemm_skinny_swiglu_normed(const float* X32, long ldx, cons
                                                 spacer_stream_t stream) {
     SP_REQUIRE(ldx % 4 == 0 && ((uintptr_t)X32 % 16) == 0, SPACER_EINVAL, "gemm_skinny_swiglu_normed: x32 rows must be 16-byte aligned");
     return launch_skinny_swiglu(X32, ldx, Bpacked, Y, ldy, M, inter, K, workspace, workspace_bytes, plan, (hipStream_t)stream, true, eps);
-}
-
-// y[M, inter] = silu(rstd g) * (rstd u), [g | u] = h . Wp^T with h = bf16(x * w_norm) and ss_part[n_parts][64] = the row sums of x^2 per
-// 64-column block, both left by spacer_gemm_skinny_packed_acc_ln; rstd = rsqrt(sum_parts / K + eps) (gemm_skinny_kernel FIN = 2).
-// Wp = spacer_pack_weight_frag_swiglu of the UNFOLDED gate|up weight.  17..64 rows of a decode step (TR:463); <= 64 accepted.
-extern "C" int spacer_gemm_skinny_swiglu_ss(const void* H, long ldh, const void* Bpacked, void* Y, long ldy, int M, int inter, int K,
-                                            const float* ss_part, int n_parts, float eps, const spacer_plan* plan, spacer_stream_t stream) {
-    SP_REQUIRE(H && Bpacked && Y && ss_part, SPACER_EINVAL, "gemm_skinny_swiglu_ss: null operand");
-    SP_REQUIRE_PLAN(plan);
-    SP_REQUIRE(M > 0 && M <= 64 && K % 256 == 0 && inter % 32 == 0 && ldh % 8 == 0, SPACER_EINVAL,
-               "gemm_skinny_swiglu_ss: need 0 < M <= 64, K %% 256 == 0, inter %% 32 == 0, ldh %% 8 == 0 (M=%d inter=%d K=%d)", M, inter, K);
-    SP_REQUIRE(n_parts > 0 && n_parts <= 64 && n_parts * 64 == K, SPACER_EINVAL,
-               "gemm_skinny_swiglu_ss: n_parts = %d must be K / 64 (K = %d) and <= 64", n_parts, K);
-    const int N = 2 * inter, col_groups = cdiv(N, 64);
-    const int slots1 = 2 * plan_cus(plan), frags = N / 16;
-    const bool one_round = N % 16 == 0 && frags > 4 * slots1 && frags < 5 * slots1 && !(plan && (plan->skinny_no_balance || plan->skinny_blocks));
-    const int wide = one_round ? frags - 4 * slots1 : 0;
-    SkinnyFin fin{nullptr, nullptr, 0, (float*)ss_part, n_parts};
-    hipLaunchKernelGGL((gemm_skinny_kernel<true, true, 1, false, false, 2>), dim3(one_round ? slots1 : col_groups, 1), dim3(256), 0,
-                       (hipStream_t)stream, (const bf16_t*)H, ldh, (const bf16_t*)Bpacked, 0L, (float*)Y, ldy, M, N, K, K / 256, M, 0, 0, 1,
-                       (float*)nullptr, (int*)nullptr, (float*)nullptr, wide, eps, fin);
-    SP_CHECK_LAUNCH();
-    return SPACER_OK;
 }
 
 extern "C" int spacer_decode_rope_table(const int* pos_base, const int* step_dev, float theta, float* cos_t, float* sin_t,

@@ -316,33 +316,6 @@ def gemm_skinny_swiglu_normed(x32: torch.Tensor, bp: torch.Tensor, inter: int, e
     return out
 
 
-def gemm_skinny_packed_acc_ln(a: torch.Tensor, bp: torch.Tensor, c32: torch.Tensor, N: int, ln_w: torch.Tensor, h: torch.Tensor,
-                              ss_part: torch.Tensor, tickets: torch.Tensor) -> torch.Tensor:
-    """c32[M,N] (fp32) += a[M,K] @ W[N,K]^T, then from the finished c32: h = bf16(c32 * ln_w), ss_part[N // 64, 64] = row sums of
-    c32^2 per 64-column block (<= 64 rows; tickets: N // 64 zeroed int32, left zeroed).  The decode o projection with the first half of
-    the post-attention RMSNorm in its last-arriving workgroups; gemm_skinny_swiglu_ss takes h and ss_part."""
-    M, K = a.shape
-    assert bp.numel() == N * K and c32.dtype == torch.float32 and h.dtype == BF16 and ln_w.dtype == BF16 and ln_w.numel() == N
-    assert ss_part.dtype == torch.float32 and ss_part.numel() >= (N // 64) * 64 and tickets.dtype == torch.int32 and tickets.numel() >= N // 64
-    assert h.shape[0] >= M and h.shape[1] == N
-    check(_lib.load().spacer_gemm_skinny_packed_acc_ln(_ptr(a), _rowmajor(a), _ptr(bp), _ptr(c32), _rowmajor(c32), M, N, K, _ptr(ln_w), _ptr(h),
-                                                       _rowmajor(h), _ptr(ss_part), _ptr(tickets), _plan(), _stream()), "gemm_skinny_packed_acc_ln")
-    return h
-
-
-def gemm_skinny_swiglu_ss(h: torch.Tensor, bp: torch.Tensor, inter: int, ss_part: torch.Tensor, eps: float,
-                          out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[M, inter] = silu(rstd g) * (rstd u), [g | u] = h @ Wp^T, rstd = rsqrt(ss_part.sum(0) / K + eps): h and ss_part as left by
-    gemm_skinny_packed_acc_ln, bp = pack_weight_frag_swiglu of the unfolded gate|up weight (<= 64 rows)."""
-    M, K = h.shape
-    assert h.dtype == BF16 and bp.numel() == 2 * inter * K and ss_part.dtype == torch.float32 and K % 64 == 0 and ss_part.numel() >= K
-    if out is None:
-        out = torch.empty(M, inter, device=h.device, dtype=BF16)
-    check(_lib.load().spacer_gemm_skinny_swiglu_ss(_ptr(h), _rowmajor(h), _ptr(bp), _ptr(out), _rowmajor(out), M, inter, K, _ptr(ss_part), K // 64,
-                                                   eps, _plan(), _stream()), "gemm_skinny_swiglu_ss")
-    return out
-
-
 def transpose_pad(x: torch.Tensor, rpad: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x[R,C] bf16 -> out[C, Rpad] with zero fill (Rpad defaults to R rounded up to 64)."""
     R, Cc = x.shape

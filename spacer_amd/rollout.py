@@ -32,10 +32,6 @@ DECODE_NORM_FOLD = os.environ.get("SPACER_DECODE_NORM", "fold") != "separate"   
 # (measured slower at 8 rows: 3.69 vs 3.28 ms per token-step -- each rollout's workgroup re-reads the prompt's keys).
 _SMALL = set(filter(None, os.environ.get("SPACER_DECODE_SMALL", "fold").split(",")))
 DECODE_SMALL_FOLD, DECODE_SMALL_ATTN1 = "fold" in _SMALL, "attn1" in _SMALL
-# decode batches of 17..64 rows (round 6): the post-attention RMSNorm rides on the o projection's last-arriving workgroups (h = bf16(x w) and
-# per-block row sums of x^2, gemm_skinny_kernel FIN = 1) and on the gate|up launch's epilogue (rstd; FIN = 2): one launch less per layer, no
-# second pass over x.  SPACER_DECODE_LN2=separate keeps the norm launch (A/B).
-DECODE_LN2_FOLD = os.environ.get("SPACER_DECODE_LN2", "fold") != "separate"
 # the sampler's wide form (several workgroups per row for the two passes over the logits; same tokens): SPACER_SAMPLER=narrow keeps one
 # workgroup per row (A/B)
 SAMPLER_WIDE = os.environ.get("SPACER_SAMPLER", "wide") != "narrow"
@@ -98,7 +94,6 @@ class RolloutEngine:
         # would clear what it reads, so it keeps the separate norm launch)
         self.fold_norm = DECODE_NORM_FOLD and engine.cfg.layers >= 2
         self.small_fold = DECODE_SMALL_FOLD and engine.cfg.hidden % 256 == 0
-        self.ln2_fold = DECODE_LN2_FOLD and engine.cfg.hidden % 256 == 0 and engine.cfg.hidden <= 4096      # (n_parts = hidden / 64 <= 64)
         # keep the prefill's tape (ViT + prompt rows of every layer) for the policy's scoring pass: None = when it fits (the tape must
         # live through the decode loop beside the training state: ~100 GB for 8 cfg3 groups at 7B -- no; 12 GB for cfg2 at 2B -- yes),
         # True / False = forced.  Only the stored (non-recompute) policy of the Qwen2-VL tower is eligible.
@@ -249,12 +244,6 @@ class RolloutEngine:
             else:
                 o = K.attn_decode(st["q"], st["pk"][i], st["pv"][i], st["plen"], st["prompt_of"], st["tk"][i], st["tv"][i],
                                   st["tail_len"], Hq, Hkv, D, scale, out=st["o"])
-            if self.ln2_fold and B <= 64 and not (self.small_fold and B <= 16):
-                # o into the residual stream; its last-arriving workgroups leave h = bf16(x w_ln2) and the row sums of x^2, gate|up applies rstd
-                K.gemm_skinny_packed_acc_ln(o, PW[p + "o_w"], x, cfg.hidden, W[p + "ln2_w"], st["h"], st["ss_part"], st["ln_tickets"])
-                a = K.gemm_skinny_swiglu_ss(st["h"], PW[p + "gu_w"], I, st["ss_part"], cfg.rms_eps, out=st["a"])
-                K.gemm_skinny_packed_acc(a, PW[p + "down_w"], x, cfg.hidden)
-                continue
             K.gemm_skinny_packed_acc(o, PW[p + "o_w"], x, cfg.hidden)
             if self.small_fold and B <= 16:    # post-attention norm folded into the gate|up launch (x itself is the A operand)
                 a = K.gemm_skinny_swiglu_normed(x, PW[p + "gu_wn"], I, cfg.rms_eps, out=st["a"])
@@ -348,8 +337,6 @@ class RolloutEngine:
             a=torch.empty(B, cfg.intermediate, device=dev, dtype=BF16),
             acc_qkv=torch.zeros(B, cfg.qkv_dim, device=dev, dtype=F32),
             rowss=torch.zeros(cfg.layers, max(B, 1), device=dev, dtype=F32),     # per layer: sum of x^2 per row (norm-folded q|k|v)
-            ss_part=torch.zeros(max(H // 64, 1), 64, device=dev, dtype=F32),     # post-attention norm: row sums of x^2 per 64-column block
-            ln_tickets=torch.zeros(max(H // 64, 1), dtype=torch.int32, device=dev),
             cos=torch.empty(B, D, device=dev, dtype=F32), sin=torch.empty(B, D, device=dev, dtype=F32),
             logits=torch.empty(B, cfg.vocab, device=dev, dtype=F32),
             sample_ws=K.sample_workspace(B, cfg.vocab, dev) if SAMPLER_WIDE else None,

@@ -35,7 +35,7 @@ def tiny(dev):
     return dict(g=g, params=params, wb=wb, prompts=prompts, rows=rows.to(torch.bfloat16).float(), grid=tuple(grid))
 
 
-@pytest.mark.parametrize("Kn", [2, 10])       # 4 rows: the <= 16-row decode forms; 20 rows: the 17..64-row forms (norm on the o launch)
+@pytest.mark.parametrize("Kn", [2, 10])       # 4 rows: the <= 16-row decode forms; 20 rows: the 17..64-row forms
 def test_greedy_rollout_is_oracle_argmax(tiny, dev, Kn):
     eng = Qwen2VLEngine(TINY, tiny["params"])
     roll = RolloutEngine(eng)
