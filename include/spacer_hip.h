@@ -230,18 +230,6 @@ int spacer_attn_decode_shared_rows(const void* q, const void* prefix_k, const vo
                                    const int* prompt_of, const int* row0, const void* tail_k, const void* tail_v,
                                    const int* tail_len_dev, void* o, void* workspace, int B, int n_prompts, int Kmax, int Pmax,
                                    int Cmax, int Hq, int Hkv, int D, float scale, spacer_stream_t stream);
-/* Round 6: spacer_decode_qkv_finish(_normed) folded into the shared-prefix decode attention.  The split launch forms rotary(q),
- * rotary(k), v of the step from acc32 (the q|k|v projection's fp32 sums [B, (Hq + 2 Hkv) * 128]; x rstd from rowss when the projection
- * is norm-folded, + bias) itself, appends k and v to the tail cache at *tail_len_dev, and the merge launch re-zeroes acc32 and clears
- * rowss_zero[0..B).  bias / rowss / rowss_zero may be NULL; row0 NULL = Kmax rollouts per prompt (B = n_prompts * Kmax), else as
- * spacer_attn_decode_shared_rows.  No q buffer, no finishing launch (HF: q/k/v_proj bias + rotary + cache append + attention of one
- * generate step, TR:463).  acc32 / bias / cos / sin 16-byte aligned; the two halves of a cos / sin row must be equal (HF's rotary tables are
- * cat(freqs, freqs); spacer_decode_rope_table writes them so) -- only the first half is read. */
-int spacer_attn_decode_shared_fused(float* acc32, const void* bias, const float* cos_t, const float* sin_t, const float* rowss,
-                                    float* rowss_zero, int norm_cols, float eps, const void* prefix_k, const void* prefix_v,
-                                    const int* prefix_len, const int* prompt_of, const int* row0, void* tail_k, void* tail_v,
-                                    const int* tail_len_dev, void* o, void* workspace, int B, int n_prompts, int Kmax, int Pmax, int Cmax,
-                                    int Hq, int Hkv, int D, float scale, spacer_stream_t stream);
 
 /* Decode-step helpers (all read the step / tail length from device memory so that one decode step can be
  * captured in a hipGraph and replayed):

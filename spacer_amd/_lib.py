@@ -68,7 +68,6 @@ SIGNATURES = {
     "spacer_attn_decode": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p],
     "spacer_attn_decode_shared": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p],
     "spacer_attn_decode_shared_rows": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p],
-    "spacer_attn_decode_shared_fused": [_p, _p, _p, _p, _p, _p, _i, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p],
     "spacer_swiglu_fwd": [_p, _p, _i, _i, _p],
     "spacer_swiglu_bwd": [_p, _p, _p, _i, _i, _p],
     "spacer_act_fwd": [_p, _p, _l, _i, _p],

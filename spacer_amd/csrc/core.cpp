@@ -14,4 +14,4 @@ void spacer_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* spacer_last_error(void) { return g_err; }
-extern "C" int spacer_version(void) { return 108; }   // 1.08: round 6 (spacer_gather_f32 / spacer_scatter_f32 / spacer_eos_schedule: EOS-trimmed scoring; spacer_attn_decode_shared_rows; spacer_attn_decode_shared_fused)
+extern "C" int spacer_version(void) { return 107; }   // 1.07: round 6 (spacer_gather_f32 / spacer_scatter_f32 / spacer_eos_schedule: EOS-trimmed scoring; spacer_attn_decode_shared_rows)

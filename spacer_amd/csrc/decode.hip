@@ -424,77 +424,6 @@ __global__ __launch_bounds__(256) void swiglu_f32_kernel(float* __restrict__ acc
 // attention: ~24 GB/s per CU, so re-reading the prompt in all 8 rollouts' workgroups costs 8x the time).
 constexpr int PRE_SPLITS = 8;
 
-// FUSED forms of the split / merge launches (round 6): the q|k|v finishing step without its launch.  The split kernel takes its query
-// fragments straight from the projection's fp32 split-K sums (x rstd, + bias, rotary -- decode_qkv_finish_kernel's arithmetic, per lane
-// for the 4 x 8 head dims its MFMA operand holds; the rotary partner d +- 64 is dc ^ 2 of the same lane), the (sequence, kv head) workgroups
-// form the NEW token's key and value the same way, use them from registers for the keys >= total - 1 of their last tile and append them to
-// the tail cache for the later steps; the merge launch, which runs after every reader, re-zeroes the sums and clears the next layer's row
-// sums.  No hand-off inside a launch: every workgroup recomputes what it needs (<= 32 KB of reads).
-struct QkvFin {
-    float* acc;             // [B, (Hq + 2 Hkv) * 128] fp32 sums of the q|k|v projection (re-zeroed by the merge launch)
-    const bf16_t* bias;     // [(Hq + 2 Hkv) * 128] or nullptr
-    const float* cs;        // [B, 128]
-    const float* sn;
-    const float* rowss;     // [B] sums of x^2 (norm-folded projection) or nullptr
-    float* rowss_zero;      // [B] cleared by the merge launch, or nullptr
-    bf16_t* tk;             // writable tail cache
-    bf16_t* tv;
-    int norm_cols;
-    float eps;
-};
-
-// the fragment (dims dc * 32 + g * 8 .. + 8, dc = 0..3) of head `head` of row b; `on` = false: zeros (address clamped by the caller)
-template <bool ROPE>
-__device__ __forceinline__ void qkv_head_frag(const QkvFin& f, int b, int head, int heads, int g, bool on, bf16x8 (&out)[4]) {
-    const float* a = f.acc + ((long)b * heads + head) * 128 + g * 8;
-    const bf16_t* bp = f.bias ? f.bias + (long)head * 128 + g * 8 : (const bf16_t*)f.cs;
-    const float* rp = f.rowss ? f.rowss + b : f.cs;
-    const float* cp = f.cs + (long)b * 128 + g * 8;
-    const float* sp = f.sn + (long)b * 128 + g * 8;
-    // every load before the first use
-    float4 av[4][2], cv[2][2], sv[2][2];
-    uint4 bv[4];
-    const float rsum = *rp;
-#pragma unroll
-    for (int dc = 0; dc < 4; ++dc) {
-        av[dc][0] = *(const float4*)(a + dc * 32); av[dc][1] = *(const float4*)(a + dc * 32 + 4);
-        bv[dc] = *(const uint4*)(bp + (f.bias ? dc * 32 : 0));
-        if (ROPE && dc < 2) {                          // the tables' halves are equal (HF: emb = cat(freqs, freqs)): dims d and d + 64 share
-            cv[dc][0] = *(const float4*)(cp + dc * 32); cv[dc][1] = *(const float4*)(cp + dc * 32 + 4);
-            sv[dc][0] = *(const float4*)(sp + dc * 32); sv[dc][1] = *(const float4*)(sp + dc * 32 + 4);
-        }
-    }
-    const float rs = f.rowss ? rsqrtf(rsum / (float)f.norm_cols + f.eps) : 1.f;
-    const float bias_on = f.bias ? 1.f : 0.f;
-    float x[4][8];
-#pragma unroll
-    for (int dc = 0; dc < 4; ++dc) {
-        const float ae[8] = {av[dc][0].x, av[dc][0].y, av[dc][0].z, av[dc][0].w, av[dc][1].x, av[dc][1].y, av[dc][1].z, av[dc][1].w};
-        const uint32_t be[4] = {bv[dc].x, bv[dc].y, bv[dc].z, bv[dc].w};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) x[dc][e] = ae[e] * rs + bias_on * __uint_as_float((e & 1) ? (be[e >> 1] & 0xffff0000u) : (be[e >> 1] << 16));
-    }
-    if (ROPE) {
-#pragma unroll
-        for (int dc = 0; dc < 2; ++dc) {
-            const float c1[8] = {cv[dc][0].x, cv[dc][0].y, cv[dc][0].z, cv[dc][0].w, cv[dc][1].x, cv[dc][1].y, cv[dc][1].z, cv[dc][1].w};
-            const float s1[8] = {sv[dc][0].x, sv[dc][0].y, sv[dc][0].z, sv[dc][0].w, sv[dc][1].x, sv[dc][1].y, sv[dc][1].z, sv[dc][1].w};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float x1 = x[dc][e], x2 = x[dc + 2][e];                 // dims d and d + 64
-                x[dc][e] = x1 * c1[e] - x2 * s1[e];
-                x[dc + 2][e] = x2 * c1[e] + x1 * s1[e];
-            }
-        }
-    }
-#pragma unroll
-    for (int dc = 0; dc < 4; ++dc) {
-        uint4 t = make_uint4(pack_bf2(x[dc][0], x[dc][1]), pack_bf2(x[dc][2], x[dc][3]), pack_bf2(x[dc][4], x[dc][5]), pack_bf2(x[dc][6], x[dc][7]));
-        if (!on) t = make_uint4(0, 0, 0, 0);
-        out[dc] = __builtin_bit_cast(bf16x8, t);
-    }
-}
-
 
 // =============================================================================== decode attention (MFMA)
 // Workgroup = (sequence b, kv head); the REP q-heads of the GQA group are the MFMA's 16-wide N dimension (zero
@@ -662,14 +591,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 4) ? 2 : 1) void attn_decode_mfma_k
 // Before: prefix kernel -> tail kernel (which also merged) = two latency-bound launches in series, 21.5 us per layer at an
 // empty tail.  V tiles are staged row-major and read through the transposing LDS read (frag_tr) in both roles; role A keeps
 // two K/V tiles in flight in registers.
-template <int REP, bool FUSED = false>
+template <int REP>
 __global__ __launch_bounds__(256, 2) void attn_decode_split_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ pk,
                                                                    const bf16_t* __restrict__ pv, const int* __restrict__ plen,
                                                                    const bf16_t* __restrict__ tk, const bf16_t* __restrict__ tv,
                                                                    const int* __restrict__ tail_len, float* __restrict__ pre,
                                                                    float* __restrict__ tailp, int n_prefix_blocks, int Kn, int Pmax,
-                                                                   int Cmax, int Hq, int Hkv, float scale, const int* __restrict__ row0,
-                                                                   QkvFin fin = QkvFin{}) {
+                                                                   int Cmax, int Hq, int Hkv, float scale, const int* __restrict__ row0) {
     // row0 != nullptr (round 6): prompt pr owns the rows [row0[pr], row0[pr + 1]) -- per-prompt rollout counts (the T-GRPO twins take
     // G / 2 rollouts, TR:473); nullptr: the uniform layout, prompt pr owns rows [pr Kn, (pr + 1) Kn)
     constexpr int D = 128, DC = 4, DF = 8;
@@ -748,32 +676,20 @@ __global__ __launch_bounds__(256, 2) void attn_decode_split_kernel(const bf16_t*
             }
             softmax_pv(st, t * 64, P, v_lds);
         };
-        if (FUSED) {
-            // the tile requests first: the fragment needs its loads back before it can be formed, and behind it the requests would be a
-            // second round trip (in-order vmcnt: waiting for the sums also waits for the tiles, which the first MFMA needs anyway)
-            if (t0 < t1) fetch(ka, va, t0);
-            if (t0 + 1 < t1) fetch(kb, vb, t0 + 1);
-        }
         {   // q fragments first, then the tile requests (in-order vmcnt: the first tile does not wait for the later ones)
             const int kr = col_ok ? col / REP : 0, hr = col_ok ? col % REP : 0;
-            if (FUSED) {
-                qkv_head_frag<true>(fin, r0 + kr, hk * REP + hr, Hq + 2 * Hkv, g, col_ok, qf);
-            } else {
-                const bf16_t* qp = q + ((long)(r0 + kr) * Hq + hk * REP + hr) * D;
+            const bf16_t* qp = q + ((long)(r0 + kr) * Hq + hk * REP + hr) * D;
 #pragma unroll
-                for (int dc = 0; dc < DC; ++dc) {
-                    uint4 t = make_uint4(0, 0, 0, 0);
-                    if (col_ok) t = *(const uint4*)(qp + dc * 32 + g * 8);
-                    qf[dc] = __builtin_bit_cast(bf16x8, t);
-                }
+            for (int dc = 0; dc < DC; ++dc) {
+                uint4 t = make_uint4(0, 0, 0, 0);
+                if (col_ok) t = *(const uint4*)(qp + dc * 32 + g * 8);
+                qf[dc] = __builtin_bit_cast(bf16x8, t);
             }
         }
         // (a third register set with all of a split's 3 tiles in flight at once: 16.3 vs 17.4 us per layer in the standalone
         // probe, 18.0 vs 16.7 us inside the decode step -- measured with rocprof in one process; not kept)
-        if (!FUSED) {
-            if (t0 < t1) fetch(ka, va, t0);
-            if (t0 + 1 < t1) fetch(kb, vb, t0 + 1);
-        }
+        if (t0 < t1) fetch(ka, va, t0);
+        if (t0 + 1 < t1) fetch(kb, vb, t0 + 1);
         for (int t = t0; t < t1; t += 2) {
             step(ka, va, t);
             if (t + 1 < t1) step(kb, vb, t + 1);
@@ -793,31 +709,8 @@ __global__ __launch_bounds__(256, 2) void attn_decode_split_kernel(const bf16_t*
     const int b = bi / Hkv, hk = bi % Hkv;
     const int total = *tail_len + 1;
     char* v_img = smem + wave * AT_RM_BYTES;
-    bf16x8 qf[DC], knew[FUSED ? DC : 1];
-    uint4 vnew = make_uint4(0, 0, 0, 0);
-    if constexpr (FUSED) {
-        const int heads = Hq + 2 * Hkv;
-        // the new token's value, dims l15 * 8 .. + 8 (the chunk this lane stages of every V row): loads first, like the fragments below
-        const float* va = fin.acc + ((long)b * heads + Hq + Hkv + hk) * D + l15 * 8;
-        const float4 v0 = *(const float4*)va, v1 = *(const float4*)(va + 4);
-        const uint4 vb = *(const uint4*)(fin.bias ? fin.bias + (long)(Hq + Hkv + hk) * D + l15 * 8 : (const bf16_t*)fin.cs);
-        const float rsum = *(fin.rowss ? fin.rowss + b : fin.cs);
-        qkv_head_frag<true>(fin, b, hk * REP + min(l15, REP - 1), heads, g, l15 < REP, qf);
-        qkv_head_frag<true>(fin, b, Hq + hk, heads, g, true, knew);
-        const float rs = fin.rowss ? rsqrtf(rsum / (float)fin.norm_cols + fin.eps) : 1.f, bon = fin.bias ? 1.f : 0.f;
-        vnew = make_uint4(pack_bf2(v0.x * rs + bon * __uint_as_float(vb.x << 16), v0.y * rs + bon * __uint_as_float(vb.x & 0xffff0000u)),
-                          pack_bf2(v0.z * rs + bon * __uint_as_float(vb.y << 16), v0.w * rs + bon * __uint_as_float(vb.y & 0xffff0000u)),
-                          pack_bf2(v1.x * rs + bon * __uint_as_float(vb.z << 16), v1.y * rs + bon * __uint_as_float(vb.z & 0xffff0000u)),
-                          pack_bf2(v1.z * rs + bon * __uint_as_float(vb.w << 16), v1.w * rs + bon * __uint_as_float(vb.w & 0xffff0000u)));
-        if (wave == 0) {                                // append to the tail cache for the later steps (this launch uses the registers)
-            const long slot = (((long)b * Cmax + (total - 1)) * Hkv + hk) * D;
-            if (l15 == 0) {
-#pragma unroll
-                for (int dc = 0; dc < DC; ++dc) *(uint4*)(fin.tk + slot + dc * 32 + g * 8) = __builtin_bit_cast(uint4, knew[FUSED ? dc : 0]);
-            }
-            if (g == 0) *(uint4*)(fin.tv + slot + l15 * 8) = vnew;
-        }
-    } else {
+    bf16x8 qf[DC];
+    {
         const bf16_t* qp = q + ((long)b * Hq + hk * REP + min(l15, REP - 1)) * D;
 #pragma unroll
         for (int dc = 0; dc < DC; ++dc) {
@@ -835,20 +728,15 @@ __global__ __launch_bounds__(256, 2) void attn_decode_split_kernel(const bf16_t*
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                vreg[i][j] = *(const uint4*)(key_ptr(tv, k0 + (g + 4 * i) * 4 + j) + l15 * 8);
-                if (FUSED && k0 + (g + 4 * i) * 4 + j >= total - 1) vreg[i][j] = vnew;       // the new token (and the clamped rows behind it)
-            }
+            for (int j = 0; j < 4; ++j) vreg[i][j] = *(const uint4*)(key_ptr(tv, k0 + (g + 4 * i) * 4 + j) + l15 * 8);
         f32x4 st[4];
 #pragma unroll
         for (int kf = 0; kf < 4; ++kf) {
             st[kf] = (f32x4){0.f, 0.f, 0.f, 0.f};
             const bf16_t* kp = key_ptr(tk, k0 + kf * 16 + l15) + g * 8;
-            const bool is_new = FUSED && k0 + kf * 16 + l15 >= total - 1;
 #pragma unroll
             for (int dc = 0; dc < DC; ++dc) {
-                bf16x8 kfr = __builtin_bit_cast(bf16x8, *(const uint4*)(kp + dc * 32));
-                if (is_new) kfr = knew[FUSED ? dc : 0];
+                const bf16x8 kfr = __builtin_bit_cast(bf16x8, *(const uint4*)(kp + dc * 32));
                 st[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[dc], st[kf], 0, 0, 0);
             }
         }
@@ -897,21 +785,12 @@ __global__ __launch_bounds__(256, 2) void attn_decode_split_kernel(const bf16_t*
 // o[b, head, :] = softmax-merge of the PRE_SPLITS prompt partials (column (b - pr*Kn)*REP + qh) and the tail partial.
 // One thread per output element (REP*128 threads), all 3 x (PRE_SPLITS + 1) loads independent of each other: ONE memory round
 // trip (the records were just written from other XCDs); the 256-thread form looped 3.5 outputs per thread, a round trip each.
-template <int REP, bool FUSED = false>
+template <int REP>
 __global__ __launch_bounds__(REP * 128) void attn_decode_merge_kernel(const float* __restrict__ pre, const float* __restrict__ tailp,
                                                                       bf16_t* __restrict__ o, int Kn, int Hq, int Hkv,
-                                                                      const int* __restrict__ prompt_of, const int* __restrict__ row0,
-                                                                      QkvFin fin = QkvFin{}) {
+                                                                      const int* __restrict__ prompt_of, const int* __restrict__ row0) {
     constexpr int D = 128;
     const int b = blockIdx.x, hk = blockIdx.y, pr = row0 ? prompt_of[b] : b / Kn;
-    if (FUSED) {
-        // every reader of the projection's sums has finished (the split launch): re-zero this (row, kv head)'s share of them -- the REP
-        // query heads, the key head and the value head -- for the next layer's split-K atomics, and clear the next layer's row sum
-        float* a = fin.acc + (long)b * (Hq + 2 * Hkv) * D;
-        for (int i = threadIdx.x; i < REP * D; i += REP * 128) a[hk * REP * D + i] = 0.f;
-        if (threadIdx.x < D) { a[(Hq + hk) * D + threadIdx.x] = 0.f; a[(Hq + Hkv + hk) * D + threadIdx.x] = 0.f; }
-        if (fin.rowss_zero && hk == 0 && threadIdx.x == 0) fin.rowss_zero[b] = 0.f;
-    }
     const int qh = threadIdx.x >> 7, d = threadIdx.x & 127;
     const float* tp = tailp + ((long)b * Hkv + hk) * REP * (D + 2) + qh * (D + 2);
     const int col = (b - (row0 ? row0[pr] : pr * Kn)) * REP + qh;
@@ -1266,52 +1145,6 @@ extern "C" int spacer_attn_decode_shared(const void* q, const void* prefix_k, co
     SP_REQUIRE(workspace != nullptr, SPACER_EINVAL, "attn_decode_shared: workspace required");
     return launch_attn_decode(q, prefix_k, prefix_v, prefix_len, prompt_of, tail_k, tail_v, tail_len_dev, o, (float*)workspace, Kn,
                               B, Pmax, Cmax, Hq, Hkv, D, scale, stream);
-}
-
-// The q|k|v finishing step (spacer_decode_qkv_finish / _normed) folded into the shared-prefix decode attention (round 6): the split launch
-// forms rotary(q), rotary(k), v of the step from the projection's fp32 sums itself (no q buffer, no finishing launch), appends k and v to the
-// tail cache, and the merge launch re-zeroes acc32 and clears rowss_zero.  bias / rowss / rowss_zero may be NULL (no bias / projection not
-// norm-folded / nothing to clear); row0 NULL = uniform Kmax rollouts per prompt (B = n_prompts * Kmax).  HF: q/k/v_proj bias + rotary +
-// KV-cache append + attention of one generate step (TR:463).
-extern "C" int spacer_attn_decode_shared_fused(float* acc32, const void* bias, const float* cos_t, const float* sin_t, const float* rowss,
-                                               float* rowss_zero, int norm_cols, float eps, const void* prefix_k, const void* prefix_v,
-                                               const int* prefix_len, const int* prompt_of, const int* row0, void* tail_k, void* tail_v,
-                                               const int* tail_len_dev, void* o, void* workspace, int B, int n_prompts, int Kmax, int Pmax,
-                                               int Cmax, int Hq, int Hkv, int D, float scale, spacer_stream_t stream) {
-    SP_REQUIRE(acc32 && cos_t && sin_t && prefix_k && prefix_v && prefix_len && tail_k && tail_v && tail_len_dev && o && workspace,
-               SPACER_EINVAL, "attn_decode_shared_fused: null operand");
-    SP_REQUIRE(D == 128 && Hkv > 0 && Hq % Hkv == 0, SPACER_EINVAL, "attn_decode_shared_fused: head_dim %d / head counts unsupported", D);
-    SP_REQUIRE(((uintptr_t)acc32 % 16) == 0 && ((uintptr_t)bias % 16) == 0 && ((uintptr_t)cos_t % 16) == 0 && ((uintptr_t)sin_t % 16) == 0,
-               SPACER_EINVAL, "attn_decode_shared_fused: acc32 / bias / cos / sin must be 16-byte aligned");
-    SP_REQUIRE(!rowss || norm_cols > 0, SPACER_EINVAL, "attn_decode_shared_fused: norm_cols missing");
-    if (B <= 0) return SPACER_OK;
-    const int rep = Hq / Hkv;
-    SP_REQUIRE(Kmax > 0 && Kmax * rep <= 64 && n_prompts > 0 && (row0 ? prompt_of != nullptr : B == n_prompts * Kmax), SPACER_EINVAL,
-               "attn_decode_shared_fused: Kmax*rep=%d must be <= 64; uniform batches need B = n_prompts * Kmax, ragged ones prompt_of", Kmax * rep);
-    hipStream_t s = (hipStream_t)stream;
-    const int nA = n_prompts * Hkv * PRE_SPLITS;
-    float* pre_ws = (float*)workspace;
-    float* tailp = pre_ws + (long)n_prompts * Hkv * PRE_SPLITS * 64 * (128 + 2);
-    QkvFin fin{acc32, (const bf16_t*)bias, cos_t, sin_t, rowss, rowss_zero, (bf16_t*)tail_k, (bf16_t*)tail_v, norm_cols, eps};
-#define LAUNCH_FUSED(R)                                                                                                  \
-    {                                                                                                                    \
-        static const int once = hipFuncSetAttribute((const void*)attn_decode_split_kernel<R, true>,                      \
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 4 * AT_RM_BYTES);        \
-        (void)once;                                                                                                      \
-        hipLaunchKernelGGL((attn_decode_split_kernel<R, true>), dim3(nA + B * Hkv), dim3(256), 4 * AT_RM_BYTES, s, (const bf16_t*)nullptr, \
-                           (const bf16_t*)prefix_k, (const bf16_t*)prefix_v, prefix_len, (const bf16_t*)tail_k,          \
-                           (const bf16_t*)tail_v, tail_len_dev, pre_ws, tailp, nA, Kmax, Pmax, Cmax, Hq, Hkv, scale, row0, fin); \
-        hipLaunchKernelGGL((attn_decode_merge_kernel<R, true>), dim3(B, Hkv), dim3(R * 128), 0, s, (const float*)pre_ws,  \
-                           (const float*)tailp, (bf16_t*)o, Kmax, Hq, Hkv, prompt_of, row0, fin);                        \
-    }
-    switch (rep) {
-        case 1: LAUNCH_FUSED(1); break; case 2: LAUNCH_FUSED(2); break; case 3: LAUNCH_FUSED(3); break; case 4: LAUNCH_FUSED(4); break;
-        case 5: LAUNCH_FUSED(5); break; case 6: LAUNCH_FUSED(6); break; case 7: LAUNCH_FUSED(7); break; case 8: LAUNCH_FUSED(8); break;
-        default: SP_REQUIRE(false, SPACER_EINVAL, "attn_decode_shared_fused: GQA ratio %d not instantiated", rep);
-    }
-#undef LAUNCH_FUSED
-    SP_CHECK_LAUNCH();
-    return SPACER_OK;
 }
 
 // Per-prompt rollout counts (round 6): prompt p owns the decode rows [row0[p], row0[p + 1]) (row0 int32 [n_prompts + 1], device), at most

@@ -455,26 +455,6 @@ def attn_decode_shared_rows(q, prefix_k, prefix_v, prefix_len, prompt_of, row0, 
     return out
 
 
-def attn_decode_shared_fused(acc32, bias, cos, sin, rowss, rowss_zero, norm_cols, eps, prefix_k, prefix_v, prefix_len, prompt_of, row0,
-                             tail_k, tail_v, tail_len_dev, Kmax, Hq, Hkv, D, scale, *, out=None, workspace=None):
-    """decode_qkv_finish(_normed) + attn_decode_shared(_rows) as the attention's two launches: q / k / v of the step are formed from the
-    projection's fp32 sums ``acc32`` [B, (Hq + 2 Hkv) D] inside the split launch (x rstd from ``rowss`` when given, + ``bias``, rotary),
-    k / v appended to the tail cache, ``acc32`` re-zeroed and ``rowss_zero`` cleared by the merge launch.  ``row0`` None: Kmax rollouts
-    per prompt."""
-    B, nP = acc32.shape[0], prefix_k.shape[0]
-    assert acc32.dtype == torch.float32 and acc32.shape[1] == (Hq + 2 * Hkv) * D and acc32.is_contiguous()
-    assert row0 is None or (row0.dtype == torch.int32 and row0.numel() == nP + 1 and prompt_of.numel() == B)
-    if out is None:
-        out = torch.empty(B, Hq * D, device=acc32.device, dtype=BF16)
-    if workspace is None:
-        workspace = torch.empty(_lib.load().spacer_attn_decode_workspace_bytes(nP, Hkv) // 4, device=acc32.device, dtype=torch.float32)
-    check(_lib.load().spacer_attn_decode_shared_fused(_ptr(acc32), _ptr(bias), _ptr(cos), _ptr(sin), _ptr(rowss), _ptr(rowss_zero), norm_cols, eps,
-                                                      _ptr(prefix_k), _ptr(prefix_v), _ptr(prefix_len), _ptr(prompt_of), _ptr(row0), _ptr(tail_k),
-                                                      _ptr(tail_v), _ptr(tail_len_dev), _ptr(out), _ptr(workspace), B, nP, Kmax, prefix_k.shape[1],
-                                                      tail_k.shape[1], Hq, Hkv, D, scale, _stream()), "attn_decode_shared_fused")
-    return out
-
-
 # ----------------------------------------------------------------------------------------- element-wise
 def swiglu_fwd(gu, *, out=None):
     rows, two_i = gu.shape

@@ -32,10 +32,6 @@ DECODE_NORM_FOLD = os.environ.get("SPACER_DECODE_NORM", "fold") != "separate"   
 # (measured slower at 8 rows: 3.69 vs 3.28 ms per token-step -- each rollout's workgroup re-reads the prompt's keys).
 _SMALL = set(filter(None, os.environ.get("SPACER_DECODE_SMALL", "fold").split(",")))
 DECODE_SMALL_FOLD, DECODE_SMALL_ATTN1 = "fold" in _SMALL, "attn1" in _SMALL
-# shared-prefix decode attention with the q|k|v finishing step folded in (round 6): the split launch forms rotary(q), rotary(k), v from the
-# projection's fp32 sums itself, the merge launch re-zeroes them -- one launch less per layer.  SPACER_DECODE_QKV=separate keeps the
-# finishing launch (A/B).
-DECODE_QKV_FUSED = os.environ.get("SPACER_DECODE_QKV", "fused") != "separate"
 # the sampler's wide form (several workgroups per row for the two passes over the logits; same tokens): SPACER_SAMPLER=narrow keeps one
 # workgroup per row (A/B)
 SAMPLER_WIDE = os.environ.get("SPACER_SAMPLER", "wide") != "narrow"
@@ -98,7 +94,6 @@ class RolloutEngine:
         # would clear what it reads, so it keeps the separate norm launch)
         self.fold_norm = DECODE_NORM_FOLD and engine.cfg.layers >= 2
         self.small_fold = DECODE_SMALL_FOLD and engine.cfg.hidden % 256 == 0
-        self.qkv_fused = DECODE_QKV_FUSED and engine.cfg.head_dim == 128
         # keep the prefill's tape (ViT + prompt rows of every layer) for the policy's scoring pass: None = when it fits (the tape must
         # live through the decode loop beside the training state: ~100 GB for 8 cfg3 groups at 7B -- no; 12 GB for cfg2 at 2B -- yes),
         # True / False = forced.  Only the stored (non-recompute) policy of the Qwen2-VL tower is eligible.
@@ -228,28 +223,19 @@ class RolloutEngine:
         scale = D ** -0.5
         for i in range(cfg.layers):
             p = f"llm.{i}."
-            fused = self.qkv_fused and st["shared_prefix"]     # the finishing step rides on the attention's split launch
             if self.fold_norm and B <= 64:
                 # norm(x) Wqkv^T = rstd * (bf16(x) (W diag(w))^T): the GEMM stages the fp32 stream and sums x^2 per row, the
-                # finishing step applies rstd (and clears the next layer's row sums)
+                # finishing kernel applies rstd (and clears the next layer's row sums)
                 rs = st["rowss"]
                 K.gemm_skinny_packed_normed(x, PW[p + "qkv_wn"], st["acc_qkv"], rs[i], cfg.qkv_dim)
-                if not fused:
-                    K.decode_qkv_finish_normed(st["acc_qkv"], W[p + "qkv_b"], st["cos"], st["sin"], st["q"], st["tk"][i], st["tv"][i],
-                                               st["tail_len"], rs[i], rs[(i + 1) % cfg.layers], cfg.hidden, cfg.rms_eps, Hq, Hkv, D)
-                rs_i, rs_next = rs[i], rs[(i + 1) % cfg.layers]
+                K.decode_qkv_finish_normed(st["acc_qkv"], W[p + "qkv_b"], st["cos"], st["sin"], st["q"], st["tk"][i], st["tv"][i],
+                                           st["tail_len"], rs[i], rs[(i + 1) % cfg.layers], cfg.hidden, cfg.rms_eps, Hq, Hkv, D)
             else:
                 h = K.rmsnorm_fwd(x, W[p + "ln1_w"], cfg.rms_eps, out=st["h"])
                 K.gemm_skinny_packed_acc(h, PW[p + "qkv_w"], st["acc_qkv"], cfg.qkv_dim)
-                if not fused:
-                    K.decode_qkv_finish(st["acc_qkv"], W[p + "qkv_b"], st["cos"], st["sin"], st["q"], st["tk"][i], st["tv"][i],
-                                        st["tail_len"], Hq, Hkv, D)
-                rs_i = rs_next = None
-            if fused:
-                o = K.attn_decode_shared_fused(st["acc_qkv"], W[p + "qkv_b"], st["cos"], st["sin"], rs_i, rs_next, cfg.hidden, cfg.rms_eps,
-                                               st["pk"][i], st["pv"][i], st["plen"], st["prompt_of"], st["row0"], st["tk"][i], st["tv"][i],
-                                               st["tail_len"], st["Kn"], Hq, Hkv, D, scale, out=st["o"], workspace=st["attn_ws"])
-            elif st["shared_prefix"] and st["row0"] is not None:      # ... with per-prompt rollout counts (the T-GRPO twins: G / 2)
+                K.decode_qkv_finish(st["acc_qkv"], W[p + "qkv_b"], st["cos"], st["sin"], st["q"], st["tk"][i], st["tv"][i],
+                                    st["tail_len"], Hq, Hkv, D)
+            if st["shared_prefix"] and st["row0"] is not None:      # ... with per-prompt rollout counts (the T-GRPO twins: G / 2)
                 o = K.attn_decode_shared_rows(st["q"], st["pk"][i], st["pv"][i], st["plen"], st["prompt_of"], st["row0"], st["tk"][i],
                                               st["tv"][i], st["tail_len"], st["Kn"], Hq, Hkv, D, scale, out=st["o"], workspace=st["attn_ws"])
             elif st["shared_prefix"]:      # prompt keys scored once per prompt for its K rollouts

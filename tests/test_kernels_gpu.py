@@ -470,63 +470,6 @@ def test_attention_decode_shared_prefix(dev):
             assert_close(o[b], want, 2e-2, 2e-2, f"shared decode attn b={b} tl={tl}")
 
 
-@pytest.mark.parametrize("Hq,Hkv,counts,normed,with_bias", [(28, 4, [8] * 3, True, True), (12, 2, [8, 4, 8, 4], True, True), (2, 1, [3, 3], False, True),
-                                                            (14, 2, [4, 1, 2], False, False), (6, 1, [10], True, False)])
-def test_attention_decode_with_the_qkv_finishing_step_folded_in(dev, Hq, Hkv, counts, normed, with_bias):
-    """spacer_attn_decode_shared_fused == spacer_decode_qkv_finish(_normed) followed by spacer_attn_decode_shared(_rows): the attention
-    output, the key / value appended to the tail cache (to one bf16 ulp: the same arithmetic, contracted differently by the compiler), the
-    re-zeroed sums and the cleared row sums; uniform and per-prompt rollout counts, with and without bias / folded norm; tail lengths that
-    put the new token first in a tile, last in a tile and behind a full tile."""
-    D, nP, Pmax, Cmax = 128, len(counts), 150, 140
-    B, Kmax, heads = sum(counts), max(counts), Hq + 2 * Hkv
-    uniform = len(set(counts)) == 1
-    g = torch.Generator(device="cpu").manual_seed(5)
-    acc0 = (torch.randn(B, heads * D, generator=g) * (3.0 if normed else 0.8)).to(dev)
-    bias = rnd((heads * D,), dev, 6, 0.3) if with_bias else None
-    ang = torch.rand(B, D // 2, generator=g) * 6.28
-    cos, sin = torch.cat([ang.cos(), ang.cos()], 1).to(dev).contiguous(), torch.cat([ang.sin(), ang.sin()], 1).to(dev).contiguous()
-    rowss = (torch.rand(B, generator=g) * 4000 + 500).to(dev) if normed else None
-    pk, pv = rnd((nP, Pmax, Hkv, D), dev, 2, 0.7), rnd((nP, Pmax, Hkv, D), dev, 3, 0.7)
-    plen = torch.tensor(([150, 64, 7, 129] * 2)[:nP], dtype=torch.int32, device=dev)
-    pof = torch.repeat_interleave(torch.arange(nP), torch.tensor(counts)).int().to(dev)
-    row0 = None if uniform else torch.tensor([sum(counts[:i]) for i in range(nP + 1)], dtype=torch.int32, device=dev)
-    tk0, tv0 = rnd((B, Cmax, Hkv, D), dev, 4, 0.7), rnd((B, Cmax, Hkv, D), dev, 5, 0.7)
-    for tl in (0, 5, 63, 64, 127, 130):
-        tld = torch.tensor([tl], dtype=torch.int32, device=dev)
-        # two launches + finishing launch
-        acc_a, tk_a, tv_a = acc0.clone(), tk0.clone(), tv0.clone()
-        q = torch.empty(B, Hq * D, device=dev, dtype=BF)
-        zero_a = torch.ones(B, device=dev)
-        if normed:
-            K.decode_qkv_finish_normed(acc_a, bias, cos, sin, q, tk_a, tv_a, tld, rowss, zero_a, 3584, 1e-6, Hq, Hkv, D)
-        else:
-            K.decode_qkv_finish(acc_a, bias, cos, sin, q, tk_a, tv_a, tld, Hq, Hkv, D)
-        if uniform:
-            o_a = K.attn_decode_shared(q, pk, pv, plen, pof, tk_a, tv_a, tld, Kmax, Hq, Hkv, D, D ** -0.5)
-        else:
-            o_a = K.attn_decode_shared_rows(q, pk, pv, plen, pof, row0, tk_a, tv_a, tld, Kmax, Hq, Hkv, D, D ** -0.5)
-        # folded
-        acc_b, tk_b, tv_b = acc0.clone(), tk0.clone(), tv0.clone()
-        zero_b = torch.ones(B, device=dev)
-        o_b = K.attn_decode_shared_fused(acc_b, bias, cos, sin, rowss, zero_b if normed else None, 3584, 1e-6, pk, pv, plen, pof, row0, tk_b, tv_b,
-                                         tld, Kmax, Hq, Hkv, D, D ** -0.5)
-        torch.cuda.synchronize()
-        assert float(acc_b.abs().max()) == 0.0 and float(acc_a.abs().max()) == 0.0
-        if normed:
-            assert float(zero_b.abs().max()) == 0.0
-        # only slot tl of the tail cache changed, and it holds the finishing launch's key / value to one bf16 ulp
-        keep = torch.ones(Cmax, dtype=torch.bool, device=dev); keep[tl] = False
-        assert torch.equal(tk_b[:, keep], tk0[:, keep]) and torch.equal(tv_b[:, keep], tv0[:, keep])
-        for nm, a, b in (("k", tk_a[:, tl], tk_b[:, tl]), ("v", tv_a[:, tl], tv_b[:, tl])):
-            assert_close(b, a.float(), 1e-6, 2.0 ** -7, f"appended {nm} (tl {tl})")
-            assert float((a != b).float().mean()) < 0.02, (nm, tl, float((a != b).float().mean()))
-        assert_close(o_b, o_a.float(), 4e-3, 1e-2, f"attention output, folded vs three launches (tl {tl})")
-    with pytest.raises(K.SpacerError):
-        cos_off = torch.zeros(B * D + 4, device=dev)[1:1 + B * D].view(B, D)           # 4 bytes off a 16-byte boundary
-        K.attn_decode_shared_fused(acc0.clone(), bias, cos_off, sin, rowss, None, 3584, 1e-6, pk, pv, plen, pof, row0, tk0, tv0, tld, Kmax, Hq, Hkv,
-                                   D, D ** -0.5)
-
-
 def test_decode_qkv_projection_with_folded_rmsnorm(dev):
     """gemm_skinny_packed_normed + decode_qkv_finish_normed (RMSNorm folded into the K-split decode projection:
     rstd * (bf16(x) (W diag(w))^T)) against fp32 torch for norm(x) W^T + b with rotary, and against the three-launch path
