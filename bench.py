@@ -292,7 +292,7 @@ def skinny_roofline(ge, cfg, dev, rows: int, step_seconds: float, launches_per_s
             "frac": round(gbps / 8000.0, 4), "avg_launch_us": round(us, 2), "launches_timed": len(ev),
             "algorithmic_bytes_per_launch": round(algo), "rows": rows,
             "traffic": 275.4e6 if (I, H) == (18944, 3584) else None,
-            "traffic_source": "profiles/r04_decode_pmc.md (rocprofv3 --pmc FETCH_SIZE x 2 KiB units over eager decode steps: 275.4 MB read per launch)",
+            "traffic_source": "profiles/r06_decode_pmc.md (rocprofv3 --pmc FETCH_SIZE x 2 KiB units over eager decode steps on the final round-6 tree: 275.4 MB read per launch; the same figure as profiles/r04_decode_pmc.md)",
             "share_of_step": round(us * 1e-6 * launches_per_step / step_seconds, 3),
             "how": "eager replay of the decode step's 28 gate|up launches after the timed region, HIP event pair per launch on the launch "
                    "stream; in the timed region the same launches run from the decode hipGraph (rocprof average of that: profiles/)"}
