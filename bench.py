@@ -478,6 +478,8 @@ def main():
             from dataclasses import replace as _replace
             sp = _replace(sp, seed=sp.seed + 7919 * step_idx)
         prompts = [make_prompt(cfg, rank * groups + g, F, Hpx, Wpx, n_text, dev, frames_u8=frames[g])[0] for g in range(groups)]
+        gpp = max(1, min(groups_per_pass or gpp_default, groups))
+        ge.roll.prefill_pass_size = gpp           # a partly kept prefill tape is kept in whole scoring passes (RolloutEngine._tape_keep_count)
         scomp = None
         if temporal:                              # the shuffled twin: same text, temporally permuted frames
             sprompts = []
@@ -503,7 +505,6 @@ def main():
             lens_g = torch.full((Kgen,), cg.shape[1]) if sp.suppress_eos else K.completion_mask(cg, cfg.eos_token_id)[1].cpu()
             rewards = length_bonus(rewards, rpf, lens_g, hyper.len_control)
             advs.append(group_advantages(rewards, Kgen)[0])
-        gpp = max(1, min(groups_per_pass or gpp_default, groups))
         for g0 in range(0, groups, gpp):
             gs = list(range(g0, min(groups, g0 + gpp)))
             # the rank's last backward of the step hands finished layer ranges to the data-parallel reducer (overlap_comm)

@@ -336,6 +336,8 @@ class SGRLVRTrainer:
     def _generate(self, prompts: List[PromptInput], n, sp: SamplingParams) -> torch.Tensor:
         """TR:463-481: n sampled completions per prompt (an int, or one count per prompt: the shuffled twins take G // 2, TR:473),
         int64 [sum of counts, C].  The rollout-server trainer overrides this."""
+        # (a prefill tape that does not fit whole is kept for the first scoring passes' prompts, in whole passes: RolloutEngine._tape_keep_count)
+        self.engine.roll.prefill_pass_size = self.groups_per_pass
         return self.engine.roll.generate(prompts, n, sp, use_graph=self.args.use_decode_graph)
 
     # ------------------------------------------------------------------ the step (TR:384-686)

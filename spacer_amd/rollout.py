@@ -100,7 +100,10 @@ class RolloutEngine:
         # (may also be a callable returning one of those, evaluated per generate call: GRPOEngine ties it to its live hyper-parameters)
         self.keep_prefill_tape = False
         self.prefill_tape_bytes = 0
-        self.static_bytes = 0            # bytes that live beside the tape for the whole step (GRPOEngine: the training state); see _tape_fits
+        # prompts per scoring pass of the caller (GRPOEngine.score_and_backward_multi takes groups_per_pass prompts): when the whole tape
+        # does not fit, the auto decision keeps the tape of the FIRST passes' prompts only, in whole passes (round 6; see _tape_keep_count)
+        self.prefill_pass_size = 1
+        self.static_bytes = 0            # bytes that live beside the tape for the whole step (GRPOEngine: the training state); see _tape_keep_count
         self._fit_logged = set()
 
     # ------------------------------------------------------------------ decode-layout weights
@@ -132,45 +135,72 @@ class RolloutEngine:
         return PW
 
     # ------------------------------------------------------------------ prefill
-    def _tape_fits(self, prompts: List[PromptInput]) -> bool:
-        """Would the prefill tape of these prompts fit beside what is allocated now, with room for the scoring passes' own tapes?
-        Estimate: bytes per token and decoder layer of llm_forward's tape + bytes per patch and vision block of vit_forward's."""
+    def _tape_keep_count(self, prompts: List[PromptInput], counts: Optional[Sequence[int]] = None, C: int = 0) -> int:
+        """How many of these prompts (counted from the front, in whole scoring passes) keep their prefill tape for the policy's scoring
+        pass?  ``counts`` / ``C``: rollouts per prompt and tokens per rollout of this generate call (the size of the scoring passes to
+        come).  Estimate: bytes per token and decoder layer of llm_forward's tape + bytes per patch and vision block of vit_forward's.
+        STATIC sizes only (a decision taken from the allocator's free memory at call time made the numerics of a run depend
+        on what happened to be allocated -- the reuse pass equals the full pass bit for bit only under one GEMM summation order): the
+        device's memory minus what lives beside the tape for the whole step.
+          * all of them when the whole tape is small: 4 x tape < memory beside the training state, tape < 15 % of the device (the scoring
+            passes that follow need ~ (K C / P + 1) x the tape of their groups on top of it) -- cfg2, cfg4;
+          * else (round 6) the first pass's prompts -- their tape BECOMES that pass's prompt-side tape, which the pass would allocate
+            anyway: nothing is added to the step's peak -- and further whole passes while the part that idles beside the earlier
+            passes' activations fits: training state + the largest pass's own tape (rectangular: every rollout C tokens) + idle tape
+            + 8 % of the device <= the device; the kept tape under 20 % of the device.  cfg3 at 7B (8 prompts x 12.9 GB, two per pass,
+            C = 512): 4 prompts = 52 GB kept, 26 GB of it idle during pass 0 -- measured HBM peak 237.5 -> 277.3 GB of 309, step 5029 ->
+            4903 ms on one box; at the shipped script's C = 1024 with two groups per pass only the first pass's prompts qualify."""
         cfg = self.cfg
         per_tok = cfg.layers * (2 * 4 * cfg.hidden + 2 * (2 * cfg.hidden + cfg.qkv_dim + cfg.heads * cfg.head_dim + 3 * cfg.intermediate) + 8 + 4 * cfg.heads)
         per_patch = cfg.vit_depth * (2 * 4 * cfg.vit_dim + 2 * (6 * cfg.vit_dim + 2 * cfg.vit_mlp) + 16 + 4 * cfg.vit_heads)
-        toks = sum(p.ids.numel() for p in prompts)
-        patches = sum(p.pix.shape[0] for p in prompts if p.pix is not None)
-        need = toks * per_tok + patches * per_patch
-        self.prefill_tape_bytes = need
-        # STATIC sizes only (ADVICE r5: a decision taken from the allocator's free memory at call time made the numerics of a run depend
-        # on what happened to be allocated -- the reuse pass equals the full pass bit for bit only under one GEMM summation order): the
-        # device's memory minus what lives beside the tape for the whole step.  The scoring passes that follow need ~ (K C / P + 1) x
-        # the tape of their groups on top of it; keep a third of the part free
+        patches = [p.pix.shape[0] if p.pix is not None else 0 for p in prompts]
+        per = [p.ids.numel() * per_tok + n * per_patch for p, n in zip(prompts, patches)]
         total = torch.cuda.get_device_properties(self.dev).total_memory
         avail = total - self.static_bytes
-        fits = need * 4 < avail and need < 0.15 * total
-        key = (toks, patches, fits)
+        nP, g = len(prompts), max(1, int(self.prefill_pass_size))
+        n = 0
+        if sum(per) * 4 < avail and sum(per) < 0.15 * total:
+            n = nP
+        else:
+            counts = list(counts) if counts is not None else [1] * nP
+            pass_dyn = max(sum(per[a:a + g]) + sum(counts[a:a + g]) * C * per_tok for a in range(0, nP, g))
+            idle_budget = total - self.static_bytes - pass_dyn - 0.08 * total
+            k = g
+            while k < nP:
+                need, idle = sum(per[:k]), sum(per[g:k])
+                if need >= 0.20 * total or (k > g and idle > idle_budget):
+                    break
+                n, k = k, k + g
+        self.prefill_tape_bytes = sum(per[:n])
+        key = (sum(p.ids.numel() for p in prompts), nP, n, C)
         if key not in self._fit_logged and len(self._fit_logged) < 8:
             self._fit_logged.add(key)
             import sys
-            print(f"[spacer_amd] prefill tape ({need / 1e9:.1f} GB for {toks} prompt tokens, {patches} patches) "
-                  f"{'kept for' if fits else 'NOT kept for'} the policy's scoring pass: {avail / 1e9:.0f} GB beside the training state", file=sys.stderr)
-        return fits
+            print(f"[spacer_amd] prefill tape: {n} of {nP} prompts keep theirs for the policy's scoring pass ({sum(per[:n]) / 1e9:.1f} of "
+                  f"{sum(per) / 1e9:.1f} GB; {avail / 1e9:.0f} GB beside the training state, {g} prompt(s) per scoring pass of <= {C} tokens "
+                  f"per rollout)", file=sys.stderr)
+        return n
 
-    def _prefill(self, prompts: List[PromptInput], era_rule: bool, keep_tape: bool = False):
+    def _prefill(self, prompts: List[PromptInput], era_rule: bool, keep_tape: bool = False, out=None):
         """ViT + LLM prefill of ALL prompts as one token-packed pass (one attention segment per prompt, one set of GEMMs
         with M = total prompt tokens): the reference runs this per rollout inside HF generate (TR:463).  ``keep_tape``: the pass
-        is taped like a scoring pass and every prompt receives its ``PrefillSlice``."""
+        is taped like a scoring pass and every prompt receives its ``PrefillSlice``.  ``out`` = (pk, pv, p0): write the prompt KV of
+        these prompts into slots [p0, p0 + len(prompts)) of caches allocated by the caller (a taped and an untaped pass over two
+        parts of the batch share one cache)."""
         cfg, e = self.cfg, self.e
         L, Hkv, D = cfg.layers, cfg.kv_heads, cfg.head_dim
         nP = len(prompts)
         plen = [p.ids.numel() for p in prompts]
-        Pmax = max(plen)
         starts = [0]
         for P in plen[:-1]:
             starts.append(starts[-1] + P)
-        pk = torch.empty(L, nP, Pmax, Hkv, D, device=self.dev, dtype=BF16)
-        pv = torch.empty_like(pk)
+        if out is None:
+            Pmax = max(plen)
+            pk = torch.empty(L, nP, Pmax, Hkv, D, device=self.dev, dtype=BF16)
+            pv = torch.empty_like(pk)
+        else:
+            pk, pv = out[0][:, out[2]:out[2] + nP], out[1][:, out[2]:out[2] + nP]        # [L, nP, Pmax, Hkv, D] views
+            Pmax = pk.shape[2]
         # packed row of every (prompt, position) slot of the prompt KV cache; slots past a prompt's length are never read
         # (the attention kernels stop at plen) and take row 0
         gidx = torch.zeros(nP, Pmax, dtype=torch.int32)
@@ -312,13 +342,22 @@ class RolloutEngine:
             pr.prefill = None
         keep = self.keep_prefill_tape() if callable(self.keep_prefill_tape) else self.keep_prefill_tape
         eligible = (not self.e.recompute and cfg.vit_kind == "qwen2" and all((p.pix is None) == (prompts[0].pix is None) for p in prompts))
+        n_keep = 0
         if keep is not False and eligible:
-            fits = self._tape_fits(prompts)               # (also records the tape's estimated size)
-            keep = fits if keep is None else keep
-        keep = bool(keep) and eligible
-        if not keep:
+            n_auto = self._tape_keep_count(prompts, counts, C)       # (also records the kept tape's estimated size)
+            n_keep = n_auto if keep is None else len(prompts)
+        if n_keep == 0:
             self.prefill_tape_bytes = 0
-        pk, pv, first_logits, plen, pos_base = self._prefill(prompts, sp.era_rule, keep_tape=keep)
+        if n_keep in (0, len(prompts)):
+            pk, pv, first_logits, plen, pos_base = self._prefill(prompts, sp.era_rule, keep_tape=n_keep > 0)
+        else:
+            # the first n_keep prompts as a taped pass, the others as an untaped one, into one prompt-KV cache
+            Pmax_all = max(p.ids.numel() for p in prompts)
+            pk = torch.empty(cfg.layers, len(prompts), Pmax_all, cfg.kv_heads, cfg.head_dim, device=dev, dtype=BF16)
+            pv = torch.empty_like(pk)
+            _, _, fl_a, plen_a, pb_a = self._prefill(prompts[:n_keep], sp.era_rule, keep_tape=True, out=(pk, pv, 0))
+            _, _, fl_b, plen_b, pb_b = self._prefill(prompts[n_keep:], sp.era_rule, keep_tape=False, out=(pk, pv, n_keep))
+            first_logits, plen, pos_base = torch.cat([fl_a, fl_b], 0), plen_a + plen_b, pb_a + pb_b
         if ev:
             ev[1].record()
         L, Hkv, D, H = cfg.layers, cfg.kv_heads, cfg.head_dim, cfg.hidden

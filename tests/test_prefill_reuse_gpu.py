@@ -123,3 +123,63 @@ def test_step_with_and_without_reuse(dev):
     assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
     assert res[True][2] == res[False][2] and res[True][3] == res[False][3]
     assert float((res[True][4].float() - res[False][4].float()).abs().max()) <= 1e-6
+
+
+def test_partly_kept_tape_whole_passes_from_the_front(dev, monkeypatch):
+    """Round 6: when the whole prefill tape does not fit, the first passes' prompts keep theirs (RolloutEngine._tape_keep_count) -- the
+    batch runs as a taped and an untaped prefill pass into ONE prompt-KV cache.  (i) the decision: whole passes from the front, never a
+    proper subset that is not a multiple of the pass size, all prompts when the whole tape is small; (ii) the rollouts equal the one-pass
+    prefill's (same greedy tokens), only the first n prompts carry a slice; (iii) a scoring pass over kept prompts reuses the tape with
+    the recompute pass's log-probs, a pass over the others recomputes."""
+    g = load_tiny()
+    params = FlatParams.empty(TINY, dev)
+    load_state_dict(params, g["w"])
+    eng = Qwen2VLEngine(TINY, params)
+    roll = RolloutEngine(eng)
+    pixs = [K.patchify(g["frames"].roll(i, 0).contiguous().to(dev), kpad=TINY.patch_kpad) for i in range(5)]
+    def mk():
+        return [PromptInput(g["prompt"].to(dev), pixs[i][0], [tuple(pixs[i][1])]) for i in range(5)]       # same text, other frames
+    # (i) the static rule on a pretend device: sizes from the tiny model, "memory" chosen around them
+    prompts = mk()
+    roll.keep_prefill_tape, roll.prefill_pass_size = None, 2
+    class Props:
+        total_memory = 0
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda d: Props)
+    assert roll._tape_keep_count(prompts) == 0                       # (no memory: nothing is kept)
+    Props.total_memory = 10 ** 15
+    assert roll._tape_keep_count(prompts) == 5
+    one = roll.prefill_tape_bytes / 5.0                              # bytes per prompt
+    # (never 1 or 3: whole passes of 2)
+    for mem, want in ((40, 5), (25, 4), (14, 2), (8, 0)):
+        roll._fit_logged.clear()
+        Props.total_memory = int(mem * one)
+        assert roll._tape_keep_count(prompts) == want, (mem, want)
+    # whole tape: 4 x 5 < total and 5 < 0.15 total -> total > 33.4 prompts' worth.  Else whole passes of 2 from the front: the first pass
+    # whenever 2 < 0.2 total; the first 4 when the idle share fits (static + largest pass 2 + idle 2 + 0.08 total <= total) and 4 < 0.2 total
+    roll.static_bytes = int(20 * one)                                # the training state beside the tape
+    Props.total_memory = int(25 * one)
+    assert roll._tape_keep_count(prompts) == 2                       # (20 + 2 + idle 2 + 2 > 25: only the first pass's prompts)
+    roll.static_bytes = 0
+    roll._fit_logged.clear()
+    assert roll._tape_keep_count(prompts, [2] * 5, 0) == 4 and roll._tape_keep_count(prompts, [2] * 5, 10 ** 7) == 2   # long rollouts: larger passes
+    monkeypatch.undo()
+    # (ii) + (iii) with the count forced to 2 of 5
+    sp = SamplingParams(max_new_tokens=5, top_k=1, top_p=1.0, suppress_eos=True)
+    with K.plan(gemm_no_split=1, gemm_tile=256, skinny_blocks=1):
+        roll.keep_prefill_tape = False
+        base_prompts = mk()
+        base = roll.generate(base_prompts, 2, sp, use_graph=False)
+        roll.keep_prefill_tape = None
+        monkeypatch.setattr(roll, "_tape_keep_count", lambda ps, counts=None, C=0: 2)
+        prompts = mk()
+        out = roll.generate(prompts, 2, sp, use_graph=False)
+        assert [p.prefill is not None for p in prompts] == [True, True, False, False, False]
+        assert prompts[0].prefill.shared is prompts[1].prefill.shared and prompts[1].prefill.index == 1
+        assert torch.equal(out, base)
+        comps = [out[2 * i:2 * i + 2] for i in range(5)]
+        _compare(eng, prompts[:2], comps[:2])
+        entries = [(p.ids, p.pix, p.grids) for p in prompts[2:4]]
+        t = {}
+        eng.score_groups(entries, comps[2:4], tape=t, prefill=None)
+        assert not t["reused_prefill"]
+
