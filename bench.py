@@ -572,6 +572,7 @@ def main():
     tok_stats.update(scored=0, rectangle=0)
     elapsed, own_ms = timed(args.steps, args.warmup)
     tok_main = dict(tok_stats)
+    main_tape = (round(ge.roll.prefill_tape_bytes / 1e9, 1), int(ge.roll.prefill_tape_prompts))      # of the timed region's last rollout
     K.PROFILER.enabled = False
     comm = ge.comm_stats(args.steps)
     ge.comm_timing(False)
@@ -757,7 +758,7 @@ def main():
                        "global_batch": groups * Kgen * world, "parallelism": f"dp{world}", "decode_graph": not args.no_graph,
                        "grad_comm": args.grad_comm, "grad_algo": args.grad_algo, "overlap_comm": not args.no_overlap, "backend": args.backend, "groups_per_pass": max(1, min(gpp_default, groups)),
                        "rccl_world": world, "recompute": bool(args.recompute), "precise_logps": bool(args.precise_logps),
-                       "reuse_prefill": args.reuse_prefill, "prefill_tape_kept": bool(reuse_seen[0]), "prefill_tape_gb": round(ge.roll.prefill_tape_bytes / 1e9, 1),
+                       "reuse_prefill": args.reuse_prefill, "prefill_tape_kept": bool(reuse_seen[0]), "prefill_tape_gb": main_tape[0], "prefill_tape_prompts": main_tape[1],
                        "groups_per_gpu": groups,
                        "launch_shape": ("the reference script's own: 1 prompt group (K rollouts) per GPU per step (run_SpaceR_SG_RLVR.sh:21)"
                                         if groups == 1 else f"weak scaling with {groups} prompt groups per GPU per step (decode batch {groups * Kgen} rows); "

@@ -100,6 +100,7 @@ class RolloutEngine:
         # (may also be a callable returning one of those, evaluated per generate call: GRPOEngine ties it to its live hyper-parameters)
         self.keep_prefill_tape = False
         self.prefill_tape_bytes = 0
+        self.prefill_tape_prompts = 0
         # prompts per scoring pass of the caller (GRPOEngine.score_and_backward_multi takes groups_per_pass prompts): when the whole tape
         # does not fit, the auto decision keeps the tape of the FIRST passes' prompts only, in whole passes (round 6; see _tape_keep_count)
         self.prefill_pass_size = 1
@@ -348,6 +349,7 @@ class RolloutEngine:
             n_keep = n_auto if keep is None else len(prompts)
         if n_keep == 0:
             self.prefill_tape_bytes = 0
+        self.prefill_tape_prompts = n_keep               # (of len(prompts), counted from the front)
         if n_keep in (0, len(prompts)):
             pk, pv, first_logits, plen, pos_base = self._prefill(prompts, sp.era_rule, keep_tape=n_keep > 0)
         else:
