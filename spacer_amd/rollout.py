@@ -145,10 +145,10 @@ class RolloutEngine:
         device's memory minus what lives beside the tape for the whole step.
           * all of them when the whole tape is small: 4 x tape < memory beside the training state, tape < 15 % of the device (the scoring
             passes that follow need ~ (K C / P + 1) x the tape of their groups on top of it) -- cfg2, cfg4;
-          * else (round 6) the first pass's prompts -- their tape BECOMES that pass's prompt-side tape, which the pass would allocate
-            anyway: nothing is added to the step's peak -- and further whole passes while the part that idles beside the earlier
-            passes' activations fits: training state + the largest pass's own tape (rectangular: every rollout C tokens) + idle tape
-            + 8 % of the device <= the device; the kept tape under 20 % of the device.  cfg3 at 7B (8 prompts x 12.9 GB, two per pass,
+          * else (round 6) whole passes from the front while what the kept tape adds to the step's peak fits: the first pass's share
+            is copied into that pass's own prompt-side tape (which the pass allocates anyway; both exist for a while: half a share,
+            measured), the later passes' shares idle beside the earlier passes' activations: training state + the largest pass's own
+            tape (rectangular: every rollout C tokens) + that + 7 % of the device <= the device; the kept tape under 20 % of the device.  cfg3 at 7B (8 prompts x 12.9 GB, two per pass,
             C = 512): 4 prompts = 52 GB kept, 26 GB of it idle during pass 0 -- measured HBM peak 237.5 -> 277.3 GB of 309, step 5029 ->
             4903 ms on one box; at the shipped script's C = 1024 with two groups per pass only the first pass's prompts qualify."""
         cfg = self.cfg
@@ -165,11 +165,13 @@ class RolloutEngine:
         else:
             counts = list(counts) if counts is not None else [1] * nP
             pass_dyn = max(sum(per[a:a + g]) + sum(counts[a:a + g]) * C * per_tok for a in range(0, nP, g))
-            idle_budget = total - self.static_bytes - pass_dyn - 0.08 * total
+            idle_budget = total - self.static_bytes - pass_dyn - 0.07 * total
             k = g
             while k < nP:
-                need, idle = sum(per[:k]), sum(per[g:k])
-                if need >= 0.20 * total or (k > g and idle > idle_budget):
+                # (measured: the first pass's share is not free either -- its rows are COPIED into the pass's own tape, so for a while
+                # both exist: cfg5, 1 prompt of 45.8 GB kept, peak + 21.5 GB; cfg3, 4 of 8, + 39.8 GB for 25.9 GB idle: half a share)
+                need, extra = sum(per[:k]), sum(per[g:k]) + 0.5 * sum(per[:g])
+                if need >= 0.20 * total or extra > idle_budget:
                     break
                 n, k = k, k + g
         self.prefill_tape_bytes = sum(per[:n])

@@ -150,18 +150,20 @@ def test_partly_kept_tape_whole_passes_from_the_front(dev, monkeypatch):
     assert roll._tape_keep_count(prompts) == 5
     one = roll.prefill_tape_bytes / 5.0                              # bytes per prompt
     # (never 1 or 3: whole passes of 2)
-    for mem, want in ((40, 5), (25, 4), (14, 2), (8, 0)):
+    for mem, want in ((40, 5), (25, 4), (14, 2), (8, 0)):            # (25: 2 + (2 + 1) + 2 <= 25; 14: 4 >= 0.2 x 14; 8: 2 >= 0.2 x 8)
         roll._fit_logged.clear()
         Props.total_memory = int(mem * one)
         assert roll._tape_keep_count(prompts) == want, (mem, want)
-    # whole tape: 4 x 5 < total and 5 < 0.15 total -> total > 33.4 prompts' worth.  Else whole passes of 2 from the front: the first pass
-    # whenever 2 < 0.2 total; the first 4 when the idle share fits (static + largest pass 2 + idle 2 + 0.08 total <= total) and 4 < 0.2 total
+    # whole tape: 4 x 5 < total and 5 < 0.15 total -> total > 33.4 prompts' worth.  Else whole passes of 2 from the front while
+    # static + largest pass (2) + half the first pass's share (1) + the idle shares + 0.07 total <= total and the kept tape < 0.2 total
     roll.static_bytes = int(20 * one)                                # the training state beside the tape
-    Props.total_memory = int(25 * one)
-    assert roll._tape_keep_count(prompts) == 2                       # (20 + 2 + idle 2 + 2 > 25: only the first pass's prompts)
+    Props.total_memory = int(24.5 * one)
+    assert roll._tape_keep_count(prompts) == 0                       # (20 + largest pass 2 + half a share 1 + 0.07 x 24.5 > 24.5: nothing)
+    Props.total_memory = int(26 * one)
+    assert roll._tape_keep_count(prompts) == 2                       # (20 + 2 + 1 + 1.82 <= 26, but + 2 more idle does not: the first pass only)
     roll.static_bytes = 0
     roll._fit_logged.clear()
-    assert roll._tape_keep_count(prompts, [2] * 5, 0) == 4 and roll._tape_keep_count(prompts, [2] * 5, 10 ** 7) == 2   # long rollouts: larger passes
+    assert roll._tape_keep_count(prompts, [2] * 5, 0) == 4 and roll._tape_keep_count(prompts, [2] * 5, 10 ** 7) == 0   # long rollouts: larger passes
     monkeypatch.undo()
     # (ii) + (iii) with the count forced to 2 of 5
     sp = SamplingParams(max_new_tokens=5, top_k=1, top_p=1.0, suppress_eos=True)
