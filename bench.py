@@ -480,6 +480,7 @@ def main():
         prompts = [make_prompt(cfg, rank * groups + g, F, Hpx, Wpx, n_text, dev, frames_u8=frames[g])[0] for g in range(groups)]
         gpp = max(1, min(groups_per_pass or gpp_default, groups))
         ge.roll.prefill_pass_size = gpp           # a partly kept prefill tape is kept in whole scoring passes (RolloutEngine._tape_keep_count)
+        ge.roll.prefill_scored = groups           # (the T-GRPO twins behind the scored prompts keep none)
         scomp = None
         if temporal:                              # the shuffled twin: same text, temporally permuted frames
             sprompts = []

@@ -386,6 +386,7 @@ class SGRLVRTrainer:
         # (a token-step costs 4.87 instead of 5.47 ms; until round 6 every prompt decoded G rows and the twins' surplus was dropped)
         sg, n_main = self.shuffled_num_generations, len(preps)
         counts = [G] * n_main + [sg] * (len(prompts) - n_main)
+        self.engine.roll.prefill_scored = n_main          # (the twins behind them are never scored: no tape kept for them)
         ids = self._generate(prompts, counts if len(prompts) > n_main else G, sp)
         host = ids.cpu()       # ONE device-to-host copy for the step, taken when the decode loop has just ended: the reward
         #                        functions read it while the scoring passes run (no sync inside the scoring phase)

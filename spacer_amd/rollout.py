@@ -104,6 +104,7 @@ class RolloutEngine:
         # prompts per scoring pass of the caller (GRPOEngine.score_and_backward_multi takes groups_per_pass prompts): when the whole tape
         # does not fit, the auto decision keeps the tape of the FIRST passes' prompts only, in whole passes (round 6; see _tape_keep_count)
         self.prefill_pass_size = 1
+        self.prefill_scored = None       # how many prompts, from the front, will be scored at all (T-GRPO twins behind them are not); None = all
         self.static_bytes = 0            # bytes that live beside the tape for the whole step (GRPOEngine: the training state); see _tape_keep_count
         self._fit_logged = set()
 
@@ -166,8 +167,8 @@ class RolloutEngine:
             counts = list(counts) if counts is not None else [1] * nP
             pass_dyn = max(sum(per[a:a + g]) + sum(counts[a:a + g]) * C * per_tok for a in range(0, nP, g))
             idle_budget = total - self.static_bytes - pass_dyn - 0.07 * total
-            k = g
-            while k < nP:
+            k, n_scored = g, min(nP, int(self.prefill_scored)) if self.prefill_scored else nP
+            while k < nP and k <= n_scored:
                 # (measured: the first pass's share is not free either -- its rows are COPIED into the pass's own tape, so for a while
                 # both exist: cfg5, 1 prompt of 45.8 GB kept, peak + 21.5 GB; cfg3, 4 of 8, + 39.8 GB for 25.9 GB idle: half a share)
                 need, extra = sum(per[:k]), sum(per[g:k]) + 0.5 * sum(per[:g])
